@@ -1,0 +1,116 @@
+/*
+ * pcrl.h -- C ABI of libpcrl_hip.so, the MI355X (gfx950) implementation of the
+ * point-cloud actor-critic hot path of lz1oceani/pointcloud_rl.
+ *
+ * The reference has no FFI on this path: it is pure Python on stock ATen ops
+ * (SURVEY.md section 2.1).  This header is therefore the boundary a maintainer
+ * would bind with ctypes from the reference's own modules;
+ * each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative PCRL_E_* code otherwise;
+ *    pcrl_last_error() returns a thread-local message for the last failure;
+ *  - all pointers except descriptor structs are DEVICE pointers; nothing is
+ *    allocated, freed or retained by the library; scratch is caller-provided;
+ *  - `stream` is a hipStream_t passed as void*; all work is asynchronous on it,
+ *    no call synchronises;
+ *  - tensors are dense row-major unless strides are given (strides in elements).
+ */
+#ifndef PCRL_H_
+#define PCRL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCRL_OK 0
+#define PCRL_E_ARG (-1)         /* invalid argument / unsupported shape */
+#define PCRL_E_WORKSPACE (-2)   /* workspace too small */
+#define PCRL_E_LAUNCH (-3)      /* HIP launch / runtime error */
+
+#define PCRL_MAX_SEG 4
+#define PCRL_MAX_CHANNELS 16
+
+enum { PCRL_DT_F32 = 0, PCRL_DT_U8 = 1, PCRL_DT_BOOL = 2 };
+
+/* One observation key ("xyz", "rgb", "pos_encoding", "seg") of the batched
+ * observation dict the reference feeds PointCloudBase.preprocess
+ * (pyrl/networks/backbones/pointnet.py:49-73).  Planar [B, channels, N] uses
+ * stride_b = channels*N, stride_c = N, stride_n = 1; an interleaved [B, N, C]
+ * tensor uses stride_b = N*C, stride_c = 1, stride_n = C. */
+typedef struct pcrl_feat_seg {
+    const void* ptr;
+    int32_t dtype;     /* PCRL_DT_* */
+    int32_t channels;
+    int32_t div255;    /* 1: value / 255.0f (uint8 rgb, pointnet.py:57-58) */
+    int32_t _pad;
+    int64_t stride_b, stride_c, stride_n;
+} pcrl_feat_seg;
+
+/* A batch of B clouds of N points; channels are the concatenation of the
+ * segments in order (torch.cat(feature, dim=-2), pointnet.py:63).  Segment 0
+ * must be xyz (3 channels, f32) when an augmentation is requested. */
+typedef struct pcrl_cloud_desc {
+    int32_t B, N, nseg, _pad;
+    pcrl_feat_seg seg[PCRL_MAX_SEG];
+} pcrl_cloud_desc;
+
+/* DrQ point-cloud augmentations fused into the encoder's load
+ * (pyrl/utils/augmentations/pcd_aug.py).  flags is an OR of PCRL_AUG_*.
+ *  JITTER  : xyz += noise, noise either explicit (jitter_noise [B,3,N] f32, the
+ *            tensor RandomJitterPoints.process_single draws, pcd_aug.py:318) or,
+ *            when jitter_noise == NULL, Philox4x32-10 U(lo,hi) keyed by
+ *            (seed, offset) -- one draw per (b, axis, n).
+ *  AFFINE  : xyz = M[b] (3x4, row-major) applied as R x + t
+ *            (GlobalRotScaleTrans.process_single -> apply_rot_trans,
+ *            pcd_aug.py:178-215, 84-123); M is built by the host class.
+ * Order when both are set: AFFINE first, then JITTER. */
+enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2 };
+typedef struct pcrl_aug_desc {
+    int32_t flags, _pad;
+    const float* jitter_noise;
+    float jitter_lo, jitter_hi;
+    uint64_t seed, offset;
+    const float* affine;
+} pcrl_aug_desc;
+
+/* Weights of the shared per-point MLP in the reference's own state_dict layout
+ * (ConvMLP built by PointNet.__init__, pointnet.py:106-109; mlp.py:43-56):
+ *   conv0.weight [c1,C,1] conv0.bias [c1] ; conv1.weight [c2,c1,1] norm1.{weight,bias} [c2] ;
+ *   conv2.weight [c3,c2,1] norm2.{weight,bias} [c3] ; LN eps (1e-6 in every shipped config). */
+typedef struct pcrl_encoder_weights {
+    int32_t c_in, c1, c2, c3;
+    const float *w0, *b0, *w1, *g1, *be1, *w2, *g2, *be2;
+    float eps;
+    int32_t _pad;
+} pcrl_encoder_weights;
+
+const char* pcrl_last_error(void);
+int pcrl_version(void);
+
+/* Bytes needed for the MFMA-operand-ordered weight image and for the forward
+ * scratch (cross-workgroup partial maxima when a cloud is split). */
+int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes);
+int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3, size_t* bytes);
+
+/* Re-order the weights into the operand order the forward kernel streams.
+ * Must be re-run whenever the weights change (after every optimizer step). */
+int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream);
+
+/* Fused PointNet encoder forward, fp32:
+ *   preprocess (pointnet.py:49-73) -> [augment] -> conv0+ReLU -> conv1+LN1d+ReLU ->
+ *   conv2+LN1d+ReLU (mlp.py:43-56, nn_layer.py:207-219) -> max over N with first-index
+ *   argmax (pointnet.py:151).
+ * pooled [B,c3] f32, argmax [B,c3] int32 (the index torch's autograd keeps as int64). */
+int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug /* may be NULL */,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         float* pooled, int32_t* argmax,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRL_H_ */

@@ -1,0 +1,64 @@
+"""ctypes binding of libpcrl_hip.so (the C ABI declared in include/pcrl.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C pointcloud_rl_amd/csrc``.
+There is no CPU fallback: if the shared object is missing, loading raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcrl_hip.so")
+
+PCRL_MAX_SEG = 4
+PCRL_MAX_CHANNELS = 16
+DT_F32, DT_U8, DT_BOOL = 0, 1, 2
+AUG_JITTER, AUG_AFFINE = 1, 2
+
+
+class FeatSeg(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("div255", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("stride_b", ctypes.c_int64), ("stride_c", ctypes.c_int64), ("stride_n", ctypes.c_int64)]
+
+
+class CloudDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("nseg", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("seg", FeatSeg * PCRL_MAX_SEG)]
+
+
+class AugDesc(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_int32), ("_pad", ctypes.c_int32), ("jitter_noise", ctypes.c_void_p),
+                ("jitter_lo", ctypes.c_float), ("jitter_hi", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p)]
+
+
+class EncoderWeights(ctypes.Structure):
+    _fields_ = [("c_in", ctypes.c_int32), ("c1", ctypes.c_int32), ("c2", ctypes.c_int32), ("c3", ctypes.c_int32),
+                ("w0", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("g1", ctypes.c_void_p),
+                ("be1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("g2", ctypes.c_void_p), ("be2", ctypes.c_void_p),
+                ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
+
+
+class PcrlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libpcrl_hip.so once.  Raises if it has not been built -- the product has no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PcrlError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C pointcloud_rl_amd/csrc)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.pcrl_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PcrlError(f"pcrl error {rc}: {lib().pcrl_last_error().decode(errors='replace')}")

@@ -1,0 +1,97 @@
+// Internal helpers shared by the HIP translation units of libpcrl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pcrl.h"
+
+namespace pcrl {
+
+// Records a thread-local error message and returns `code` (see pcrl_last_error()).
+int fail(int code, const char* fmt, ...);
+// Number of compute units of the current device (cached).
+int num_cus();
+
+#define PCRL_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return ::pcrl::fail(PCRL_E_LAUNCH, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define PCRL_CHECK_LAUNCH(name)                                                               \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) return ::pcrl::fail(PCRL_E_LAUNCH, "launch %s: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 32x32 MFMA accumulator geometry -------------------------------------------------
+// v_mfma_f32_32x32x2_f32: lane l holds column (l & 31); register r of the tile holds row
+// (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).  With output channels on rows and points on
+// columns, accumulator slot R = 16 * block + r of lane-half h holds channel acc_chan(R, h)
+// of point (l & 31) -- which is exactly the B-operand layout of k-step R of the next
+// layer (B[k = l >> 5][j = l & 31]), so activations never leave registers between layers.
+__host__ __device__ constexpr int acc_chan(int R, int h) {
+    return 32 * (R >> 4) + ((R & 15) & 3) + 8 * ((R & 15) >> 2) + 4 * h;
+}
+
+// Offsets (in floats) inside the packed weight image, shared by pack kernel, forward and backward.
+struct PackedLayout {
+    int T0, C1, C2, C3;
+    __host__ __device__ constexpr int w0() const { return 0; }                       // [C1/32][T0][64]
+    __host__ __device__ constexpr int b0() const { return w0() + (C1 / 32) * T0 * 64; }  // [C1]
+    __host__ __device__ constexpr int w1() const { return align4(b0() + C1); }       // [C2/32][C1/8][64][4]
+    __host__ __device__ constexpr int ln1() const { return w1() + C2 * C1; }         // [C2][2] (gamma, beta)
+    __host__ __device__ constexpr int w2() const { return align4(ln1() + 2 * C2); }  // [C3/32][C2/8][64][4]
+    __host__ __device__ constexpr int ln2() const { return w2() + C3 * C2; }         // [C3][2]
+    __host__ __device__ constexpr int total() const { return align4(ln2() + 2 * C3); }
+    __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
+};
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// ReLU that propagates NaN and maps -0 to +0 (torch.relu semantics).
+__device__ __forceinline__ float relu_nan(float x) { return !(x <= 0.0f) ? x : 0.0f; }
+
+// Values of lane (l & 31) in the low half and in the high half of the wave, in every lane:
+// v_permlane32_swap exchanges vdst[32..63] with vsrc[0..31].
+__device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+    lo = u2f(r[0]);
+    hi = u2f(r[1]);
+}
+
+// Max over the 32 lanes of each wave half, result in every lane, unsigned compare.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned allreduce_umax32(unsigned v) {
+    v = umax_(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = umax_(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = umax_(v, dpp_u<0x141>(v));   // row_half_mirror
+    v = umax_(v, dpp_u<0x140>(v));   // row_mirror
+    v = umax_(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));  // lane ^ 16
+    return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011); one call yields four 32-bit words.
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// U[lo, hi) from a 32-bit word with 24 bits of mantissa.
+__host__ __device__ inline float u01_to_range(uint32_t w, float lo, float hi) {
+    return lo + (float)(w >> 8) * (1.0f / 16777216.0f) * (hi - lo);
+}
+
+}  // namespace pcrl

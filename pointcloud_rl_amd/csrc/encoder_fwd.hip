@@ -1,0 +1,452 @@
+// Fused PointNet encoder forward for gfx950 (MI355X), fp32.
+//
+// Replaces, per call, the reference's op sequence
+//   PointCloudBase.preprocess (pyrl/networks/backbones/pointnet.py:49-73)
+//   [RandomJitterPoints / GlobalRotScaleTrans (pyrl/utils/augmentations/pcd_aug.py:306-327, 125-227)]
+//   ConvMLP: Conv1d(k=1)+ReLU, Conv1d+LN1d+ReLU, Conv1d+LN1d+ReLU (mlp.py:43-56, nn_layer.py:207-219)
+//   feature.max(-1) (pointnet.py:151)
+// with one kernel that never materialises a [B, c, N] activation.
+//
+// Mapping to CDNA4.  One wave owns a tile of 32 points.  Output channels are MFMA rows,
+// points are MFMA columns (v_mfma_f32_32x32x2_f32, exact f32 fma chains).  The accumulator
+// layout of a layer (lane = point, register = channel) is already the B-operand layout of
+// the next layer's k-steps, so the three layers chain in registers; only the weights
+// stream, as A operands: conv2 from LDS (128 KB image, loaded once per workgroup), conv1
+// from L1/L2 in 1 KB lane-linear pieces.  Per-point LayerNorm is an in-lane sum plus one
+// v_permlane32_swap.  The symmetric max-pool is a DPP max over the 32 lanes of a half-wave
+// followed by one ds_max_u64 on a {value bits, ~point index} key per winning lane, which
+// gives torch's first-index tie rule for free and merges the 8 waves of the workgroup.
+#include "common.h"
+
+namespace pcrl {
+
+struct ChanSrc {
+    const void* base;     // already offset to this channel
+    long long stride_b;   // elements
+    long long stride_n;   // elements
+    int dtype;            // PCRL_DT_*
+    int div255;
+};
+
+struct FwdParams {
+    int B, N, C, S;
+    int tiles_total, tiles_per_seg;
+    int aug_flags;
+    float jitter_lo, jitter_hi, eps;
+    const float* jitter_noise;
+    const float* affine;
+    unsigned long long seed, offset;
+    const float* packed;
+    float* pooled;
+    int* argmax;
+    unsigned long long* partial;   // [B][S][C3] keys when S > 1
+    ChanSrc ch[PCRL_MAX_CHANNELS];
+};
+
+// Channel descriptors are staged in LDS (not SGPRs: 16 x 32 B of kernel arguments would stay
+// live across the whole tile body).  All lanes read the same descriptor; the dtype flags are
+// made scalar again so the branches stay wave-uniform.
+__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n) {
+    const ChanSrc d = s_desc[c];
+    const long long off = (long long)b * d.stride_b + (long long)n * d.stride_n;
+    const int dtype = __builtin_amdgcn_readfirstlane(d.dtype);
+    const int div255 = __builtin_amdgcn_readfirstlane(d.div255);
+    float v;
+    if (dtype == PCRL_DT_F32) {
+        v = static_cast<const float*>(d.base)[off];
+    } else {
+        v = (float)static_cast<const unsigned char*>(d.base)[off];
+        if (dtype == PCRL_DT_BOOL) v = v != 0.0f ? 1.0f : 0.0f;
+    }
+    if (div255) v = v / 255.0f;
+    return v;
+}
+
+// Per-point LayerNorm (biased variance, eps inside the sqrt, affine) + ReLU on an
+// accumulator set, statistics in the canonical order documented in oracle/pcrl_oracle.c.
+// Returns true for a point whose variance is NaN (all outputs NaN).
+template <int C, bool INT_RELU>
+__device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
+    constexpr int MB = C / 32;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            p0 = p0 + a[mb][r + 0]; p1 = p1 + a[mb][r + 1];
+            p2 = p2 + a[mb][r + 2]; p3 = p3 + a[mb][r + 3];
+        }
+    }
+    float lo, hi;
+    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    const float mean = (lo + hi) / (float)C;
+    p0 = p1 = p2 = p3 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            float d0 = a[mb][r + 0] - mean, d1 = a[mb][r + 1] - mean;
+            float d2 = a[mb][r + 2] - mean, d3 = a[mb][r + 3] - mean;
+            p0 = __builtin_fmaf(d0, d0, p0); p1 = __builtin_fmaf(d1, d1, p1);
+            p2 = __builtin_fmaf(d2, d2, p2); p3 = __builtin_fmaf(d3, d3, p3);
+        }
+    }
+    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    const float var = (lo + hi) / (float)C;
+    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+            const float2 gb = reinterpret_cast<const float2*>(s_ln)[ch];
+            const float y = __builtin_fmaf((a[mb][r] - mean) * rstd, gb.x, gb.y);
+            if (INT_RELU) {
+                const int yi = __builtin_bit_cast(int, y);
+                a[mb][r] = __builtin_bit_cast(float, yi > 0 ? yi : 0);
+            } else {
+                a[mb][r] = relu_nan(y);
+            }
+        }
+    }
+    return var != var;
+}
+
+template <int T0, int C1, int C2, int C3>
+__global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
+    constexpr PackedLayout L{T0, C1, C2, C3};
+    constexpr int MB1 = C1 / 32, MB2 = C2 / 32, MB3 = C3 / 32;
+    // LDS image: small tables first (DS instructions carry a 16-bit offset, so everything that is
+    // addressed with per-register constants must sit below 64 KB), the 128 KB conv2 image last.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_desc + PCRL_MAX_CHANNELS);
+    float* s_ln1 = reinterpret_cast<float*>(s_keys + C3);
+    float* s_ln2 = s_ln1 + 2 * C2;
+    float* s_b0 = s_ln2 + 2 * C3;
+    float* s_w0 = s_b0 + C1;
+    float* s_w2 = s_w0 + MB1 * T0 * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+
+    {   // prologue: weights -> LDS, once per workgroup
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
+        f32x4* s = reinterpret_cast<f32x4*>(s_w2);
+        for (int i = tid; i < C3 * C2 / 4; i += 512) s[i] = g[i];
+        for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
+        for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
+        for (int i = tid; i < 2 * C2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
+        for (int i = tid; i < 2 * C3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
+        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.ch[tid];
+    }
+    const f32x4* g_w1 = reinterpret_cast<const f32x4*>(p.packed + L.w1());
+    const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
+
+    for (int work = blockIdx.x; work < p.B * p.S; work += gridDim.x) {
+        const int b = work / p.S, seg = work - b * p.S;
+        const int t_begin = seg * p.tiles_per_seg;
+        const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
+        __syncthreads();   // previous read-out of s_keys (and the prologue) is complete
+        for (int i = tid; i < C3; i += 512) s_keys[i] = 0ull;
+        __syncthreads();
+
+        for (int tile = t_begin + wave; tile < t_end; tile += 8) {
+            const int pidx = tile * 32 + l31;
+            const bool valid = pidx < p.N;
+            const int pc = valid ? pidx : p.N - 1;
+
+            // ---- preprocess (+ augmentation) ---------------------------------------------
+            f32x16 x;
+#pragma unroll
+            for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, pc) : 0.0f;
+            if (p.aug_flags & PCRL_AUG_AFFINE) {
+                const float* M = p.affine + (long long)b * 12;
+                const float x0 = x[0], x1 = x[1], x2 = x[2];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    x[j] = ((M[4 * j + 0] * x0 + M[4 * j + 1] * x1) + M[4 * j + 2] * x2) + M[4 * j + 3];
+            }
+            if (p.aug_flags & PCRL_AUG_JITTER) {
+                if (p.jitter_noise) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[((long long)b * 3 + j) * p.N + pc];
+                } else {
+                    const unsigned long long e = (unsigned long long)b * p.N + pc;
+                    uint32_t w[4];
+                    philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32),
+                                  (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) x[j] = x[j] + u01_to_range(w[j], p.jitter_lo, p.jitter_hi);
+                }
+            }
+
+            // ---- conv0 + bias + ReLU ------------------------------------------------------
+            f32x16 a0[MB1];
+#pragma unroll
+            for (int mb = 0; mb < MB1; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const float bop = half ? x[2 * t + 1] : x[2 * t];
+                    a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = relu_nan(a0[mb][r]);
+            }
+
+            // ---- conv1 + LN + ReLU --------------------------------------------------------
+            f32x16 a1[MB2];
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
+#pragma unroll
+                for (int tq = 0; tq < C1 / 8; ++tq) {
+                    const f32x4 w = g_w1[(mb * (C1 / 8) + tq) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int t = 4 * tq + j;
+                        a1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a0[t >> 4][t & 15], a1[mb], 0, 0, 0);
+                    }
+                }
+            }
+            ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
+
+            // ---- conv2 + LN + ReLU --------------------------------------------------------
+            f32x16 a2[MB3];
+#pragma unroll
+            for (int mb = 0; mb < MB3; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a2[mb][r] = 0.0f;
+#pragma unroll
+                for (int tq = 0; tq < C2 / 8; ++tq) {
+                    const f32x4 w = s_w2v[(mb * (C2 / 8) + tq) * 64 + lane];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int t = 4 * tq + j;
+                        a2[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a1[t >> 4][t & 15], a2[mb], 0, 0, 0);
+                    }
+                }
+            }
+            const bool nan_pt = ln_relu_acc<C3, true>(a2, s_ln2, half, p.eps);
+            if (__builtin_expect(__ballot(nan_pt) != 0ull, 0)) {
+                // torch: a NaN wins the max and the first NaN's index is returned
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (nan_pt) a2[mb][r] = u2f(0xFFFFFFFFu);
+            }
+
+            // ---- symmetric max-pool with first-index argmax --------------------------------
+            const unsigned inv_idx = ~(unsigned)pidx;
+#pragma unroll
+            for (int mb = 0; mb < MB3; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned v = f2u(a2[mb][r]);
+                    const unsigned m = allreduce_umax32(v);
+                    // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.
+                    // An all-zero channel ties everywhere: only the tile's first point needs to report.
+                    if (valid && v == m && (m != 0u || l31 == 0)) {
+                        const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                        atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C3; c += 512) {
+            const unsigned long long key = s_keys[c];
+            if (p.S == 1) {
+                unsigned vb = (unsigned)(key >> 32);
+                if (vb > 0x7F800000u) vb = 0x7FC00000u;
+                p.pooled[(long long)b * C3 + c] = u2f(vb);
+                p.argmax[(long long)b * C3 + c] = (int)~(unsigned)key;
+            } else {
+                p.partial[((long long)b * p.S + seg) * C3 + c] = key;
+            }
+        }
+    }
+}
+
+// Second stage of the split-cloud pool: max over the S partial keys of a cloud.
+__global__ void encoder_merge_kernel(const unsigned long long* __restrict__ partial, int B, int S, int C3,
+                                     float* __restrict__ pooled, int* __restrict__ argmax) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * C3) return;
+    const int b = (int)(i / C3), c = (int)(i - (long long)b * C3);
+    unsigned long long key = 0ull;
+    for (int s = 0; s < S; ++s) {
+        const unsigned long long k = partial[((long long)b * S + s) * C3 + c];
+        key = k > key ? k : key;
+    }
+    unsigned vb = (unsigned)(key >> 32);
+    if (vb > 0x7F800000u) vb = 0x7FC00000u;
+    pooled[i] = u2f(vb);
+    argmax[i] = (int)~(unsigned)key;
+}
+
+// Weights (reference state_dict layout) -> operand order.  One thread per packed float.
+__global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __restrict__ out) {
+    const PackedLayout L{T0, w.c1, w.c2, w.c3};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.total()) return;
+    float v = 0.0f;
+    if (i < L.b0()) {                       // conv0: [mb][t][lane], natural k order, zero padded
+        const int e = i - L.w0(), ln = e & 63, t = (e >> 6) % T0, mb = (e >> 6) / T0;
+        const int row = 32 * mb + (ln & 31), k = 2 * t + (ln >> 5);
+        v = k < w.c_in ? w.w0[row * w.c_in + k] : 0.0f;
+    } else if (i < L.b0() + w.c1) {
+        v = w.b0[i - L.b0()];
+    } else if (i >= L.w1() && i < L.ln1()) { // conv1: [mb][tq][lane][4]
+        const int e = i - L.w1(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c1 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(4 * tq + j, ln >> 5)];
+    } else if (i >= L.ln1() && i < L.ln1() + 2 * w.c2) {
+        const int e = i - L.ln1();
+        v = (e & 1) ? w.be1[e >> 1] : w.g1[e >> 1];
+    } else if (i >= L.w2() && i < L.ln2()) { // conv2: [mb][tq][lane][4]
+        const int e = i - L.w2(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(4 * tq + j, ln >> 5)];
+    } else if (i >= L.ln2() && i < L.ln2() + 2 * w.c3) {
+        const int e = i - L.ln2();
+        v = (e & 1) ? w.be2[e >> 1] : w.g2[e >> 1];
+    }
+    out[i] = v;
+}
+
+static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3) {
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 +
+           sizeof(float) * ((size_t)C3 * C2 + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
+}
+
+template <int T0, int C1, int C2, int C3>
+static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3);
+    auto kern = encoder_fwd_kernel<T0, C1, C2, C3>;
+    if (!attr_set) {
+        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    PCRL_CHECK_LAUNCH("encoder_fwd_kernel");
+    return PCRL_OK;
+}
+
+static bool dims_supported(int c1, int c2, int c3) {
+    return (c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256;
+}
+
+}  // namespace pcrl
+
+using namespace pcrl;
+
+extern "C" int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes) {
+    if (!bytes) return fail(PCRL_E_ARG, "bytes is NULL");
+    if (c_in < 1 || c_in > PCRL_MAX_CHANNELS || !dims_supported(c1, c2, c3))
+        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256])", c_in, c1, c2, c3);
+    const PackedLayout L{(c_in + 1) / 2, c1, c2, c3};
+    *bytes = sizeof(float) * (size_t)L.total();
+    return PCRL_OK;
+}
+
+static void split_plan(int B, int N, int* S, int* tiles_total, int* tiles_per_seg) {
+    const int tiles = (N + 31) / 32, cus = num_cus();
+    int s = 1;
+    if (B < cus) {
+        s = cus / B;
+        const int max_s = (tiles + 7) / 8;    // keep >= 8 tiles (one per wave) per workgroup
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+    }
+    int tps = (tiles + s - 1) / s;
+    s = (tiles + tps - 1) / tps;
+    *S = s; *tiles_total = tiles; *tiles_per_seg = tps;
+}
+
+extern "C" int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3, size_t* bytes) {
+    if (!bytes || B < 1 || N < 1 || c3 < 1) return fail(PCRL_E_ARG, "bad arguments");
+    int S, tt, tps;
+    split_plan(B, N, &S, &tt, &tps);
+    *bytes = S > 1 ? (size_t)B * S * c3 * sizeof(unsigned long long) : 0;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream) {
+    if (!w || !packed) return fail(PCRL_E_ARG, "NULL argument");
+    size_t need;
+    if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
+    if (packed_bytes < need) return fail(PCRL_E_WORKSPACE, "packed buffer %zu < %zu bytes", packed_bytes, need);
+    const int T0 = (w->c_in + 1) / 2;
+    const int total = (int)(need / sizeof(float));
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *w, T0, (float*)packed);
+    PCRL_CHECK_LAUNCH("encoder_pack_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                    const pcrl_encoder_weights* w, const void* packed,
+                                    float* pooled, int32_t* argmax,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!clouds || !w || !packed || !pooled || !argmax) return fail(PCRL_E_ARG, "NULL argument");
+    if (clouds->B < 0 || clouds->N < 1) return fail(PCRL_E_ARG, "bad cloud shape B=%d N=%d", clouds->B, clouds->N);
+    if (clouds->B == 0) return PCRL_OK;
+    if (clouds->nseg < 1 || clouds->nseg > PCRL_MAX_SEG) return fail(PCRL_E_ARG, "nseg=%d out of range", clouds->nseg);
+    size_t need;
+    if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
+
+    FwdParams p{};
+    p.B = clouds->B; p.N = clouds->N;
+    int c = 0;
+    for (int s = 0; s < clouds->nseg; ++s) {
+        const pcrl_feat_seg& sg = clouds->seg[s];
+        if (!sg.ptr || sg.channels < 1) return fail(PCRL_E_ARG, "segment %d is empty", s);
+        if (sg.dtype != PCRL_DT_F32 && sg.dtype != PCRL_DT_U8 && sg.dtype != PCRL_DT_BOOL) return fail(PCRL_E_ARG, "segment %d: bad dtype", s);
+        const size_t esz = sg.dtype == PCRL_DT_F32 ? 4 : 1;
+        for (int k = 0; k < sg.channels; ++k, ++c) {
+            if (c >= PCRL_MAX_CHANNELS) return fail(PCRL_E_ARG, "more than %d channels", PCRL_MAX_CHANNELS);
+            p.ch[c].base = static_cast<const char*>(sg.ptr) + esz * (size_t)k * sg.stride_c;
+            p.ch[c].stride_b = sg.stride_b; p.ch[c].stride_n = sg.stride_n;
+            p.ch[c].dtype = sg.dtype; p.ch[c].div255 = sg.div255;
+        }
+    }
+    if (c != w->c_in) return fail(PCRL_E_ARG, "clouds carry %d channels, weights expect %d", c, w->c_in);
+    p.C = c;
+    if (aug && aug->flags) {
+        if (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32)
+            return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
+        if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
+        p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
+        p.jitter_lo = aug->jitter_lo; p.jitter_hi = aug->jitter_hi; p.seed = aug->seed; p.offset = aug->offset;
+    }
+    split_plan(p.B, p.N, &p.S, &p.tiles_total, &p.tiles_per_seg);
+    if (p.S > 1) {
+        const size_t ws = (size_t)p.B * p.S * w->c3 * sizeof(unsigned long long);
+        if (!workspace || workspace_bytes < ws) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws);
+        p.partial = static_cast<unsigned long long*>(workspace);
+    }
+    p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.pooled = pooled; p.argmax = argmax;
+
+    const int grid = min(p.B * p.S, num_cus());
+    const int T0 = (p.C + 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = PCRL_E_ARG;
+#define PCRL_FWD_CASE(T0_, C1_)                                                   \
+    if (T0 == T0_ && w->c1 == C1_) rc = launch_fwd<T0_, C1_, 128, 256>(p, grid, st);
+    PCRL_FWD_CASE(2, 64) PCRL_FWD_CASE(3, 64) PCRL_FWD_CASE(4, 64) PCRL_FWD_CASE(5, 64)
+    PCRL_FWD_CASE(2, 128) PCRL_FWD_CASE(3, 128) PCRL_FWD_CASE(4, 128) PCRL_FWD_CASE(5, 128)
+#undef PCRL_FWD_CASE
+    if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.C);
+    if (rc) return rc;
+    if (p.S > 1) {
+        const long long n = (long long)p.B * w->c3;
+        hipLaunchKernelGGL(encoder_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           p.partial, p.B, p.S, w->c3, pooled, argmax);
+        PCRL_CHECK_LAUNCH("encoder_merge_kernel");
+    }
+    return PCRL_OK;
+}

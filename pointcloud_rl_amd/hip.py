@@ -1,0 +1,114 @@
+"""Host-side launchers: torch CUDA tensors -> raw pointers -> C ABI (include/pcrl.h).
+
+PyTorch is used for device memory and the current HIP stream only; every computation here is a
+call into libpcrl_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AugDesc, CloudDesc, EncoderWeights, FeatSeg, check, lib
+
+_DT = {torch.float32: _lib.DT_F32, torch.uint8: _lib.DT_U8, torch.bool: _lib.DT_BOOL}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def make_cloud_desc(obs):
+    """Describe the observation dict PointCloudBase.preprocess consumes (reference
+    pyrl/networks/backbones/pointnet.py:49-73): keys xyz [B,3,N] f32, rgb [B,3,N] u8|f32,
+    pos_encoding [B,F,N], seg [B,K,N]; or a bare xyz tensor.  Returns (desc, tensors kept alive)."""
+    if torch.is_tensor(obs):
+        obs = {"xyz": obs}
+    keep, segs = [], []
+    xyz = obs["xyz"]
+    assert xyz.is_cuda and xyz.ndim == 3, f"xyz must be a CUDA [B,C,N] tensor, got {tuple(xyz.shape)} on {xyz.device}"
+    B, _, N = xyz.shape
+    for key in ("xyz", "rgb", "pos_encoding", "seg"):
+        if key not in obs:
+            continue
+        t = obs[key]
+        assert t.is_cuda and t.ndim == 3 and t.shape[0] == B and t.shape[2] == N, f"{key}: bad shape {tuple(t.shape)}"
+        if t.dtype not in _DT:
+            t = t.to(torch.float32)
+        div255 = 1 if (key == "rgb" and t.dtype == torch.uint8) else 0
+        s = FeatSeg(ptr=t.data_ptr(), dtype=_DT[t.dtype], channels=t.shape[1], div255=div255,
+                    stride_b=t.stride(0), stride_c=t.stride(1), stride_n=t.stride(2))
+        segs.append(s)
+        keep.append(t)
+    desc = CloudDesc(B=B, N=N, nseg=len(segs))
+    for i, s in enumerate(segs):
+        desc.seg[i] = s
+    return desc, keep
+
+
+def make_interleaved_desc(points):
+    """[B, N, C] f32 point tensor (the synthetic benchmark layout of BASELINE.json)."""
+    assert points.is_cuda and points.ndim == 3 and points.dtype == torch.float32
+    B, N, C = points.shape
+    desc = CloudDesc(B=B, N=N, nseg=1)
+    desc.seg[0] = FeatSeg(ptr=points.data_ptr(), dtype=_lib.DT_F32, channels=C, div255=0,
+                          stride_b=points.stride(0), stride_c=points.stride(2), stride_n=points.stride(1))
+    return desc, [points]
+
+
+def make_encoder_weights(w0, b0, w1, g1, be1, w2, g2, be2, eps):
+    ts = [w0, b0, w1, g1, be1, w2, g2, be2]
+    for t in ts:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    c1, c_in = w0.shape[0], w0.shape[1]
+    c2, c3 = w1.shape[0], w2.shape[0]
+    ew = EncoderWeights(c_in=c_in, c1=c1, c2=c2, c3=c3, eps=eps,
+                        w0=w0.data_ptr(), b0=b0.data_ptr(), w1=w1.data_ptr(), g1=g1.data_ptr(), be1=be1.data_ptr(),
+                        w2=w2.data_ptr(), g2=g2.data_ptr(), be2=be2.data_ptr())
+    return ew, ts
+
+
+def encoder_packed_bytes(c_in, c1, c2, c3):
+    n = ctypes.c_size_t()
+    check(lib().pcrl_encoder_packed_bytes(c_in, c1, c2, c3, ctypes.byref(n)))
+    return n.value
+
+
+def encoder_pack_weights(ew, packed):
+    check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
+
+
+def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None):
+    flags = 0
+    aug = AugDesc()
+    if jitter_noise is not None or jitter_range is not None:
+        flags |= _lib.AUG_JITTER
+        aug.jitter_noise = jitter_noise.data_ptr() if jitter_noise is not None else None
+        if jitter_range is not None:
+            aug.jitter_lo, aug.jitter_hi = float(jitter_range[0]), float(jitter_range[1])
+        aug.seed, aug.offset = int(seed), int(offset)
+    if affine is not None:
+        flags |= _lib.AUG_AFFINE
+        aug.affine = affine.data_ptr()
+    aug.flags = flags
+    return aug
+
+
+def encoder_fwd(desc, ew, packed, aug=None, workspace=None):
+    """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device)."""
+    B, c3 = desc.B, ew.c3
+    dev = packed.device
+    pooled = torch.empty((B, c3), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, c3), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t()
+    if B > 0:
+        check(lib().pcrl_encoder_fwd_workspace_bytes(B, desc.N, c3, ctypes.byref(need)))
+    if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
+        workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    check(lib().pcrl_encoder_fwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
+                                     ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
+                                     _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
+    return pooled, argmax
