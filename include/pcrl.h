@@ -110,6 +110,25 @@ int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
                          float* pooled, int32_t* argmax,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Number of floats of the flat encoder gradient, laid out in the reference's parameter order
+ * inside visual_nn.conv.mlp: conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias,
+ * conv2.weight, norm2.weight, norm2.bias. */
+int pcrl_encoder_num_grads(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* n);
+int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes);
+
+/* Encoder backward, fp32: gradient of the shared per-point MLP's parameters given d(loss)/d(pooled).
+ * Replaces autograd through feature.max(-1), LayerNorm1D, ReLU and Conv1d(k=1)
+ * (pointnet.py:148-151, nn_layer.py:207-219, mlp.py:43-56).  Exact: the max-pool routes gradient to
+ * at most c3 points per cloud (argmax), so only those points are recomputed and back-propagated.
+ * `clouds`/`aug` must describe the same inputs (and the same noise) as the forward call that
+ * produced `argmax`.  grads [pcrl_encoder_num_grads] f32 is overwritten; n_active [B] int32 (optional)
+ * receives the number of distinct argmax points per cloud.  Deterministic (no float atomics). */
+int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         const int32_t* argmax, const float* grad_pooled,
+                         float* grads, int32_t* n_active,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,9 +45,29 @@ struct PackedLayout {
     __host__ __device__ constexpr int ln1() const { return w1() + C2 * C1; }         // [C2][2] (gamma, beta)
     __host__ __device__ constexpr int w2() const { return align4(ln1() + 2 * C2); }  // [C3/32][C2/8][64][4]
     __host__ __device__ constexpr int ln2() const { return w2() + C3 * C2; }         // [C3][2]
-    __host__ __device__ constexpr int total() const { return align4(ln2() + 2 * C3); }
+    __host__ __device__ constexpr int w2t() const { return align4(ln2() + 2 * C3); } // [C2/32][C3/8][64][4]
+    __host__ __device__ constexpr int w1t() const { return w2t() + C2 * C3; }        // [C1/32][C2/8][64][4]
+    __host__ __device__ constexpr int total() const { return align4(w1t() + C1 * C2); }
     __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
 };
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer addressing: SGPR resource + one 32-bit VGPR byte offset + scalar/immediate offset.  Used
+// wherever a wave walks many constant-stride pieces of one array, so that no 64-bit VGPR address
+// is materialised per piece.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }

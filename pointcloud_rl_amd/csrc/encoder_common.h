@@ -1,0 +1,139 @@
+// Device code shared by the encoder forward and backward kernels: observation loading
+// (PointCloudBase.preprocess, reference pyrl/networks/backbones/pointnet.py:49-73), the fused
+// DrQ augmentations (pyrl/utils/augmentations/pcd_aug.py) and the per-point LayerNorm.
+#pragma once
+#include "common.h"
+
+namespace pcrl {
+
+struct ChanSrc {
+    const void* base;     // already offset to this channel
+    long long stride_b;   // elements
+    long long stride_n;   // elements
+    int dtype;            // PCRL_DT_*
+    int div255;
+};
+
+// Where the points come from and how they are augmented (shared by forward and backward so that
+// the backward recomputes exactly the forward's inputs).
+struct CloudParams {
+    int B, N, C;
+    int aug_flags;
+    float jitter_lo, jitter_hi;
+    const float* jitter_noise;
+    const float* affine;
+    unsigned long long seed, offset;
+    ChanSrc ch[PCRL_MAX_CHANNELS];
+};
+
+// Channel descriptors are staged in LDS (not SGPRs: 16 x 32 B of kernel arguments would stay
+// live across the whole tile body).  All lanes read the same descriptor; the dtype flags are
+// made scalar again so the branches stay wave-uniform.
+__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n) {
+    const ChanSrc d = s_desc[c];
+    const long long off = (long long)b * d.stride_b + (long long)n * d.stride_n;
+    const int dtype = __builtin_amdgcn_readfirstlane(d.dtype);
+    const int div255 = __builtin_amdgcn_readfirstlane(d.div255);
+    float v;
+    if (dtype == PCRL_DT_F32) {
+        v = static_cast<const float*>(d.base)[off];
+    } else {
+        v = (float)static_cast<const unsigned char*>(d.base)[off];
+        if (dtype == PCRL_DT_BOOL) v = v != 0.0f ? 1.0f : 0.0f;
+    }
+    if (div255) v = v / 255.0f;
+    return v;
+}
+
+// Features of point n of cloud b, channels 0..2*T0-1 (zero beyond C), augmentation applied to xyz.
+template <int T0>
+__device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc* s_desc, int b, int n) {
+    f32x16 x;
+#pragma unroll
+    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n) : 0.0f;
+    if (p.aug_flags & PCRL_AUG_AFFINE) {
+        const float* M = p.affine + (long long)b * 12;
+        const float x0 = x[0], x1 = x[1], x2 = x[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            x[j] = ((M[4 * j + 0] * x0 + M[4 * j + 1] * x1) + M[4 * j + 2] * x2) + M[4 * j + 3];
+    }
+    if (p.aug_flags & PCRL_AUG_JITTER) {
+        if (p.jitter_noise) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[((long long)b * 3 + j) * p.N + n];
+        } else {
+            const unsigned long long e = (unsigned long long)b * p.N + n;
+            uint32_t w[4];
+            philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32),
+                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[j] = x[j] + u01_to_range(w[j], p.jitter_lo, p.jitter_hi);
+        }
+    }
+    return x;
+}
+
+template <int C>
+__device__ __forceinline__ float ln_center_rstd(f32x16 (&a)[C / 32], float eps, bool* var_is_nan) {
+    // mean and variance in the canonical order (oracle/pcrl_oracle.c); `a` is replaced by a - mean.
+    constexpr int MB = C / 32;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            p0 = p0 + a[mb][r + 0]; p1 = p1 + a[mb][r + 1];
+            p2 = p2 + a[mb][r + 2]; p3 = p3 + a[mb][r + 3];
+        }
+    }
+    float lo, hi;
+    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    const float mean = (lo + hi) / (float)C;
+    p0 = p1 = p2 = p3 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            a[mb][r + 0] = a[mb][r + 0] - mean; a[mb][r + 1] = a[mb][r + 1] - mean;
+            a[mb][r + 2] = a[mb][r + 2] - mean; a[mb][r + 3] = a[mb][r + 3] - mean;
+            p0 = __builtin_fmaf(a[mb][r + 0], a[mb][r + 0], p0); p1 = __builtin_fmaf(a[mb][r + 1], a[mb][r + 1], p1);
+            p2 = __builtin_fmaf(a[mb][r + 2], a[mb][r + 2], p2); p3 = __builtin_fmaf(a[mb][r + 3], a[mb][r + 3], p3);
+        }
+    }
+    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    const float var = (lo + hi) / (float)C;
+    *var_is_nan = var != var;
+    return 1.0f / __builtin_sqrtf(var + eps);
+}
+
+// Per-point LayerNorm (biased variance, eps inside the sqrt, affine) + ReLU on an accumulator
+// set (LayerNormkD.forward, reference pyrl/networks/modules/nn_layer.py:207-219).
+// Returns true for a point whose variance is NaN (all outputs NaN).
+template <int C, bool INT_RELU>
+__device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
+    constexpr int MB = C / 32;
+    bool nan_pt;
+    const float rstd = ln_center_rstd<C>(a, eps, &nan_pt);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+            const float2 gb = reinterpret_cast<const float2*>(s_ln)[ch];
+            const float y = __builtin_fmaf(a[mb][r] * rstd, gb.x, gb.y);
+            if (INT_RELU) {
+                const int yi = __builtin_bit_cast(int, y);
+                a[mb][r] = __builtin_bit_cast(float, yi > 0 ? yi : 0);
+            } else {
+                a[mb][r] = relu_nan(y);
+            }
+        }
+    }
+    return nan_pt;
+}
+
+// Host side: validate the descriptors of the C ABI and flatten them into CloudParams.
+int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out);
+
+}  // namespace pcrl

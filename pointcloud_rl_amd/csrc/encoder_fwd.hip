@@ -16,101 +16,19 @@
 // v_permlane32_swap.  The symmetric max-pool is a DPP max over the 32 lanes of a half-wave
 // followed by one ds_max_u64 on a {value bits, ~point index} key per winning lane, which
 // gives torch's first-index tie rule for free and merges the 8 waves of the workgroup.
-#include "common.h"
+#include "encoder_common.h"
 
 namespace pcrl {
 
-struct ChanSrc {
-    const void* base;     // already offset to this channel
-    long long stride_b;   // elements
-    long long stride_n;   // elements
-    int dtype;            // PCRL_DT_*
-    int div255;
-};
-
 struct FwdParams {
-    int B, N, C, S;
-    int tiles_total, tiles_per_seg;
-    int aug_flags;
-    float jitter_lo, jitter_hi, eps;
-    const float* jitter_noise;
-    const float* affine;
-    unsigned long long seed, offset;
+    CloudParams cl;
+    int S, tiles_total, tiles_per_seg;
+    float eps;
     const float* packed;
     float* pooled;
     int* argmax;
     unsigned long long* partial;   // [B][S][C3] keys when S > 1
-    ChanSrc ch[PCRL_MAX_CHANNELS];
 };
-
-// Channel descriptors are staged in LDS (not SGPRs: 16 x 32 B of kernel arguments would stay
-// live across the whole tile body).  All lanes read the same descriptor; the dtype flags are
-// made scalar again so the branches stay wave-uniform.
-__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n) {
-    const ChanSrc d = s_desc[c];
-    const long long off = (long long)b * d.stride_b + (long long)n * d.stride_n;
-    const int dtype = __builtin_amdgcn_readfirstlane(d.dtype);
-    const int div255 = __builtin_amdgcn_readfirstlane(d.div255);
-    float v;
-    if (dtype == PCRL_DT_F32) {
-        v = static_cast<const float*>(d.base)[off];
-    } else {
-        v = (float)static_cast<const unsigned char*>(d.base)[off];
-        if (dtype == PCRL_DT_BOOL) v = v != 0.0f ? 1.0f : 0.0f;
-    }
-    if (div255) v = v / 255.0f;
-    return v;
-}
-
-// Per-point LayerNorm (biased variance, eps inside the sqrt, affine) + ReLU on an
-// accumulator set, statistics in the canonical order documented in oracle/pcrl_oracle.c.
-// Returns true for a point whose variance is NaN (all outputs NaN).
-template <int C, bool INT_RELU>
-__device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
-    constexpr int MB = C / 32;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-            p0 = p0 + a[mb][r + 0]; p1 = p1 + a[mb][r + 1];
-            p2 = p2 + a[mb][r + 2]; p3 = p3 + a[mb][r + 3];
-        }
-    }
-    float lo, hi;
-    both_halves((p0 + p1) + (p2 + p3), lo, hi);
-    const float mean = (lo + hi) / (float)C;
-    p0 = p1 = p2 = p3 = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 4) {
-            float d0 = a[mb][r + 0] - mean, d1 = a[mb][r + 1] - mean;
-            float d2 = a[mb][r + 2] - mean, d3 = a[mb][r + 3] - mean;
-            p0 = __builtin_fmaf(d0, d0, p0); p1 = __builtin_fmaf(d1, d1, p1);
-            p2 = __builtin_fmaf(d2, d2, p2); p3 = __builtin_fmaf(d3, d3, p3);
-        }
-    }
-    both_halves((p0 + p1) + (p2 + p3), lo, hi);
-    const float var = (lo + hi) / (float)C;
-    const float rstd = 1.0f / __builtin_sqrtf(var + eps);
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-            const float2 gb = reinterpret_cast<const float2*>(s_ln)[ch];
-            const float y = __builtin_fmaf((a[mb][r] - mean) * rstd, gb.x, gb.y);
-            if (INT_RELU) {
-                const int yi = __builtin_bit_cast(int, y);
-                a[mb][r] = __builtin_bit_cast(float, yi > 0 ? yi : 0);
-            } else {
-                a[mb][r] = relu_nan(y);
-            }
-        }
-    }
-    return var != var;
-}
 
 template <int T0, int C1, int C2, int C3>
 __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
@@ -137,12 +55,13 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
         for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
         for (int i = tid; i < 2 * C2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
         for (int i = tid; i < 2 * C3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
-        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.ch[tid];
+        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
     }
-    const f32x4* g_w1 = reinterpret_cast<const f32x4*>(p.packed + L.w1());
+    const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
+    const unsigned lane16 = 16u * (unsigned)lane;
     const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
 
-    for (int work = blockIdx.x; work < p.B * p.S; work += gridDim.x) {
+    for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
         const int b = work / p.S, seg = work - b * p.S;
         const int t_begin = seg * p.tiles_per_seg;
         const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
@@ -152,33 +71,11 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
         for (int tile = t_begin + wave; tile < t_end; tile += 8) {
             const int pidx = tile * 32 + l31;
-            const bool valid = pidx < p.N;
-            const int pc = valid ? pidx : p.N - 1;
+            const bool valid = pidx < p.cl.N;
+            const int pc = valid ? pidx : p.cl.N - 1;
 
             // ---- preprocess (+ augmentation) ---------------------------------------------
-            f32x16 x;
-#pragma unroll
-            for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, pc) : 0.0f;
-            if (p.aug_flags & PCRL_AUG_AFFINE) {
-                const float* M = p.affine + (long long)b * 12;
-                const float x0 = x[0], x1 = x[1], x2 = x[2];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    x[j] = ((M[4 * j + 0] * x0 + M[4 * j + 1] * x1) + M[4 * j + 2] * x2) + M[4 * j + 3];
-            }
-            if (p.aug_flags & PCRL_AUG_JITTER) {
-                if (p.jitter_noise) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[((long long)b * 3 + j) * p.N + pc];
-                } else {
-                    const unsigned long long e = (unsigned long long)b * p.N + pc;
-                    uint32_t w[4];
-                    philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32),
-                                  (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) x[j] = x[j] + u01_to_range(w[j], p.jitter_lo, p.jitter_hi);
-                }
-            }
+            const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
 
             // ---- conv0 + bias + ReLU ------------------------------------------------------
             f32x16 a0[MB1];
@@ -203,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
 #pragma unroll
                 for (int tq = 0; tq < C1 / 8; ++tq) {
-                    const f32x4 w = g_w1[(mb * (C1 / 8) + tq) * 64 + lane];
+                    const f32x4 w = buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int t = 4 * tq + j;
@@ -314,8 +211,48 @@ __global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __res
     } else if (i >= L.ln2() && i < L.ln2() + 2 * w.c3) {
         const int e = i - L.ln2();
         v = (e & 1) ? w.be2[e >> 1] : w.g2[e >> 1];
+    } else if (i >= L.w2t() && i < L.w1t()) { // conv2 transposed (dX GEMM of the backward): rows = c2, k = c3
+        const int e = i - L.w2t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c3 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w2[acc_chan(4 * tq + j, ln >> 5) * w.c2 + 32 * mb + (ln & 31)];
+    } else if (i >= L.w1t() && i < L.w1t() + w.c1 * w.c2) { // conv1 transposed: rows = c1, k = c2
+        const int e = i - L.w1t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w1[acc_chan(4 * tq + j, ln >> 5) * w.c1 + 32 * mb + (ln & 31)];
     }
     out[i] = v;
+}
+
+int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out) {
+    if (!clouds) return fail(PCRL_E_ARG, "clouds is NULL");
+    if (clouds->B < 0 || clouds->N < 1) return fail(PCRL_E_ARG, "bad cloud shape B=%d N=%d", clouds->B, clouds->N);
+    if (clouds->nseg < 1 || clouds->nseg > PCRL_MAX_SEG) return fail(PCRL_E_ARG, "nseg=%d out of range", clouds->nseg);
+    CloudParams& p = *out;
+    p = CloudParams{};
+    p.B = clouds->B; p.N = clouds->N;
+    int c = 0;
+    for (int s = 0; s < clouds->nseg; ++s) {
+        const pcrl_feat_seg& sg = clouds->seg[s];
+        if (!sg.ptr || sg.channels < 1) return fail(PCRL_E_ARG, "segment %d is empty", s);
+        if (sg.dtype != PCRL_DT_F32 && sg.dtype != PCRL_DT_U8 && sg.dtype != PCRL_DT_BOOL) return fail(PCRL_E_ARG, "segment %d: bad dtype", s);
+        const size_t esz = sg.dtype == PCRL_DT_F32 ? 4 : 1;
+        for (int k = 0; k < sg.channels; ++k, ++c) {
+            if (c >= PCRL_MAX_CHANNELS) return fail(PCRL_E_ARG, "more than %d channels", PCRL_MAX_CHANNELS);
+            p.ch[c].base = static_cast<const char*>(sg.ptr) + esz * (size_t)k * sg.stride_c;
+            p.ch[c].stride_b = sg.stride_b; p.ch[c].stride_n = sg.stride_n;
+            p.ch[c].dtype = sg.dtype; p.ch[c].div255 = sg.div255;
+        }
+    }
+    if (c != expect_channels) return fail(PCRL_E_ARG, "clouds carry %d channels, weights expect %d", c, expect_channels);
+    p.C = c;
+    if (aug && aug->flags) {
+        if (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32)
+            return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
+        if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
+        p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
+        p.jitter_lo = aug->jitter_lo; p.jitter_hi = aug->jitter_hi; p.seed = aug->seed; p.offset = aug->offset;
+    }
+    return PCRL_OK;
 }
 
 static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3) {
@@ -393,46 +330,21 @@ extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
                                     float* pooled, int32_t* argmax,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!clouds || !w || !packed || !pooled || !argmax) return fail(PCRL_E_ARG, "NULL argument");
-    if (clouds->B < 0 || clouds->N < 1) return fail(PCRL_E_ARG, "bad cloud shape B=%d N=%d", clouds->B, clouds->N);
-    if (clouds->B == 0) return PCRL_OK;
-    if (clouds->nseg < 1 || clouds->nseg > PCRL_MAX_SEG) return fail(PCRL_E_ARG, "nseg=%d out of range", clouds->nseg);
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
-
     FwdParams p{};
-    p.B = clouds->B; p.N = clouds->N;
-    int c = 0;
-    for (int s = 0; s < clouds->nseg; ++s) {
-        const pcrl_feat_seg& sg = clouds->seg[s];
-        if (!sg.ptr || sg.channels < 1) return fail(PCRL_E_ARG, "segment %d is empty", s);
-        if (sg.dtype != PCRL_DT_F32 && sg.dtype != PCRL_DT_U8 && sg.dtype != PCRL_DT_BOOL) return fail(PCRL_E_ARG, "segment %d: bad dtype", s);
-        const size_t esz = sg.dtype == PCRL_DT_F32 ? 4 : 1;
-        for (int k = 0; k < sg.channels; ++k, ++c) {
-            if (c >= PCRL_MAX_CHANNELS) return fail(PCRL_E_ARG, "more than %d channels", PCRL_MAX_CHANNELS);
-            p.ch[c].base = static_cast<const char*>(sg.ptr) + esz * (size_t)k * sg.stride_c;
-            p.ch[c].stride_b = sg.stride_b; p.ch[c].stride_n = sg.stride_n;
-            p.ch[c].dtype = sg.dtype; p.ch[c].div255 = sg.div255;
-        }
-    }
-    if (c != w->c_in) return fail(PCRL_E_ARG, "clouds carry %d channels, weights expect %d", c, w->c_in);
-    p.C = c;
-    if (aug && aug->flags) {
-        if (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32)
-            return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
-        if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
-        p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
-        p.jitter_lo = aug->jitter_lo; p.jitter_hi = aug->jitter_hi; p.seed = aug->seed; p.offset = aug->offset;
-    }
-    split_plan(p.B, p.N, &p.S, &p.tiles_total, &p.tiles_per_seg);
+    if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
+    if (p.cl.B == 0) return PCRL_OK;
+    split_plan(p.cl.B, p.cl.N, &p.S, &p.tiles_total, &p.tiles_per_seg);
     if (p.S > 1) {
-        const size_t ws = (size_t)p.B * p.S * w->c3 * sizeof(unsigned long long);
+        const size_t ws = (size_t)p.cl.B * p.S * w->c3 * sizeof(unsigned long long);
         if (!workspace || workspace_bytes < ws) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws);
         p.partial = static_cast<unsigned long long*>(workspace);
     }
     p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.pooled = pooled; p.argmax = argmax;
 
-    const int grid = min(p.B * p.S, num_cus());
-    const int T0 = (p.C + 1) / 2;
+    const int grid = min(p.cl.B * p.S, num_cus());
+    const int T0 = (p.cl.C + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     int rc = PCRL_E_ARG;
 #define PCRL_FWD_CASE(T0_, C1_)                                                   \
@@ -440,12 +352,12 @@ extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
     PCRL_FWD_CASE(2, 64) PCRL_FWD_CASE(3, 64) PCRL_FWD_CASE(4, 64) PCRL_FWD_CASE(5, 64)
     PCRL_FWD_CASE(2, 128) PCRL_FWD_CASE(3, 128) PCRL_FWD_CASE(4, 128) PCRL_FWD_CASE(5, 128)
 #undef PCRL_FWD_CASE
-    if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.C);
+    if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
     if (p.S > 1) {
-        const long long n = (long long)p.B * w->c3;
+        const long long n = (long long)p.cl.B * w->c3;
         hipLaunchKernelGGL(encoder_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                           p.partial, p.B, p.S, w->c3, pooled, argmax);
+                           p.partial, p.cl.B, p.S, w->c3, pooled, argmax);
         PCRL_CHECK_LAUNCH("encoder_merge_kernel");
     }
     return PCRL_OK;

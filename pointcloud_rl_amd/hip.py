@@ -112,3 +112,42 @@ def encoder_fwd(desc, ew, packed, aug=None, workspace=None):
                                      ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
                                      _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
     return pooled, argmax
+
+
+def encoder_num_grads(ew):
+    n = ctypes.c_size_t()
+    check(lib().pcrl_encoder_num_grads(ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(n)))
+    return n.value
+
+
+def encoder_grad_views(flat, ew):
+    """Split the flat gradient into the reference's parameter order/shapes (conv weights as [out,in,1])."""
+    C, c1, c2, c3 = ew.c_in, ew.c1, ew.c2, ew.c3
+    sizes = [("conv0.weight", (c1, C, 1)), ("conv0.bias", (c1,)), ("conv1.weight", (c2, c1, 1)), ("norm1.weight", (c2,)),
+             ("norm1.bias", (c2,)), ("conv2.weight", (c3, c2, 1)), ("norm2.weight", (c3,)), ("norm2.bias", (c3,))]
+    out, o = {}, 0
+    for name, shape in sizes:
+        n = 1
+        for d in shape:
+            n *= d
+        out[name] = flat[o:o + n].view(shape)
+        o += n
+    assert o == flat.numel()
+    return out
+
+
+def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None, want_n_active=False):
+    """Flat encoder gradient [pcrl_encoder_num_grads] for d(loss)/d(pooled) = grad_pooled [B,c3]."""
+    dev = packed.device
+    assert argmax.dtype == torch.int32 and argmax.is_contiguous() and grad_pooled.dtype == torch.float32
+    grad_pooled = grad_pooled.contiguous()
+    grads = torch.empty(encoder_num_grads(ew), dtype=torch.float32, device=dev)
+    need = ctypes.c_size_t()
+    check(lib().pcrl_encoder_bwd_workspace_bytes(desc.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)
+    n_active = torch.empty(desc.B, dtype=torch.int32, device=dev) if want_n_active else None
+    check(lib().pcrl_encoder_bwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
+                                     _ptr(packed), _ptr(argmax), _ptr(grad_pooled), _ptr(grads), _ptr(n_active),
+                                     _ptr(workspace), ctypes.c_size_t(workspace.numel()), _stream()))
+    return (grads, n_active) if want_n_active else grads
