@@ -67,10 +67,13 @@ typedef struct pcrl_cloud_desc {
  *  AFFINE  : xyz = M[b] (3x4, row-major) applied as R x + t
  *            (GlobalRotScaleTrans.process_single -> apply_rot_trans,
  *            pcd_aug.py:178-215, 84-123); M is built by the host class.
- * Order when both are set: AFFINE first, then JITTER. */
+ * Order when both are set: AFFINE first, then JITTER.
+ * Cloud b uses row (b * row_mul + row_add) of jitter_noise / affine / the Philox counter
+ * (row_mul == 0 means 1), so a strided sub-batch (DrQ's actor step uses augmentation #0 of every
+ * sample, drq.py:115) sees exactly the noise the full batch saw. */
 enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2 };
 typedef struct pcrl_aug_desc {
-    int32_t flags, _pad;
+    int32_t flags, row_mul, row_add, _pad;
     const float* jitter_noise;
     float jitter_lo, jitter_hi;
     uint64_t seed, offset;

@@ -19,6 +19,7 @@ struct ChanSrc {
 struct CloudParams {
     int B, N, C;
     int aug_flags;
+    int row_mul, row_add;     // augmentation row of cloud b = b * row_mul + row_add
     float jitter_lo, jitter_hi;
     const float* jitter_noise;
     const float* affine;
@@ -51,8 +52,9 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
     f32x16 x;
 #pragma unroll
     for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n) : 0.0f;
+    const long long row = (long long)b * p.row_mul + p.row_add;
     if (p.aug_flags & PCRL_AUG_AFFINE) {
-        const float* M = p.affine + (long long)b * 12;
+        const float* M = p.affine + row * 12;
         const float x0 = x[0], x1 = x[1], x2 = x[2];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -61,9 +63,9 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
     if (p.aug_flags & PCRL_AUG_JITTER) {
         if (p.jitter_noise) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[((long long)b * 3 + j) * p.N + n];
+            for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[(row * 3 + j) * p.N + n];
         } else {
-            const unsigned long long e = (unsigned long long)b * p.N + n;
+            const unsigned long long e = (unsigned long long)row * p.N + n;
             uint32_t w[4];
             philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32),
                           (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);

@@ -81,9 +81,10 @@ def encoder_pack_weights(ew, packed):
     check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
 
 
-def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None):
+def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0):
     flags = 0
     aug = AugDesc()
+    aug.row_mul, aug.row_add = int(row_mul), int(row_add)
     if jitter_noise is not None or jitter_range is not None:
         flags |= _lib.AUG_JITTER
         aug.jitter_noise = jitter_noise.data_ptr() if jitter_noise is not None else None
