@@ -1,0 +1,173 @@
+"""Headline benchmark: SAC gradient steps/sec (encoder + update) on B=256, N=1024 points.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one `agent.update_parameters(memory, updates)` (reference pyrl/methods/mfrl/sac.py:103),
+on BASELINE.json config 2 ("K1"): synthetic replay B=256, N=1024, C=6 (xyz f32 + rgb u8, planar),
+A=6, nets of configs/mfrl/sac/dm_control/pn.py, fp32.  Inputs are resident in HBM before the timed
+region.  With N > 1 the batch of 256 is sharded over the ranks (256/N clouds each), parameters are
+replicated and the flat gradient buffers are all-reduced over RCCL after each backward: strong
+scaling, value = global gradient steps per second.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fused encoder forward),
+timed with HIP events inside the timed region; `cpu_baseline` is the op-for-op PyTorch-CPU
+restatement of the reference (oracle/torch_ref.py) timed on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (B, N, pcd channels extras, action_dim, agent_dim, config builder)
+    "k1": dict(B=256, N=1024, A=6, S=0, obs_kw={}, cfg="sac_dmc", desc="SAC PointNet, synthetic replay B=256 N=1024 C=6 (BASELINE config 2)"),
+    "k3": dict(B=1024, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="sac_maniskill",
+               desc="SAC PointNet, ManiSkill shape B=1024 N=1200 C=7 (BASELINE config 4)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="k1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_agent(wl, batch_per_rank, device):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent as _build
+    C = 6 + wl["obs_kw"].get("seg", 0) + wl["obs_kw"].get("pos_encoding", 0)
+    if wl["cfg"] == "sac_dmc":
+        cfg = configs.sac_dmc(C, wl["A"], batch_per_rank)
+    else:
+        cfg = configs.sac_maniskill(C, wl["A"], wl["S"], batch_per_rank)
+    obs_shape = {"xyz": [3, wl["N"]], "rgb": [3, wl["N"]]}
+    cfg["env_params"] = configs.env_params(obs_shape, wl["A"])
+    torch.manual_seed(0)                       # random-init weights of the named architecture
+    return _build(cfg).to(device), C
+
+
+def cpu_baseline(agent, wl, steps):
+    """The reference's update step restated op for op (six encoder passes, permute LayerNorm, per-tensor
+    Adam groups), timed on the host: 1 warm-up + `steps` timed steps of the full B=256 batch."""
+    from oracle import torch_ref
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    params = {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}
+    ref = torch_ref.RefAgent(params, kind="sac", gamma=agent.gamma, reward_scale=agent.reward_scale, alpha=0.1,
+                             target_entropy=agent.target_entropy, actor_update_interval=agent.actor_update_interval,
+                             target_update_interval=agent.target_update_interval,
+                             update_coeff=agent.update_coeff["default"], mirror_redundancy=True)
+    batch = make_batch_np(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
+    tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch.items()}
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    eps = lambda: [torch.randn(wl["B"], wl["A"], generator=g), torch.randn(wl["B"], wl["A"], generator=g)]
+    ref.update_parameters(tb, 1, eps())
+    t0 = time.perf_counter()
+    for u in range(2, 2 + steps):
+        ref.update_parameters(tb, u, eps())
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full update steps (B={wl['B']}, N={wl['N']}) after 1 warm-up, torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    args = parse()
+    wl = WORKLOADS[args.workload]
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)   # RCCL
+    assert wl["B"] % world == 0, "batch must divide over the ranks"
+    b_rank = wl["B"] // world
+
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    agent, C = build_agent(wl, b_rank, device)
+    if world > 1:
+        for p in agent.parameters():                      # replicas start identical (DDP's constructor broadcast)
+            torch.distributed.broadcast(p.data, 0)
+        agent.to_ddp(device_ids=["cuda"])
+    # every rank generates the global batch with the same seed and keeps its shard resident in HBM
+    full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
+    sl = slice(rank * b_rank, (rank + 1) * b_rank)
+    shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
+    memory = SyntheticReplay.__new__(SyntheticReplay)
+    from pointcloud_rl_amd.utils.torch_utils import to_torch
+    memory.batch_np, memory.batch = shard, to_torch(shard, device=device)
+    agent.train()
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    updates = 0
+    for _ in range(args.warmup):
+        updates += 1
+        agent.update_parameters(memory, updates)
+    hip.TIMER = hip.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        updates += 1
+        agent.update_parameters(memory, updates)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timer, hip.TIMER = hip.TIMER, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        spans = timer.summary()
+        n_fwd, ms_fwd = spans.get("encoder_fwd", (0, float("nan")))
+        f_pt = 2.0 * (C * agent.encoder.mlp_spec[0] + agent.encoder.mlp_spec[0] * agent.encoder.mlp_spec[1] +
+                      agent.encoder.mlp_spec[1] * agent.encoder.mlp_spec[2])
+        # the launches of one step have different cloud counts only for DrQ; for SAC every launch encodes b_rank clouds
+        flops_per_launch = f_pt * b_rank * wl["N"]
+        achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
+        out = {
+            "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
+            "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
+                       "parallelism": f"dp{world}", "batch_per_gpu": b_rank},
+            "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": achieved / 157.3, "traffic": None, "launches": n_fwd, "avg_launch_ms": ms_fwd,
+                         "algorithmic_flops_per_launch": flops_per_launch},
+            "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,25 @@ int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
                          float* grads, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Fused Adam (+ Polyak + gradient 2-norm) over one flat parameter buffer.
+ * Replaces torch.optim.Adam over one parameter group per tensor (build_optimizer,
+ * pyrl/utils/torch/optimizer_utils.py:43-57; Adam defaults: no weight decay, no amsgrad), the
+ * per-parameter soft_update (pyrl/utils/torch/ops.py:59-90) and grad_norm
+ * (pyrl/utils/torch/module_utils.py:40-45).
+ *   g = grad * grad_scale (1/world after a sum all-reduce); m, v, param updated in place;
+ *   step_counter (device int32) is incremented first and used for the bias corrections, so the call
+ *   can be replayed from a hipGraph; grad_norm_out (device float, optional) <- ||g||_2;
+ *   target (optional): for target_begin <= i < target_end,
+ *   target[i - target_begin] <- (1 - tau) * target[..] + tau * param_new[i]. */
+int pcrl_adam_workspace_bytes(size_t n, size_t* bytes);
+int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                       int32_t* step_counter, float* grad_norm_out,
+                       float* target, size_t target_begin, size_t target_end, float tau,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
+int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

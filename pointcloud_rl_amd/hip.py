@@ -13,6 +13,50 @@ from ._lib import AugDesc, CloudDesc, EncoderWeights, FeatSeg, check, lib
 _DT = {torch.float32: _lib.DT_F32, torch.uint8: _lib.DT_U8, torch.bool: _lib.DT_BOOL}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of every C-ABI launch (bench.py's roofline figures).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def summary(self):
+        """name -> (launches, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.spans.items() if v}
+
+
+class _Span:
+    def __init__(self, timer, name):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record()
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.timer.spans.setdefault(self.name, []).append((self.start, end))
+
+
+class _NoSpan:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+TIMER = None          # set to a KernelTimer() to time launches
+
+
+def _span(name):
+    return TIMER.span(name) if TIMER is not None else _NoSpan()
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -109,9 +153,10 @@ def encoder_fwd(desc, ew, packed, aug=None, workspace=None):
         check(lib().pcrl_encoder_fwd_workspace_bytes(B, desc.N, c3, ctypes.byref(need)))
     if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
         workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
-    check(lib().pcrl_encoder_fwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
-                                     ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
-                                     _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
+    with _span("encoder_fwd"):
+        check(lib().pcrl_encoder_fwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
+                                         ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
+                                         _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
     return pooled, argmax
 
 
@@ -148,7 +193,28 @@ def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None,
     if workspace is None or workspace.numel() * workspace.element_size() < need.value:
         workspace = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)
     n_active = torch.empty(desc.B, dtype=torch.int32, device=dev) if want_n_active else None
-    check(lib().pcrl_encoder_bwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
-                                     _ptr(packed), _ptr(argmax), _ptr(grad_pooled), _ptr(grads), _ptr(n_active),
-                                     _ptr(workspace), ctypes.c_size_t(workspace.numel()), _stream()))
+    with _span("encoder_bwd"):
+        check(lib().pcrl_encoder_bwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
+                                         _ptr(packed), _ptr(argmax), _ptr(grad_pooled), _ptr(grads), _ptr(n_active),
+                                         _ptr(workspace), ctypes.c_size_t(workspace.numel()), _stream()))
     return (grads, n_active) if want_n_active else grads
+
+
+def adam_workspace_bytes(n):
+    need = ctypes.c_size_t()
+    check(lib().pcrl_adam_workspace_bytes(ctypes.c_size_t(n), ctypes.byref(need)))
+    return need.value
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, workspace,
+              target=None, target_begin=0, target_end=0, tau=0.0):
+    with _span("adam_step"):
+        check(lib().pcrl_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
+                                       ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                       ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(grad_norm_out),
+                                       _ptr(target), ctypes.c_size_t(target_begin), ctypes.c_size_t(target_end), ctypes.c_float(tau),
+                                       _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
+
+
+def polyak(target, src, tau):
+    check(lib().pcrl_polyak_f32(_ptr(target), _ptr(src), ctypes.c_size_t(target.numel()), ctypes.c_float(tau), _stream()))

@@ -10,7 +10,7 @@ import torch
 
 from ..augmentations import build_data_augmentations
 from ..networks.pointnet import AugmentedObs
-from ..utils.torch_utils import soft_update, to_torch
+from ..utils.torch_utils import to_torch
 from .builder import MFRL
 from .sac import SAC
 
@@ -67,9 +67,8 @@ class DrQ(SAC):
             dones = torch.repeat_interleave(sampled_batch["dones"], self.num_aug, dim=0)
         stats = {}
         q_target = self._q_target(next_obs, rewards, dones, n_groups=B)
-        self._critic_step(obs, actions, q_target, stats)
+        self._critic_step(obs, actions, q_target, stats, polyak=self._polyak_now(updates))
         if updates % self.actor_update_interval == 0:
             self._actor_step(first_augmentation(obs, B, self.num_aug), stats)
-        if updates % self.target_update_interval == 0:
-            soft_update(self.target_critic, self.critic, self.update_coeff)
+        self._soft_update(updates)
         return self._finish(stats, updates)

@@ -17,28 +17,30 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.torch_utils import BaseAgent, build_optimizer, select_optimizer_params, soft_update
+from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
 
 class FlatBuffer:
     """Re-homes a list of parameters into one contiguous buffer (data and grad as views)."""
 
-    def __init__(self, named_params):
+    def __init__(self, named_params, with_grad=True):
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.data = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev) if with_grad else None
         o = 0
         for p in self.params:
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + n].view(p.shape)
-            p.grad = self.grad[o:o + n].view(p.shape)
+            if with_grad:
+                p.grad = self.grad[o:o + n].view(p.shape)
             o += n
 
     def zero_grad(self):
@@ -52,6 +54,67 @@ class FlatBuffer:
 
     def grad_norm_sq(self):
         return (self.grad * self.grad).sum()
+
+
+class HipAdam:
+    """torch.optim.Adam-compatible facade over the fused flat-buffer kernel (pcrl_adam_step_f32).
+
+    Keeps what the reference's drivers touch: `param_groups` (one group per tensor, as
+    build_optimizer makes them), `state_dict()/load_state_dict()` in torch's format (checkpoints store
+    the optimizers under their attribute names, checkpoint_utils.py:215-237), `zero_grad()`, `step()`.
+    """
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **unused):
+        self.flat = flat
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False)
+        self.param_groups = [dict(self.defaults, params=[p]) for p in flat.params]
+        dev = flat.data.device
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.workspace = torch.empty(hip.adam_workspace_bytes(flat.data.numel()), dtype=torch.uint8, device=dev)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0):
+        g = self.param_groups[0]
+        hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
+                      g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
+                      target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau)
+
+    def _views(self, flat_tensor):
+        out, o = [], 0
+        for p in self.flat.params:
+            out.append(flat_tensor[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        return out
+
+    def state_dict(self):
+        step = self.step_counter.to(torch.float32).reshape(())
+        state = {i: dict(step=step.clone(), exp_avg=m, exp_avg_sq=v)
+                 for i, (m, v) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq)))} if int(self.step_counter.item()) > 0 else {}
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=[i]) for i, g in enumerate(self.param_groups)]
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        for i, st in sd.get("state", {}).items():
+            i = int(i)
+            self._views(self.exp_avg)[i].copy_(st["exp_avg"])
+            self._views(self.exp_avg_sq)[i].copy_(st["exp_avg_sq"])
+            self.step_counter.fill_(int(st["step"]))
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in src.items() if k != "params"})
+
+
+def _plain_adam(optim):
+    if type(optim) is not torch.optim.Adam:
+        return None
+    d = optim.defaults
+    if d.get("amsgrad") or d.get("weight_decay") or d.get("maximize"):
+        return None
+    return dict(lr=d["lr"], betas=d["betas"], eps=d["eps"])
 
 
 @MFRL.register_module()
@@ -115,15 +178,59 @@ class SAC(BaseAgent):
             "critic": FlatBuffer(select_optimizer_params(self.critic, self._critic_optim_cfg.get("param_cfg"))),
             "actor": FlatBuffer(select_optimizer_params(self.actor, self._actor_optim_cfg.get("param_cfg"))),
         }
-        self.log_alpha.grad = torch.zeros_like(self.log_alpha)
+        self._flat["alpha"] = FlatBuffer([("log_alpha", self.log_alpha)])
+        for name in ("critic", "actor", "alpha"):      # torch.optim.Adam (one group per tensor) -> one fused launch
+            hp = _plain_adam(getattr(self, f"{name}_optim"))
+            if hp is not None:
+                setattr(self, f"{name}_optim", HipAdam(self._flat[name], **hp))
+        # Polyak: the target's own (non-shared) parameters mirror a tail range of the critic buffer
+        online = {id(p) for p in self.critic.parameters()}
+        tgt = [(n, p) for n, p in self.target_critic.named_parameters() if id(p) not in online]
+        self._target_flat, self._target_range, self._target_tau = None, (0, 0), None
+        own = [(n, p) for n, p in zip(self._flat["critic"].names, self._flat["critic"].params)
+               if n in {tn for tn, _ in tgt}]
+        taus = {self._tau_for(n) for n, _ in own}
+        if tgt and len(own) == len(tgt) and len(taus) == 1 and [n for n, _ in own] == [n for n, _ in tgt]:
+            first = self._flat["critic"].names.index(own[0][0])
+            begin = sum(p.numel() for p in self._flat["critic"].params[:first])
+            count = sum(p.numel() for _, p in own)
+            if first + len(own) == len(self._flat["critic"].params):
+                self._target_flat = FlatBuffer(tgt, with_grad=False)
+                self._target_range = (begin, begin + count)
+                self._target_tau = taus.pop()
         self._alpha_t = self.log_alpha.detach().exp()
         self._dedup = self._encoder_is_shared()
         self._world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
 
+    def _tau_for(self, name):
+        """soft_update's regex -> tau rule (pyrl/utils/torch/ops.py:66-90)."""
+        if not isinstance(self.update_coeff, dict):
+            return float(self.update_coeff)
+        for pattern, value in self.update_coeff.items():
+            if pattern != "default" and regex_match(name, pattern):
+                return float(value)
+        return float(self.update_coeff["default"])
+
     def _allreduce(self, tensor):
+        """Sum the flat gradient over the ranks (RCCL); the 1/world factor is applied by the optimizer kernel."""
         if self._be_data_parallel and self._world > 1:
             torch.distributed.all_reduce(tensor)
-            tensor.div_(self._world)
+            return 1.0 / self._world
+        return 1.0
+
+    def _optim_step(self, name, scale, polyak=False):
+        opt = getattr(self, f"{name}_optim")
+        fb = self._flat[name]
+        if isinstance(opt, HipAdam):
+            if polyak and self._target_flat is not None:
+                opt.step(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau)
+            else:
+                opt.step(scale)
+            return opt.grad_norm.reshape(())
+        if scale != 1.0:
+            fb.grad.mul_(scale)
+        opt.step()
+        return fb.grad_norm_sq().sqrt()
 
     def _encode(self, module_for_fallback, obs):
         """Visual feature of `obs` when the encoder is shared (else None: the module encodes itself)."""
@@ -147,15 +254,15 @@ class SAC(BaseAgent):
                 q_target = torch.repeat_interleave(q_target, q_next.shape[0] // n_groups, dim=0)
             return q_target.repeat(1, q_next.shape[-1])
 
-    def _critic_step(self, obs, actions, q_target, stats):
+    def _critic_step(self, obs, actions, q_target, stats, polyak=False):
         fb = self._flat["critic"]
         vis = self._encode(self.critic, obs)
         q = self.critic(obs, actions, **({} if vis is None else dict(visual_feature=vis)))
         critic_loss = F.mse_loss(q, q_target) * q_target.shape[-1]
         fb.zero_grad()
         critic_loss.backward()
-        self._allreduce(fb.grad)
-        self.critic_optim.step()
+        scale = self._allreduce(fb.grad)
+        grad_norm = self._optim_step("critic", scale, polyak=polyak)
         if self.encoder is not None:
             self.encoder.invalidate_packed()
         with torch.no_grad():
@@ -164,7 +271,7 @@ class SAC(BaseAgent):
             stats["q"] = torch.min(q, dim=-1).values.mean()
             stats["q_target"] = q_target.mean()
             # 2-norm over all critic parameters == norm of the per-tensor norms (module_utils.py:40-45)
-            stats["critic_grad"] = fb.grad_norm_sq().sqrt()
+            stats["critic_grad"] = grad_norm
 
     def _actor_step(self, obs, stats):
         fb = self._flat["actor"]
@@ -196,18 +303,14 @@ class SAC(BaseAgent):
         actor_loss = -(q_pi.mean() + self._alpha_t * entropy_term)
         fb.zero_grad()
         actor_loss.backward()
-        self._allreduce(fb.grad)
-        self.actor_optim.step()
+        stats["actor_grad"] = self._optim_step("actor", self._allreduce(fb.grad))
         stats["actor_loss"] = actor_loss.detach()
         stats["entropy"] = entropy_term.detach()
-        stats["actor_grad"] = fb.grad_norm_sq().sqrt()
         if self.automatic_alpha_tuning:
             alpha_loss = self.log_alpha.exp() * (entropy_term - self.target_entropy).detach()
-            self.log_alpha.grad.zero_()
+            self._flat["alpha"].zero_grad()
             alpha_loss.backward()
-            if self.sync_alpha:
-                self._allreduce(self.log_alpha.grad)
-            self.alpha_optim.step()
+            self._optim_step("alpha", self._allreduce(self._flat["alpha"].grad) if self.sync_alpha else 1.0)
             self._alpha_t = self.log_alpha.detach().exp()
             stats["alpha_loss"] = alpha_loss.detach().reshape(())
         else:
@@ -230,6 +333,16 @@ class SAC(BaseAgent):
                 self.alpha = got["new_alpha"]
         return ret
 
+    def _polyak_now(self, updates):
+        """True when this step's target update is fused into the critic's optimizer pass.  The critic's
+        weights do not change between its optimizer step and the reference's soft_update call at the end
+        of the step (sac.py:207-208), so updating the target right after the step is equivalent."""
+        return updates % self.target_update_interval == 0 and self._target_flat is not None and isinstance(self.critic_optim, HipAdam)
+
+    def _soft_update(self, updates):
+        if updates % self.target_update_interval == 0 and not self._polyak_now(updates):
+            soft_update(self.target_critic, self.critic, self.update_coeff)
+
     def update_parameters(self, memory, updates):
         if self._flat is None:
             self._prepare()
@@ -239,9 +352,8 @@ class SAC(BaseAgent):
             sampled_batch["dones"] = sampled_batch["episode_dones"]
         stats = {}
         q_target = self._q_target(sampled_batch["next_obs"], sampled_batch["rewards"], sampled_batch["dones"])
-        self._critic_step(sampled_batch["obs"], sampled_batch["actions"], q_target, stats)
+        self._critic_step(sampled_batch["obs"], sampled_batch["actions"], q_target, stats, polyak=self._polyak_now(updates))
         if updates % self.actor_update_interval == 0:
             self._actor_step(sampled_batch["obs"], stats)
-        if updates % self.target_update_interval == 0:
-            soft_update(self.target_critic, self.critic, self.update_coeff)
+        self._soft_update(updates)
         return self._finish(stats, updates)
