@@ -78,6 +78,8 @@ typedef struct pcrl_aug_desc {
     float jitter_lo, jitter_hi;
     uint64_t seed, offset;
     const float* affine;
+    const uint64_t* offset_ptr;   /* device; when non-NULL the Philox offset is read from here at run
+                                     time (a launch replayed from a hipGraph then draws fresh noise) */
 } pcrl_aug_desc;
 
 /* Weights of the shared per-point MLP in the reference's own state_dict layout

@@ -30,7 +30,8 @@ class AugDesc(ctypes.Structure):
     _fields_ = [("flags", ctypes.c_int32), ("row_mul", ctypes.c_int32), ("row_add", ctypes.c_int32), ("_pad", ctypes.c_int32),
                 ("jitter_noise", ctypes.c_void_p),
                 ("jitter_lo", ctypes.c_float), ("jitter_hi", ctypes.c_float),
-                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p)]
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p),
+                ("offset_ptr", ctypes.c_void_p)]
 
 
 class EncoderWeights(ctypes.Structure):

@@ -83,6 +83,7 @@ class RandomJitterPoints(_PointAug):
         self.jitter_range = [float(jitter_range[0]), float(jitter_range[1])]
         self.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
         self.calls = 0
+        self._counter = None           # device int64 call counter: a hipGraph replay must draw fresh noise
         self.noise_override = []       # parity tests queue explicit noise tensors here (consumed in call order)
 
     def __call__(self, data):
@@ -93,7 +94,12 @@ class RandomJitterPoints(_PointAug):
             assert noise.shape == data["xyz"].shape, f"{noise.shape} vs {data['xyz'].shape}"
             out.aug["jitter_noise"] = noise.to(device=data["xyz"].device, dtype=torch.float32).contiguous()
         else:
-            out.aug.update(jitter_range=self.jitter_range, seed=self.seed, offset=self.calls)
+            dev = data["xyz"].device
+            if self._counter is None or self._counter.device != dev:
+                self._counter = torch.full((1,), self.calls, dtype=torch.int64, device=dev)
+            self._counter += 1
+            out.aug.update(jitter_range=self.jitter_range, seed=self.seed, offset=self.calls,
+                           offset_tensor=self._counter.clone())   # this call's own slot, filled on the device
         self.calls += 1
         return out
 

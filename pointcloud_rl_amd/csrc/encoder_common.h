@@ -24,6 +24,7 @@ struct CloudParams {
     const float* jitter_noise;
     const float* affine;
     unsigned long long seed, offset;
+    const unsigned long long* offset_ptr;
     ChanSrc ch[PCRL_MAX_CHANNELS];
 };
 
@@ -66,8 +67,9 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
             for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[(row * 3 + j) * p.N + n];
         } else {
             const unsigned long long e = (unsigned long long)row * p.N + n;
+            const unsigned long long off = p.offset_ptr ? *p.offset_ptr : p.offset;
             uint32_t w[4];
-            philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)p.offset, (uint32_t)(p.offset >> 32),
+            philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)off, (uint32_t)(off >> 32),
                           (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);
 #pragma unroll
             for (int j = 0; j < 3; ++j) x[j] = x[j] + u01_to_range(w[j], p.jitter_lo, p.jitter_hi);

@@ -251,6 +251,7 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
         if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
         p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
         p.row_mul = aug->row_mul ? aug->row_mul : 1; p.row_add = aug->row_add;
+        p.offset_ptr = reinterpret_cast<const unsigned long long*>(aug->offset_ptr);
         p.jitter_lo = aug->jitter_lo; p.jitter_hi = aug->jitter_hi; p.seed = aug->seed; p.offset = aug->offset;
     }
     return PCRL_OK;

@@ -87,12 +87,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p) {
     if (threadIdx.x == 0) p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
-__global__ void gradnorm_finalize_kernel(const float* partial, int n, float* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        float s = 0.0f;
-        for (int i = 0; i < n; ++i) s += partial[i];
-        out[0] = __builtin_sqrtf(s);
-    }
+__global__ __launch_bounds__(256) void gradnorm_finalize_kernel(const float* partial, int n, float* out) {
+    // one block; thread t sums partial[t], partial[t + 256], ... then a fixed-order tree
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ float s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = __builtin_sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
 }
 
 // theta' <- (1 - tau) theta' + tau theta without an optimizer step (hard_update with tau = 1).
@@ -136,7 +139,7 @@ extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_av
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p);
     PCRL_CHECK_LAUNCH("adam_kernel");
     if (grad_norm_out) {
-        hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(1), 0, st, p.partial, grid, grad_norm_out);
+        hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, p.partial, grid, grad_norm_out);
         PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
     }
     return PCRL_OK;

@@ -125,7 +125,7 @@ def encoder_pack_weights(ew, packed):
     check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
 
 
-def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0):
+def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None):
     flags = 0
     aug = AugDesc()
     aug.row_mul, aug.row_add = int(row_mul), int(row_add)
@@ -135,6 +135,9 @@ def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine
         if jitter_range is not None:
             aug.jitter_lo, aug.jitter_hi = float(jitter_range[0]), float(jitter_range[1])
         aug.seed, aug.offset = int(seed), int(offset)
+        if offset_tensor is not None:
+            assert offset_tensor.dtype == torch.int64 and offset_tensor.is_cuda
+            aug.offset_ptr = offset_tensor.data_ptr()
     if affine is not None:
         flags |= _lib.AUG_AFFINE
         aug.affine = affine.data_ptr()

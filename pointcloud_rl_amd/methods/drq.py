@@ -52,23 +52,25 @@ class DrQ(SAC):
             obs = self.inference_aug(to_torch(obs, device=self.device))
         return super().forward(obs, **kwargs)
 
+    def _step_body(self, batch, do_actor, polyak):
+        B = batch["actions"].shape[0]
+        with torch.no_grad():
+            obs = self._augment(batch["obs"])
+            actions = torch.repeat_interleave(batch["actions"], self.num_aug, dim=0)
+            next_obs = self._augment(batch["next_obs"])
+            rewards = torch.repeat_interleave(batch["rewards"], self.num_aug, dim=0)
+            dones = torch.repeat_interleave(batch["dones"], self.num_aug, dim=0)
+        stats = {}
+        q_target = self._q_target(next_obs, rewards, dones, n_groups=B)
+        self._critic_step(obs, actions, q_target, stats, polyak=polyak)
+        if do_actor:
+            self._actor_step(first_augmentation(obs, B, self.num_aug), stats)
+        return stats
+
     def update_parameters(self, memory, updates):
         if self._flat is None:
             self._prepare()
         sampled_batch = memory.sample(self.batch_size).to_torch(device=self.device, non_blocking=True)
         if self.use_episode_dones:
             sampled_batch["dones"] = sampled_batch["episode_dones"]
-        B = sampled_batch["actions"].shape[0]
-        with torch.no_grad():
-            obs = self._augment(sampled_batch["obs"])
-            actions = torch.repeat_interleave(sampled_batch["actions"], self.num_aug, dim=0)
-            next_obs = self._augment(sampled_batch["next_obs"])
-            rewards = torch.repeat_interleave(sampled_batch["rewards"], self.num_aug, dim=0)
-            dones = torch.repeat_interleave(sampled_batch["dones"], self.num_aug, dim=0)
-        stats = {}
-        q_target = self._q_target(next_obs, rewards, dones, n_groups=B)
-        self._critic_step(obs, actions, q_target, stats, polyak=self._polyak_now(updates))
-        if updates % self.actor_update_interval == 0:
-            self._actor_step(first_augmentation(obs, B, self.num_aug), stats)
-        self._soft_update(updates)
-        return self._finish(stats, updates)
+        return self._run_step(sampled_batch, updates)

@@ -311,11 +311,11 @@ class SAC(BaseAgent):
             self._flat["alpha"].zero_grad()
             alpha_loss.backward()
             self._optim_step("alpha", self._allreduce(self._flat["alpha"].grad) if self.sync_alpha else 1.0)
-            self._alpha_t = self.log_alpha.detach().exp()
+            self._alpha_t.copy_(self.log_alpha.detach().exp())     # in place: captured graphs read this tensor
             stats["alpha_loss"] = alpha_loss.detach().reshape(())
         else:
             stats["alpha_loss"] = torch.zeros((), device=self.device)
-        stats["new_alpha"] = self._alpha_t.reshape(())
+        stats["new_alpha"] = self._alpha_t.reshape(()).clone()
 
     def _finish(self, stats, updates):
         """One device->host copy for every metric the reference reads with .item() (sac.py:140-203)."""
@@ -343,6 +343,68 @@ class SAC(BaseAgent):
         if updates % self.target_update_interval == 0 and not self._polyak_now(updates):
             soft_update(self.target_critic, self.critic, self.update_coeff)
 
+    # -- step execution: eager, or replayed from a hipGraph --------------------------------------
+    def _step_body(self, batch, do_actor, polyak):
+        """SAC step on a device-resident batch; returns the dict of device scalars for the metrics."""
+        stats = {}
+        q_target = self._q_target(batch["next_obs"], batch["rewards"], batch["dones"])
+        self._critic_step(batch["obs"], batch["actions"], q_target, stats, polyak=polyak)
+        if do_actor:
+            self._actor_step(batch["obs"], stats)
+        return stats
+
+    def enable_graphs(self, enabled=True, warmup=2):
+        """Capture the whole update step in a hipGraph (one graph per (actor-update?, target-update?)
+        combination) and replay it: per-step host work drops to copying the batch into static buffers,
+        one graph launch and one device->host copy.  Requires device-resident state only, which is why
+        alpha, the Adam step counts and the Philox offsets live in device memory."""
+        self._use_graphs, self._graph_warmup = enabled, warmup
+        self._graphs, self._graph_seen, self._static_batch = {}, {}, None
+
+    def _to_static(self, batch):
+        """Copy `batch` into buffers whose addresses the captured graphs refer to."""
+        keys = ("obs", "next_obs", "actions", "rewards", "dones")
+        if self._static_batch is None:
+            self._static_batch = {k: ({kk: vv.clone() for kk, vv in batch[k].items()} if isinstance(batch[k], dict) else batch[k].clone())
+                                  for k in keys}
+            return self._static_batch
+        for k in keys:
+            src, dst = batch[k], self._static_batch[k]
+            for kk in (src if isinstance(src, dict) else [None]):
+                s_, d_ = (src[kk], dst[kk]) if kk is not None else (src, dst)
+                if s_.data_ptr() != d_.data_ptr():
+                    d_.copy_(s_, non_blocking=True)
+        return self._static_batch
+
+    def _run_step(self, batch, updates):
+        do_actor = updates % self.actor_update_interval == 0
+        polyak = self._polyak_now(updates)
+        graphable = getattr(self, "_use_graphs", False) and not (self._be_data_parallel and self._world > 1) \
+            and (not (updates % self.target_update_interval == 0) or polyak)
+        if not graphable:
+            stats = self._step_body(batch, do_actor, polyak)
+            self._soft_update(updates)
+            return self._finish({k: v for k, v in stats.items()}, updates)
+        batch = self._to_static(batch)
+        key = (do_actor, polyak)
+        if key not in self._graphs:
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen < self._graph_warmup:          # eager warm-up: lazy initialisation must not be captured
+                return self._finish(self._step_body(batch, do_actor, polyak), updates)
+            if self.encoder is not None:
+                self.encoder.invalidate_packed()   # every replay starts by re-packing the (updated) weights
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                stats = self._step_body(batch, do_actor, polyak)
+                names = list(stats.keys())
+                out = torch.stack([stats[k].reshape(()).float() for k in names])
+            self._graphs[key] = (graph, names, out)
+        graph, names, out = self._graphs[key]
+        graph.replay()
+        return self._finish(dict(zip(names, out.unbind(0))), updates)
+
     def update_parameters(self, memory, updates):
         if self._flat is None:
             self._prepare()
@@ -350,10 +412,4 @@ class SAC(BaseAgent):
         sampled_batch = self.process_obs(sampled_batch)
         if self.use_episode_dones:
             sampled_batch["dones"] = sampled_batch["episode_dones"]
-        stats = {}
-        q_target = self._q_target(sampled_batch["next_obs"], sampled_batch["rewards"], sampled_batch["dones"])
-        self._critic_step(sampled_batch["obs"], sampled_batch["actions"], q_target, stats, polyak=self._polyak_now(updates))
-        if updates % self.actor_update_interval == 0:
-            self._actor_step(sampled_batch["obs"], stats)
-        self._soft_update(updates)
-        return self._finish(stats, updates)
+        return self._run_step(sampled_batch, updates)
