@@ -153,6 +153,70 @@ int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* e
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 
+/* ---- dense heads --------------------------------------------------------------------------------
+ * Batched fp32 GEMM  C[z] = epilogue(A[z] . B[z])  with generic operand strides (elements):
+ *   A[m][k] at A + z*a_batch_stride + m*a_stride_m + k*a_stride_k,  B[k][n] likewise,  C row-major (ldc).
+ * Epilogue: + bias[n]; relu; * (mask[m][n] > 0); accumulate into C.  ones_col >= 0 makes column
+ * `ones_col` of B read as 1 for every k (bias gradient as an extra output column).
+ * A Linear layer y = x W^T + b of the reference's LinearMLP heads (pyrl/networks/backbones/mlp.py:97-100)
+ * maps to:  forward  A = x, B[k][n] = W[n][k] (b_stride_k = 1, b_stride_n = K);
+ *           dx = dy W:   A = dy, B = W (b_stride_k = K_in, b_stride_n = 1), mask = the layer input
+ *           (its ReLU output);  dW|db = dy^T [x | 1]:  A[m][k] = dy[k][m], B = x, ones_col = K_in. */
+typedef struct pcrl_gemm_desc {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* mask;
+    int32_t M, N, K, batch;
+    int64_t a_stride_m, a_stride_k, b_stride_k, b_stride_n, ldc, ld_mask;
+    int64_t a_batch_stride, b_batch_stride, c_batch_stride, bias_batch_stride, mask_batch_stride;
+    int32_t relu, ones_col, accumulate, _pad;
+} pcrl_gemm_desc;
+int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
+
+/* Row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1] = nn.LayerNorm(out), pointnet.py:110).
+ * The result is written to n_dst <= 4 destinations (dst[i] with leading dimension ld_dst[i]): the
+ * concatenated input buffers of the actor / Q heads (Visuomotor's torch.cat, visuomotor.py:130-141).
+ * xhat [M,F] and rstd [M] are saved for the backward.  Backward: dy = dy0 (+ dy1), dx, and
+ * dgamma/dbeta (optionally accumulated); workspace >= ceil(M/4)*2*F floats. */
+int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,
+                                float eps, float* const* dst, const int64_t* ld_dst, int32_t n_dst,
+                                float* xhat, float* rstd, void* stream);
+int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                float* dgamma, float* dbeta, int32_t accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- update tail ---------------------------------------------------------------------------------
+ * Squashed-Gaussian policy head, mode "max-entropy" (TanhGaussianHead + ScaledTanhNormal,
+ * pyrl/networks/regression_heads/gaussian.py:23-50,83-87; pyrl/utils/torch/distributions.py:89,116-127):
+ *   std = exp(clamp(log_std)), u = mean + eps*std, action = tanh(u)*scale + bias,
+ *   log p = sum_j [ -(u-mean)^2/(2 std^2) - log std - log sqrt(2 pi) - log(scale*(1-tanh(u)^2) + epsilon) ].
+ * feat [B, 2A] = mean | log_std.  The action is written to `action` and optionally `action2` (the Q heads'
+ * concatenated input).  saved [B, 2A] keeps tanh(u) | std for the backward.
+ * Backward: d_action = d_action0 (+ d_action1), d_neglogp = device scalar shared by all rows. */
+int pcrl_tanh_gaussian_fwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* scale, const float* bias,
+                               int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                               float* action, int64_t ld_action, float* action2, int64_t ld_action2,
+                               float* neg_logp, float* saved, void* stream);
+int pcrl_tanh_gaussian_bwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* saved, const float* scale,
+                               int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                               const float* d_action0, const float* d_action1, int64_t ld_d_action, const float* d_neglogp,
+                               float* d_feat, int64_t ld_d_feat, void* stream);
+
+/* Double-Q TD target + critic loss (sac.py:125-157; drq.py:76-103 with group = num_aug):
+ *   y = r*reward_scale + (1-done)*gamma*(min_h q_next + exp(log_alpha)*neg_logp_next)  [mean over each
+ *   group of `group` consecutive rows], loss = mse_loss(q, y)*H, dq = d loss / d q,
+ *   stats = {loss, max|q-y|, mean_b min_h q, mean y}. */
+int pcrl_sac_critic_loss_f32(const float* q_next, int64_t ld_q_next, const float* neg_logp_next, const float* rewards,
+                             const uint8_t* dones, const float* log_alpha, float gamma, float reward_scale,
+                             int32_t ignore_dones, int32_t group, const float* q, int64_t ld_q, int32_t B, int32_t H,
+                             float* q_target, float* dq, int64_t ld_dq, float* stats, void* stream);
+/* Actor and temperature losses (sac.py:177-195): actor_loss = -(mean_b min_h q_pi + alpha*mean neg_logp),
+ * alpha_loss = exp(log_alpha)*(entropy - target_entropy); outputs dq_pi, d_neglogp (= -alpha/B),
+ * alpha_grad (= d alpha_loss / d log_alpha), stats = {actor_loss, entropy, alpha_loss}. */
+int pcrl_sac_actor_loss_f32(const float* q_pi, int64_t ld_q, const float* neg_logp, const float* log_alpha, float target_entropy,
+                            int32_t B, int32_t H, float* dq, int64_t ld_dq, float* d_neglogp, float* alpha_grad, float* stats,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

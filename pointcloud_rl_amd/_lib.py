@@ -41,6 +41,16 @@ class EncoderWeights(ctypes.Structure):
                 ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
 
 
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("batch", ctypes.c_int32),
+                ("a_stride_m", ctypes.c_int64), ("a_stride_k", ctypes.c_int64), ("b_stride_k", ctypes.c_int64), ("b_stride_n", ctypes.c_int64),
+                ("ldc", ctypes.c_int64), ("ld_mask", ctypes.c_int64),
+                ("a_batch_stride", ctypes.c_int64), ("b_batch_stride", ctypes.c_int64), ("c_batch_stride", ctypes.c_int64),
+                ("bias_batch_stride", ctypes.c_int64), ("mask_batch_stride", ctypes.c_int64),
+                ("relu", ctypes.c_int32), ("ones_col", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
 class PcrlError(RuntimeError):
     pass
 

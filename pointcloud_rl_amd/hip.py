@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AugDesc, CloudDesc, EncoderWeights, FeatSeg, check, lib
+from ._lib import AugDesc, CloudDesc, EncoderWeights, FeatSeg, GemmDesc, check, lib
 
 _DT = {torch.float32: _lib.DT_F32, torch.uint8: _lib.DT_U8, torch.bool: _lib.DT_BOOL}
 
@@ -221,3 +221,62 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scal
 
 def polyak(target, src, tau):
     check(lib().pcrl_polyak_f32(_ptr(target), _ptr(src), ctypes.c_size_t(target.numel()), ctypes.c_float(tau), _stream()))
+
+
+# ---- dense heads ---------------------------------------------------------------------------------
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+def gemm(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,
+         batch=1, batch_strides=(0, 0, 0, 0, 0)):
+    """C[z] = epilogue(A[z] . B[z]); strides in elements; batch_strides = (A, B, C, bias, mask).  See include/pcrl.h."""
+    d = GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=C.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                 mask=mask.data_ptr() if mask is not None else None, M=M, N=N, K=K, batch=batch,
+                 a_stride_m=a_strides[0], a_stride_k=a_strides[1], b_stride_k=b_strides[0], b_stride_n=b_strides[1], ldc=ldc, ld_mask=ld_mask,
+                 a_batch_stride=batch_strides[0], b_batch_stride=batch_strides[1], c_batch_stride=batch_strides[2],
+                 bias_batch_stride=batch_strides[3], mask_batch_stride=batch_strides[4],
+                 relu=int(relu), ones_col=ones_col, accumulate=int(accumulate))
+    with _span("gemm"):
+        check(lib().pcrl_gemm_f32(ctypes.byref(d), _stream()))
+
+
+def layernorm_rows_fwd(x, ldx, gamma, beta, M, F, eps, dsts, xhat=None, rstd=None):
+    """dsts: list of (tensor, column offset, leading dimension)."""
+    n = len(dsts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() + 4 * off for t, off, _ in dsts])
+    lds = (ctypes.c_int64 * n)(*[ld for _, _, ld in dsts])
+    check(lib().pcrl_layernorm_rows_fwd_f32(_ptr(x), ctypes.c_int64(ldx), _ptr(gamma), _ptr(beta), M, F, _f(eps), ptrs, lds, n,
+                                            _ptr(xhat), _ptr(rstd), _stream()))
+
+
+def layernorm_rows_bwd(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, dgamma, dbeta, workspace, accumulate=False):
+    check(lib().pcrl_layernorm_rows_bwd_f32(ctypes.c_void_p(dy0), ctypes.c_void_p(dy1) if dy1 else None, ctypes.c_int64(lddy), _ptr(xhat), _ptr(rstd),
+                                            _ptr(gamma), M, F, _ptr(dx), ctypes.c_int64(lddx), _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                            _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
+
+
+def tanh_gaussian_fwd(feat, ld_feat, eps, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action, neg_logp, saved=None,
+                      action2_ptr=None, ld_action2=0):
+    check(lib().pcrl_tanh_gaussian_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
+                                           _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
+                                           ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
+                                           _ptr(neg_logp), _ptr(saved), _stream()))
+
+
+def tanh_gaussian_bwd(feat, ld_feat, eps, saved, scale, B, A, ls_min, ls_max, epsilon, da0_ptr, da1_ptr, ld_da, d_neglogp, d_feat, ld_d_feat):
+    check(lib().pcrl_tanh_gaussian_bwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(saved), _ptr(scale), B, A, _f(ls_min), _f(ls_max),
+                                           _f(epsilon), ctypes.c_void_p(da0_ptr), ctypes.c_void_p(da1_ptr) if da1_ptr else None,
+                                           ctypes.c_int64(ld_da), _ptr(d_neglogp), _ptr(d_feat), ctypes.c_int64(ld_d_feat), _stream()))
+
+
+def sac_critic_loss(q_next, ld_qn, neg_logp_next, rewards, dones_u8, log_alpha, gamma, reward_scale, ignore_dones, group, q, ld_q, B, H,
+                    q_target, dq, ld_dq, stats):
+    check(lib().pcrl_sac_critic_loss_f32(_ptr(q_next), ctypes.c_int64(ld_qn), _ptr(neg_logp_next), _ptr(rewards), _ptr(dones_u8), _ptr(log_alpha),
+                                         _f(gamma), _f(reward_scale), int(ignore_dones), int(group), _ptr(q), ctypes.c_int64(ld_q), B, H,
+                                         _ptr(q_target), _ptr(dq), ctypes.c_int64(ld_dq), _ptr(stats), _stream()))
+
+
+def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld_dq, d_neglogp, alpha_grad, stats):
+    check(lib().pcrl_sac_actor_loss_f32(_ptr(q_pi), ctypes.c_int64(ld_q), _ptr(neg_logp), _ptr(log_alpha), _f(target_entropy), B, H,
+                                        _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
