@@ -169,6 +169,8 @@ typedef struct pcrl_gemm_desc {
     int64_t a_stride_m, a_stride_k, b_stride_k, b_stride_n, ldc, ld_mask;
     int64_t a_batch_stride, b_batch_stride, c_batch_stride, bias_batch_stride, mask_batch_stride;
     int32_t relu, ones_col, accumulate, _pad;
+    float* C_ones;                 /* when non-NULL, output column `ones_col` is written to C_ones[m] instead of C */
+    int64_t c_ones_batch_stride;
 } pcrl_gemm_desc;
 int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
 

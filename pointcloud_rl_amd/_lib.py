@@ -48,7 +48,8 @@ class GemmDesc(ctypes.Structure):
                 ("ldc", ctypes.c_int64), ("ld_mask", ctypes.c_int64),
                 ("a_batch_stride", ctypes.c_int64), ("b_batch_stride", ctypes.c_int64), ("c_batch_stride", ctypes.c_int64),
                 ("bias_batch_stride", ctypes.c_int64), ("mask_batch_stride", ctypes.c_int64),
-                ("relu", ctypes.c_int32), ("ones_col", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("ones_col", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("C_ones", ctypes.c_void_p), ("c_ones_batch_stride", ctypes.c_int64)]
 
 
 class PcrlError(RuntimeError):

@@ -25,6 +25,8 @@ struct GemmParams {
     int relu;                // C = max(acc + bias, 0)
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
+    float* C_ones;           // optional separate destination of column `ones_col`
+    long long c_ones_bs;
 };
 
 template <bool A_K4, bool B_K4>
@@ -45,7 +47,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll 2
     for (int q = q_begin; q < q_end; ++q) {
         const int k = 8 * q + 4 * h;
         f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
             if (bias) v = v + bias[col];
             if (p.relu) v = v > 0.0f ? v : 0.0f;
             if (mask) v = mask[(long long)row * p.ld_mask + col] > 0.0f ? v : 0.0f;
-            float* dst = C + (long long)row * p.ldc + col;
+            float* dst = (p.C_ones && col == p.ones_col) ? p.C_ones + bz * p.c_ones_bs + row : C + (long long)row * p.ldc + col;
             *dst = p.accumulate ? *dst + v : v;
         }
     }
@@ -202,6 +203,7 @@ extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
     p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
     p.bias_bs = d->bias_batch_stride; p.mask_bs = d->mask_batch_stride;
     p.relu = d->relu; p.ones_col = d->ones_col; p.accumulate = d->accumulate;
+    p.C_ones = d->C_ones; p.c_ones_bs = d->c_ones_batch_stride;
     auto aligned = [](const float* ptr, long long sm, long long bs) {
         return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && sm % 4 == 0 && bs % 4 == 0;
     };

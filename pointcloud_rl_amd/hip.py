@@ -185,12 +185,14 @@ def encoder_grad_views(flat, ew):
     return out
 
 
-def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None, want_n_active=False):
-    """Flat encoder gradient [pcrl_encoder_num_grads] for d(loss)/d(pooled) = grad_pooled [B,c3]."""
+def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None, want_n_active=False, out=None):
+    """Flat encoder gradient [pcrl_encoder_num_grads] for d(loss)/d(pooled) = grad_pooled [B,c3]
+    (written into `out` when given: a slice of an optimizer's flat gradient buffer)."""
     dev = packed.device
     assert argmax.dtype == torch.int32 and argmax.is_contiguous() and grad_pooled.dtype == torch.float32
     grad_pooled = grad_pooled.contiguous()
-    grads = torch.empty(encoder_num_grads(ew), dtype=torch.float32, device=dev)
+    grads = out if out is not None else torch.empty(encoder_num_grads(ew), dtype=torch.float32, device=dev)
+    assert grads.numel() == encoder_num_grads(ew) and grads.is_contiguous()
     need = ctypes.c_size_t()
     check(lib().pcrl_encoder_bwd_workspace_bytes(desc.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
     if workspace is None or workspace.numel() * workspace.element_size() < need.value:
@@ -229,14 +231,15 @@ def _f(x):
 
 
 def gemm(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,
-         batch=1, batch_strides=(0, 0, 0, 0, 0)):
+         batch=1, batch_strides=(0, 0, 0, 0, 0), c_ones=None, c_ones_batch_stride=0):
     """C[z] = epilogue(A[z] . B[z]); strides in elements; batch_strides = (A, B, C, bias, mask).  See include/pcrl.h."""
     d = GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=C.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
                  mask=mask.data_ptr() if mask is not None else None, M=M, N=N, K=K, batch=batch,
                  a_stride_m=a_strides[0], a_stride_k=a_strides[1], b_stride_k=b_strides[0], b_stride_n=b_strides[1], ldc=ldc, ld_mask=ld_mask,
                  a_batch_stride=batch_strides[0], b_batch_stride=batch_strides[1], c_batch_stride=batch_strides[2],
                  bias_batch_stride=batch_strides[3], mask_batch_stride=batch_strides[4],
-                 relu=int(relu), ones_col=ones_col, accumulate=int(accumulate))
+                 relu=int(relu), ones_col=ones_col, accumulate=int(accumulate),
+                 C_ones=c_ones.data_ptr() if c_ones is not None else None, c_ones_batch_stride=c_ones_batch_stride)
     with _span("gemm"):
         check(lib().pcrl_gemm_f32(ctypes.byref(d), _stream()))
 

@@ -60,6 +60,9 @@ class DrQ(SAC):
             next_obs = self._augment(batch["next_obs"])
             rewards = torch.repeat_interleave(batch["rewards"], self.num_aug, dim=0)
             dones = torch.repeat_interleave(batch["dones"], self.num_aug, dim=0)
+        if self._fused is not None:
+            return self._fused.run(obs, next_obs, actions, rewards, dones, do_actor, polyak, group=self.num_aug,
+                                   actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
         stats = {}
         q_target = self._q_target(next_obs, rewards, dones, n_groups=B)
         self._critic_step(obs, actions, q_target, stats, polyak=polyak)

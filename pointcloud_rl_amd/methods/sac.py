@@ -25,32 +25,41 @@ from .builder import MFRL
 
 
 class FlatBuffer:
-    """Re-homes a list of parameters into one contiguous buffer (data and grad as views)."""
+    """Re-homes a list of parameters into one contiguous buffer (data and grad as views).  Every
+    tensor starts on a 16-byte boundary so that the GEMM kernels can use 16-byte operand loads; the
+    padding floats stay zero (zero gradient -> Adam leaves them at zero)."""
+
+    ALIGN = 4    # floats
 
     def __init__(self, named_params, with_grad=True):
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.data = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev) if with_grad else None
-        o = 0
+        self.offsets, o = [], 0
         for p in self.params:
+            self.offsets.append(o)
+            o += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = o
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_grad else None
+        for p, o in zip(self.params, self.offsets):
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + n].view(p.shape)
             if with_grad:
                 p.grad = self.grad[o:o + n].view(p.shape)
-            o += n
+
+    def offset_of(self, name):
+        return self.offsets[self.names.index(name)]
+
+    def views(self, flat_tensor):
+        return [flat_tensor[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
 
     def zero_grad(self):
         self.grad.zero_()
-        o = 0
-        for p in self.params:   # re-attach in case something set .grad to None
-            n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad[o:o + n].data_ptr():
-                p.grad = self.grad[o:o + n].view(p.shape)
-            o += n
+        for p, g in zip(self.params, self.views(self.grad)):   # re-attach in case something set .grad to None
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
 
     def grad_norm_sq(self):
         return (self.grad * self.grad).sum()
@@ -85,11 +94,7 @@ class HipAdam:
                       target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau)
 
     def _views(self, flat_tensor):
-        out, o = [], 0
-        for p in self.flat.params:
-            out.append(flat_tensor[o:o + p.numel()].view(p.shape))
-            o += p.numel()
-        return out
+        return self.flat.views(flat_tensor)
 
     def state_dict(self):
         step = self.step_counter.to(torch.float32).reshape(())
@@ -155,6 +160,7 @@ class SAC(BaseAgent):
             self.alpha = self.log_alpha.exp().item()
         self.alpha_optim = build_optimizer(self.log_alpha, alpha_optim_cfg)
         self._flat = None
+        self.use_fused_step = True   # autograd-free launch sequence (methods/fused.py) when the topology allows
         self.sync_alpha = True     # data-parallel: all-reduce log_alpha's gradient too (the reference does not)
 
     # ---------------------------------------------------------------------------------------------
@@ -191,15 +197,17 @@ class SAC(BaseAgent):
                if n in {tn for tn, _ in tgt}]
         taus = {self._tau_for(n) for n, _ in own}
         if tgt and len(own) == len(tgt) and len(taus) == 1 and [n for n, _ in own] == [n for n, _ in tgt]:
-            first = self._flat["critic"].names.index(own[0][0])
-            begin = sum(p.numel() for p in self._flat["critic"].params[:first])
-            count = sum(p.numel() for _, p in own)
-            if first + len(own) == len(self._flat["critic"].params):
-                self._target_flat = FlatBuffer(tgt, with_grad=False)
-                self._target_range = (begin, begin + count)
-                self._target_tau = taus.pop()
+            fc = self._flat["critic"]
+            first = fc.names.index(own[0][0])
+            if first + len(own) == len(fc.params):
+                target_flat = FlatBuffer(tgt, with_grad=False)
+                begin = fc.offsets[first]
+                if target_flat.total == fc.total - begin:      # same relative layout (identical padding)
+                    self._target_flat, self._target_range, self._target_tau = target_flat, (begin, fc.total), taus.pop()
         self._alpha_t = self.log_alpha.detach().exp()
         self._dedup = self._encoder_is_shared()
+        from .fused import FusedStep
+        self._fused = FusedStep(self) if (self.use_fused_step and FusedStep.supported(self)) else None
         self._world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
 
     def _tau_for(self, name):
@@ -346,6 +354,8 @@ class SAC(BaseAgent):
     # -- step execution: eager, or replayed from a hipGraph --------------------------------------
     def _step_body(self, batch, do_actor, polyak):
         """SAC step on a device-resident batch; returns the dict of device scalars for the metrics."""
+        if self._fused is not None:
+            return self._fused.run(batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak)
         stats = {}
         q_target = self._q_target(batch["next_obs"], batch["rewards"], batch["dones"])
         self._critic_step(batch["obs"], batch["actions"], q_target, stats, polyak=polyak)

@@ -140,6 +140,23 @@ class PointNet(ExtendedModule):
         desc, keep = hip.make_cloud_desc(inputs)
         return _EncoderFn.apply(self, desc, keep, aug, *self.conv.kernel_params())
 
+    # -- autograd-free entry points used by the fused update step --------------------------------
+    def encode_raw(self, inputs):
+        """(pooled [B,c3], argmax [B,c3] int32, ctx) without building an autograd graph."""
+        aug = getattr(inputs, "aug", None)
+        if torch.is_tensor(inputs):
+            inputs = {"xyz": inputs.to(dtype=torch.float32)}
+        desc, keep = hip.make_cloud_desc(inputs)
+        ew, packed = self._weights_desc()
+        aug_desc = hip.make_aug_desc(**aug) if aug else None
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"))
+        return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed)
+
+    def backward_raw(self, ctx, argmax, grad_pooled, out):
+        """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
+        desc, keep, aug, aug_desc, ew, packed = ctx
+        hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out)
+
     def forward(self, inputs, object_feature=True, concat_state=None, **kwargs):
         feature, _ = self.pooled(inputs)
         if self.final_mlp is not None:
