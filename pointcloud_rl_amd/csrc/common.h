@@ -94,8 +94,11 @@ __device__ __forceinline__ unsigned allreduce_umax32(unsigned v) {
     v = umax_(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
     v = umax_(v, dpp_u<0x141>(v));   // row_half_mirror
     v = umax_(v, dpp_u<0x140>(v));   // row_mirror
-    v = umax_(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));  // lane ^ 16
-    return v;
+    // lane ^ 16 without the LDS pipe: v_permlane16_swap exchanges row 1 of vdst with row 0 of vsrc and
+    // row 3 of vdst with row 2 of vsrc (rows = 16 lanes), so with both operands = v the two results
+    // hold {row0,row0,row2,row2} and {row1,row1,row3,row3}.
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return umax_(r[0], r[1]);
 }
 
 // Philox4x32-10 (Salmon et al. 2011); one call yields four 32-bit words.

@@ -29,9 +29,35 @@ struct GemmParams {
     long long c_ones_bs;
 };
 
+constexpr int kGemmWaves = 8;
+
 template <bool A_K4, bool B_K4>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float s_red[4][16][64];
+__device__ __forceinline__ void gemm_load_chunk(const GemmParams& p, const float* a_row, const float* b_col, int k,
+                                                bool m_ok, bool n_ok, bool n_ones, f32x4& a, f32x4& b) {
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (A_K4 && k + 3 < p.K) {
+        if (m_ok) a = *reinterpret_cast<const f32x4*>(a_row + k);
+    } else if (m_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < p.K) a[j] = a_row[(long long)(k + j) * p.a_sk];
+    }
+    if (n_ones) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = k + j < p.K ? 1.0f : 0.0f;
+    } else if (B_K4 && k + 3 < p.K) {
+        if (n_ok) b = *reinterpret_cast<const f32x4*>(b_col + k);
+    } else if (n_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k + j < p.K) b[j] = b_col[(long long)(k + j) * p.b_sk];
+    }
+}
+
+template <bool A_K4, bool B_K4>
+__global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float s_red[kGemmWaves][16][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, bz = blockIdx.z;
     const float* A = p.A + bz * p.a_bs;
@@ -39,7 +65,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const int m = m0 + i, n = n0 + i;
     const bool m_ok = m < p.M, n_ok = n < p.N, n_ones = n == p.ones_col;
     const int n_chunks = (p.K + 7) / 8;
-    const int per_wave = (n_chunks + 3) / 4;
+    const int per_wave = (n_chunks + kGemmWaves - 1) / kGemmWaves;
     const int q_begin = wave * per_wave, q_end = min(q_begin + per_wave, n_chunks);
     const float* a_row = A + (long long)m * p.a_sm;
     const float* b_col = B + (long long)n * p.b_sn;
@@ -47,28 +73,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    for (int q = q_begin; q < q_end; ++q) {
-        const int k = 8 * q + 4 * h;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-        if (A_K4 && k + 3 < p.K) {
-            if (m_ok) a = *reinterpret_cast<const f32x4*>(a_row + k);
-        } else if (m_ok) {
+    // two chunks (8 MFMAs) in flight per iteration, next pair's loads issued before this pair's MFMAs
+    f32x4 a0, b0, a1, b1;
+    int q = q_begin;
+    if (q < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * q + 4 * h, m_ok, n_ok, n_ones, a0, b0);
+    if (q + 1 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 1) + 4 * h, m_ok, n_ok, n_ones, a1, b1);
+    for (; q < q_end; q += 2) {
+        const f32x4 ca0 = a0, cb0 = b0, ca1 = a1, cb1 = b1;
+        const bool second = q + 1 < q_end;
+        if (q + 2 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 2) + 4 * h, m_ok, n_ok, n_ones, a0, b0);
+        if (q + 3 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 3) + 4 * h, m_ok, n_ok, n_ones, a1, b1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j < p.K) a[j] = a_row[(long long)(k + j) * p.a_sk];
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[j], cb0[j], acc, 0, 0, 0);
+        if (second) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[j], cb1[j], acc, 0, 0, 0);
         }
-        if (n_ones) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = k + j < p.K ? 1.0f : 0.0f;
-        } else if (B_K4 && k + 3 < p.K) {
-            if (n_ok) b = *reinterpret_cast<const f32x4*>(b_col + k);
-        } else if (n_ok) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j < p.K) b[j] = b_col[(long long)(k + j) * p.b_sk];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
@@ -77,11 +97,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
     const float* bias = p.bias ? p.bias + bz * p.bias_bs : nullptr;
     const float* mask = p.mask ? p.mask + bz * p.mask_bs : nullptr;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int idx = tid + 256 * e, r = idx >> 6, ln = idx & 63;
+    for (int e = 0; e < 1024 / (64 * kGemmWaves); ++e) {
+        const int idx = tid + 64 * kGemmWaves * e, r = idx >> 6, ln = idx & 63;
         const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
         if (row < p.M && col < p.N) {
-            float v = (s_red[0][r][ln] + s_red[1][r][ln]) + (s_red[2][r][ln] + s_red[3][r][ln]);
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kGemmWaves; w += 2) v = v + (s_red[w][r][ln] + s_red[w + 1][r][ln]);
             if (bias) v = v + bias[col];
             if (p.relu) v = v > 0.0f ? v : 0.0f;
             if (mask) v = mask[(long long)row * p.ld_mask + col] > 0.0f ? v : 0.0f;
@@ -211,10 +233,10 @@ extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
     const bool b4 = p.b_sk == 1 && aligned(p.B, p.b_sn, p.b_bs);
     const dim3 grid((p.N + 31) / 32, (p.M + 31) / 32, d->batch);
     hipStream_t st = (hipStream_t)stream;
-    if (a4 && b4) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, p);
-    else if (a4) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, p);
-    else if (b4) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, p);
+    if (a4 && b4) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(64 * kGemmWaves), 0, st, p);
+    else if (a4) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(64 * kGemmWaves), 0, st, p);
+    else if (b4) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(64 * kGemmWaves), 0, st, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(64 * kGemmWaves), 0, st, p);
     PCRL_CHECK_LAUNCH("gemm_f32_kernel");
     return PCRL_OK;
 }

@@ -218,19 +218,12 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb) {
+            for (int mb = 0; mb < MB2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
-#pragma unroll
-                for (int tq = 0; tq < C1 / 8; ++tq) {
-                    const f32x4 w = buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        a1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a0[t >> 4][t & 15], a1[mb], 0, 0, 0);
-                    }
-                }
-            }
+            dense_layer_mfma<MB2, C1 / 8, 3>(
+                a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                [&](int t) { return a0[t >> 4][t & 15]; });
             const float rstd1 = ln_to_xhat<kC2>(a1, p.eps);
 #pragma unroll
             for (int mb = 0; mb < MB2; ++mb)
@@ -245,19 +238,12 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb) {
+            for (int mb = 0; mb < MB3; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a2[mb][r] = 0.0f;
-#pragma unroll
-                for (int tq = 0; tq < kC2 / 8; ++tq) {
-                    const f32x4 w = s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        a2[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a1[t >> 4][t & 15], a2[mb], 0, 0, 0);
-                    }
-                }
-            }
+            dense_layer_mfma<MB3, kC2 / 8, 2>(
+                a2, [&](int mb, int tq) { return s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane]; },
+                [&](int t) { return a1[t >> 4][t & 15]; });
             const float rstd2 = ln_to_xhat<kC3>(a2, p.eps);
 
             // ---- max-pool + ReLU + LN2 backward ----------------------------------------------------
@@ -314,19 +300,12 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb) {
+            for (int mb = 0; mb < MB2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) d1[mb][r] = 0.0f;
-#pragma unroll
-                for (int tq = 0; tq < kC3 / 8; ++tq) {
-                    const f32x4 w = buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        d1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a2[t >> 4][t & 15], d1[mb], 0, 0, 0);
-                    }
-                }
-            }
+            dense_layer_mfma<MB2, kC3 / 8, 3>(
+                d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
+                [&](int t) { return a2[t >> 4][t & 15]; });
             f32x16 xh1[MB2];
             s1 = 0.0f; s2 = 0.0f;
 #pragma unroll
@@ -359,24 +338,19 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
                 }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
+            f32x16 d0[MB1];
 #pragma unroll
-            for (int mb = 0; mb < MB1; ++mb) {
-                f32x16 d0;
+            for (int mb = 0; mb < MB1; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) d0[r] = 0.0f;
+                for (int r = 0; r < 16; ++r) d0[mb][r] = 0.0f;
+            dense_layer_mfma<MB1, kC2 / 8, 3>(
+                d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
+                [&](int t) { return d1[t >> 4][t & 15]; });
 #pragma unroll
-                for (int tq = 0; tq < kC2 / 8; ++tq) {
-                    const f32x4 w = buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], d1[t >> 4][t & 15], d0, 0, 0, 0);
-                    }
-                }
+            for (int mb = 0; mb < MB1; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[r] : 0.0f);
-            }
+                    buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
         }
         __syncthreads();
         if (tid < 2 * kC2) {   // norm1 gradients: fixed-order sum over the waves of this cloud

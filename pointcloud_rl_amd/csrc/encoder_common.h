@@ -137,6 +137,56 @@ __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __
     return nan_pt;
 }
 
+// Streams the A operands of one dense layer through a register ring DEPTH groups deep: group g
+// (4 k-steps of one 32-row block) is consumed while groups g+1 .. g+DEPTH are in flight, so the
+// L2 / LDS latency of an operand load is hidden behind 4*DEPTH MFMAs instead of being paid per group.
+// `load(g)` returns the f32x4 of group g, `body(g, w)` issues its 4 MFMAs.  Fully unrolled.
+template <int NG, int DEPTH, class LoadFn, class BodyFn>
+__device__ __forceinline__ void stream_operands(LoadFn load, BodyFn body) {
+    f32x4 ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < NG) ring[d] = load(d);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 w = ring[g % DEPTH];
+        if (g + DEPTH < NG) ring[g % DEPTH] = load(g + DEPTH);
+        body(g, w);
+    }
+}
+
+// One dense layer on the MFMA: acc[mb] += W[32mb.., :] . act, all MB row blocks, K = 8 * TQ channels.
+// Two row blocks are advanced together so that consecutive MFMAs never touch the same accumulator
+// (a dependent v_mfma_f32_32x32x2_f32 must otherwise issue in the exact cycle its predecessor retires;
+// any instruction slipped in between -- an operand load, a wait -- idles the matrix pipe), and the A
+// operands of pair-group g + DEPTH are in flight while group g computes.
+// load(mb, tq) -> the f32x4 holding A operands of k-steps 4tq..4tq+3 of row block mb;
+// act(t) -> the B operand (activation register) of k-step t.
+template <int MB, int TQ, int DEPTH, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    static_assert(MB % 2 == 0, "row blocks are processed in pairs");
+    constexpr int NG = (MB / 2) * TQ;
+    f32x4 ra[DEPTH], rb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < NG) { ra[d] = load(2 * (d / TQ), d % TQ); rb[d] = load(2 * (d / TQ) + 1, d % TQ); }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 wa = ra[g % DEPTH], wb = rb[g % DEPTH];
+        if (g + DEPTH < NG) {
+            ra[g % DEPTH] = load(2 * ((g + DEPTH) / TQ), (g + DEPTH) % TQ);
+            rb[g % DEPTH] = load(2 * ((g + DEPTH) / TQ) + 1, (g + DEPTH) % TQ);
+        }
+        const int mb = 2 * (g / TQ), tq = g % TQ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float b = act(4 * tq + j);
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, acc[mb], 0, 0, 0);
+            acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, acc[mb + 1], 0, 0, 0);
+        }
+    }
+}
+
 // Host side: validate the descriptors of the C ABI and flatten them into CloudParams.
 int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out);
 

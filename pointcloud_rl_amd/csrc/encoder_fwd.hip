@@ -46,15 +46,16 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     float* s_w2 = s_w0 + MB1 * T0 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
 
     {   // prologue: weights -> LDS, once per workgroup
         const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        for (int i = tid; i < C3 * C2 / 4; i += 512) s[i] = g[i];
-        for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
-        for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
-        for (int i = tid; i < 2 * C2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
-        for (int i = tid; i < 2 * C3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
+        for (int i = tid; i < C3 * C2 / 4; i += nthreads) s[i] = g[i];
+        for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
+        for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
+        for (int i = tid; i < 2 * C2; i += nthreads) s_ln1[i] = p.packed[L.ln1() + i];
+        for (int i = tid; i < 2 * C3; i += nthreads) s_ln2[i] = p.packed[L.ln2() + i];
         if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
     }
     const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
@@ -66,10 +67,10 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
         const int t_begin = seg * p.tiles_per_seg;
         const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
         __syncthreads();   // previous read-out of s_keys (and the prologue) is complete
-        for (int i = tid; i < C3; i += 512) s_keys[i] = 0ull;
+        for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0ull;
         __syncthreads();
 
-        for (int tile = t_begin + wave; tile < t_end; tile += 8) {
+        for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
             const int pidx = tile * 32 + l31;
             const bool valid = pidx < p.cl.N;
             const int pc = valid ? pidx : p.cl.N - 1;
@@ -95,37 +96,23 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             // ---- conv1 + LN + ReLU --------------------------------------------------------
             f32x16 a1[MB2];
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb) {
+            for (int mb = 0; mb < MB2; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
-#pragma unroll
-                for (int tq = 0; tq < C1 / 8; ++tq) {
-                    const f32x4 w = buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        a1[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a0[t >> 4][t & 15], a1[mb], 0, 0, 0);
-                    }
-                }
-            }
+            dense_layer_mfma<MB2, C1 / 8, 3>(
+                a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                [&](int t) { return a0[t >> 4][t & 15]; });
             ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
 
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb) {
+            for (int mb = 0; mb < MB3; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) a2[mb][r] = 0.0f;
-#pragma unroll
-                for (int tq = 0; tq < C2 / 8; ++tq) {
-                    const f32x4 w = s_w2v[(mb * (C2 / 8) + tq) * 64 + lane];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int t = 4 * tq + j;
-                        a2[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], a1[t >> 4][t & 15], a2[mb], 0, 0, 0);
-                    }
-                }
-            }
+            dense_layer_mfma<MB3, C2 / 8, 2>(
+                a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
+                [&](int t) { return a1[t >> 4][t & 15]; });
             const bool nan_pt = ln_relu_acc<C3, true>(a2, s_ln2, half, p.eps);
             if (__builtin_expect(__ballot(nan_pt) != 0ull, 0)) {
                 // torch: a NaN wins the max and the first NaN's index is returned
@@ -154,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             }
         }
         __syncthreads();
-        for (int c = tid; c < C3; c += 512) {
+        for (int c = tid; c < C3; c += nthreads) {
             const unsigned long long key = s_keys[c];
             if (p.S == 1) {
                 unsigned vb = (unsigned)(key >> 32);

@@ -19,14 +19,12 @@ struct AdamParams {
     float* exp_avg_sq;
     long long n;
     float lr, beta1, beta2, eps, grad_scale;
-    const int* step;          // device: number of steps INCLUDING this one
+    const int* step;          // device: number of steps BEFORE this one
     float* target;            // Polyak: target[i - t_begin] for t_begin <= i < t_end (may be NULL)
     long long t_begin, t_end;
     float tau;
     float* partial;           // [gridDim.x] sum of (scaled) grad^2 per block
 };
-
-__global__ void counter_inc_kernel(int* step) { step[0] += 1; }
 
 __device__ __forceinline__ void adam_elem(const AdamParams& p, float g_raw, float& m, float& v, float& w,
                                           float step_size, float bc2_sqrt, float& gsq) {
@@ -38,7 +36,7 @@ __device__ __forceinline__ void adam_elem(const AdamParams& p, float g_raw, floa
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p) {
-    const float step = (float)p.step[0];
+    const float step = (float)(p.step[0] + 1);
     const float bc1 = 1.0f - powf(p.beta1, step);
     const float bc2_sqrt = __builtin_sqrtf(1.0f - powf(p.beta2, step));
     const float step_size = p.lr / bc1;
@@ -87,7 +85,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p) {
     if (threadIdx.x == 0) p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
 }
 
-__global__ __launch_bounds__(256) void gradnorm_finalize_kernel(const float* partial, int n, float* out) {
+__global__ __launch_bounds__(256) void gradnorm_finalize_kernel(const float* partial, int n, float* out, int* step) {
+    // runs after adam_kernel on the same stream: the only writer of the step counter
+    if (threadIdx.x == 0) step[0] += 1;
+    if (!out) return;
     // one block; thread t sums partial[t], partial[t + 256], ... then a fixed-order tree
     float s = 0.0f;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -135,13 +136,10 @@ extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_av
     hipStream_t st = (hipStream_t)stream;
     AdamParams p{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, grad_scale, step_counter,
                  target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace)};
-    hipLaunchKernelGGL(counter_inc_kernel, dim3(1), dim3(1), 0, st, step_counter);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p);
     PCRL_CHECK_LAUNCH("adam_kernel");
-    if (grad_norm_out) {
-        hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, p.partial, grid, grad_norm_out);
-        PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
-    }
+    hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, p.partial, grid, grad_norm_out, step_counter);
+    PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
     return PCRL_OK;
 }
 
