@@ -107,12 +107,13 @@ def main():
     from pointcloud_rl_amd.synthetic import SyntheticReplay
     agent, C = build_agent(wl, b_rank, device)
     if world > 1:
-        for p in agent.parameters():                      # replicas start identical (DDP's constructor broadcast)
-            torch.distributed.broadcast(p.data, 0)
+        from pointcloud_rl_amd.utils.dist import broadcast_parameters_
+        broadcast_parameters_(agent)                      # replicas start identical (DDP's constructor broadcast)
         agent.to_ddp(device_ids=["cuda"])
     # every rank generates the global batch with the same seed and keeps its shard resident in HBM
     full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
-    sl = slice(rank * b_rank, (rank + 1) * b_rank)
+    from pointcloud_rl_amd.utils.dist import shard_slice
+    sl = shard_slice(wl["B"], rank, world)
     shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
     memory = SyntheticReplay.__new__(SyntheticReplay)
     from pointcloud_rl_amd.utils.torch_utils import to_torch

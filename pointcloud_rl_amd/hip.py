@@ -73,7 +73,9 @@ def make_cloud_desc(obs):
         obs = {"xyz": obs}
     keep, segs = [], []
     xyz = obs["xyz"]
-    assert xyz.is_cuda and xyz.ndim == 3, f"xyz must be a CUDA [B,C,N] tensor, got {tuple(xyz.shape)} on {xyz.device}"
+    if not xyz.is_cuda:
+        raise RuntimeError(f"point clouds must live on the MI355X (got device {xyz.device}); pointcloud_rl_amd has no CPU encoder")
+    assert xyz.ndim == 3, f"xyz must be a [B,C,N] tensor, got {tuple(xyz.shape)}"
     B, _, N = xyz.shape
     for key in ("xyz", "rgb", "pos_encoding", "seg"):
         if key not in obs:

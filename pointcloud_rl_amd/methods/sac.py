@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
+from ..utils.dist import allreduce_sum_
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -221,10 +222,7 @@ class SAC(BaseAgent):
 
     def _allreduce(self, tensor):
         """Sum the flat gradient over the ranks (RCCL); the 1/world factor is applied by the optimizer kernel."""
-        if self._be_data_parallel and self._world > 1:
-            torch.distributed.all_reduce(tensor)
-            return 1.0 / self._world
-        return 1.0
+        return allreduce_sum_(tensor, enabled=self._be_data_parallel)
 
     def _optim_step(self, name, scale, polyak=False):
         opt = getattr(self, f"{name}_optim")
