@@ -153,6 +153,17 @@ int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* e
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 
+/* ---- stand-alone memory-shaped kernels -----------------------------------------------------------
+ * Symmetric max-pool with first-index argmax over a materialised [rows, N] f32 tensor (rows = B*c) and
+ * its backward: `feature.max(-1)` (pointnet.py:151).  torch CPU rules: first index among equal values;
+ * a NaN wins and the first NaN's index is returned.  HBM-bound: 4 B/element read (forward) or written
+ * (backward). */
+int pcrl_segmax_fwd_f32(const float* x, int64_t rows, int32_t N, float* out, int32_t* idx, void* stream);
+int pcrl_segmax_bwd_f32(const float* grad_out, const int32_t* idx, int64_t rows, int32_t N, float* grad_x, void* stream);
+/* RandomJitterPoints / GlobalRotScaleTrans applied to a [B,3,N] f32 tensor (in place when xyz_out ==
+ * xyz_in): pcd_aug.py:306-327, 84-123.  Same pcrl_aug_desc semantics as the fused encoder load. */
+int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t B, int32_t N, const pcrl_aug_desc* aug, void* stream);
+
 /* ---- dense heads --------------------------------------------------------------------------------
  * Batched fp32 GEMM  C[z] = epilogue(A[z] . B[z])  with generic operand strides (elements):
  *   A[m][k] at A + z*a_batch_stride + m*a_stride_m + k*a_stride_k,  B[k][n] likewise,  C row-major (ldc).

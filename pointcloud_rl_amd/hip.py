@@ -285,3 +285,33 @@ def sac_critic_loss(q_next, ld_qn, neg_logp_next, rewards, dones_u8, log_alpha, 
 def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld_dq, d_neglogp, alpha_grad, stats):
     check(lib().pcrl_sac_actor_loss_f32(_ptr(q_pi), ctypes.c_int64(ld_q), _ptr(neg_logp), _ptr(log_alpha), _f(target_entropy), B, H,
                                         _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
+
+
+# ---- stand-alone memory-shaped kernels --------------------------------------------------------------
+def segmax_fwd(x):
+    """x [..., N] f32 contiguous -> (max [...], argmax [...] int32), torch.max(dim=-1) semantics."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    N, rows = x.shape[-1], x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    idx = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+    with _span("segmax_fwd"):
+        check(lib().pcrl_segmax_fwd_f32(_ptr(x), ctypes.c_int64(rows), N, _ptr(out), _ptr(idx), _stream()))
+    return out, idx
+
+
+def segmax_bwd(grad_out, idx, N):
+    grad_out = grad_out.contiguous()
+    dx = torch.empty(tuple(idx.shape) + (N,), dtype=torch.float32, device=idx.device)
+    with _span("segmax_bwd"):
+        check(lib().pcrl_segmax_bwd_f32(_ptr(grad_out), _ptr(idx), ctypes.c_int64(idx.numel()), N, _ptr(dx), _stream()))
+    return dx
+
+
+def augment_xyz(xyz, out=None, **aug):
+    """Materialised RandomJitterPoints / GlobalRotScaleTrans on xyz [B,3,N] (same keywords as make_aug_desc)."""
+    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous() and xyz.shape[1] == 3
+    out = torch.empty_like(xyz) if out is None else out
+    desc = make_aug_desc(**aug)
+    with _span("augment_xyz"):
+        check(lib().pcrl_augment_xyz_f32(_ptr(xyz), _ptr(out), xyz.shape[0], xyz.shape[2], ctypes.byref(desc), _stream()))
+    return out

@@ -24,6 +24,16 @@ class AugmentedObs(dict):
     aug = None           # dict(jitter_noise=, jitter_range=, seed=, offset=, affine=)
 
 
+def materialize(obs):
+    """Apply a pending augmentation of an AugmentedObs to its xyz tensor (for consumers other than the
+    fused encoder, e.g. visualisation); returns a plain dict."""
+    aug = getattr(obs, "aug", None)
+    out = dict(obs)
+    if aug:
+        out["xyz"] = hip.augment_xyz(obs["xyz"].contiguous(), **aug)
+    return out
+
+
 class ConvMLP(ExtendedModule):
     """Holds the shared per-point MLP's parameters under the reference's names (mlp.py:43-56, 103-108)."""
 
