@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
+                    "exercising the multi-process path with several ranks on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -96,10 +99,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)   # RCCL
+        torch.distributed.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     assert wl["B"] % world == 0, "batch must divide over the ranks"
     b_rank = wl["B"] // world
 

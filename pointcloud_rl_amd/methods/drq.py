@@ -70,6 +70,17 @@ class DrQ(SAC):
             self._actor_step(first_augmentation(obs, B, self.num_aug), stats)
         return stats
 
+    def _fused_args(self, batch, do_actor, polyak):
+        B = batch["actions"].shape[0]
+        with torch.no_grad():
+            obs = self._augment(batch["obs"])
+            actions = torch.repeat_interleave(batch["actions"], self.num_aug, dim=0)
+            next_obs = self._augment(batch["next_obs"])
+            rewards = torch.repeat_interleave(batch["rewards"], self.num_aug, dim=0)
+            dones = torch.repeat_interleave(batch["dones"], self.num_aug, dim=0)
+        return (obs, next_obs, actions, rewards, dones, do_actor, polyak), dict(
+            group=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
+
     def update_parameters(self, memory, updates):
         if self._flat is None:
             self._prepare()

@@ -166,7 +166,25 @@ class FusedStep:
         return feat, eps, saved, nlp, h1, h2
 
     # -- the step -------------------------------------------------------------------------------------
-    def run(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None):
+    def run(self, *args, **kwargs):
+        """Execute the step in one go; gradient exchanges (data-parallel) happen inline."""
+        a = self.a
+        gen = self.steps(*args, **kwargs)
+        exchange = next(gen)
+        try:
+            while True:
+                scale = 1.0
+                for t in exchange:
+                    scale = a._allreduce(t)
+                exchange = gen.send(scale)
+        except StopIteration as done:
+            return done.value
+
+    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None):
+        """Generator form of the step: yields the flat gradient buffers that have to be all-reduced at
+        that point (empty list when single-process semantics suffice) and receives the factor 1/world
+        to fold into the optimizer pass.  Between two yields no cross-rank communication happens, so
+        every stretch can be captured as its own hipGraph while the collectives stay eager."""
         a = self.a
         enc, F, S, A, H = a.encoder, self.F, self.S, self.A, self.H
         ldq, lda = self.ldq, self.lda
@@ -216,7 +234,8 @@ class FusedStep:
         dpooled = self._buf("dpooled", M, c3)
         hip.gemm(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
-        stats["critic_grad"] = a._optim_step("critic", a._allreduce(fc.grad), polyak=polyak)
+        scale = yield [fc.grad]
+        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak)
         enc.invalidate_packed()
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
 
@@ -246,8 +265,9 @@ class FusedStep:
                                   d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
-            stats["actor_grad"] = a._optim_step("actor", a._allreduce(fa.grad))
-            a._optim_step("alpha", a._allreduce(fal.grad) if a.sync_alpha else 1.0)
+            scale = yield ([fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
+            stats["actor_grad"] = a._optim_step("actor", scale)
+            a._optim_step("alpha", scale if a.sync_alpha else 1.0)
             a._alpha_t.copy_(a.log_alpha.detach().exp())
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2],
                          new_alpha=a._alpha_t.reshape(()).clone())

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.dist import allreduce_sum_
+from ..utils.dist import allreduce_sum_, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -384,11 +384,15 @@ class SAC(BaseAgent):
                     d_.copy_(s_, non_blocking=True)
         return self._static_batch
 
+    def _fused_args(self, batch, do_actor, polyak):
+        return (batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), {}
+
     def _run_step(self, batch, updates):
         do_actor = updates % self.actor_update_interval == 0
         polyak = self._polyak_now(updates)
-        graphable = getattr(self, "_use_graphs", False) and not (self._be_data_parallel and self._world > 1) \
-            and (not (updates % self.target_update_interval == 0) or polyak)
+        exchanging = self._be_data_parallel and world_size() > 1
+        graphable = getattr(self, "_use_graphs", False) and (not (updates % self.target_update_interval == 0) or polyak) \
+            and (not exchanging or self._fused is not None)
         if not graphable:
             stats = self._step_body(batch, do_actor, polyak)
             self._soft_update(updates)
@@ -403,15 +407,53 @@ class SAC(BaseAgent):
             if self.encoder is not None:
                 self.encoder.invalidate_packed()   # every replay starts by re-packing the (updated) weights
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                stats = self._step_body(batch, do_actor, polyak)
-                names = list(stats.keys())
-                out = torch.stack([stats[k].reshape(()).float() for k in names])
-            self._graphs[key] = (graph, names, out)
-        graph, names, out = self._graphs[key]
-        graph.replay()
+            self._graphs[key] = self._capture_segments(batch, do_actor, polyak) if exchanging else self._capture_whole(batch, do_actor, polyak)
+            if exchanging:                          # capturing a segmented step also executed it
+                segments, names, out = self._graphs[key]
+                return self._finish(dict(zip(names, out.unbind(0))), updates)
+        segments, names, out = self._graphs[key]
+        for graph, exchange in segments:
+            graph.replay()
+            for t in exchange:
+                allreduce_sum_(t)
         return self._finish(dict(zip(names, out.unbind(0))), updates)
+
+    def _capture_whole(self, batch, do_actor, polyak):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            stats = self._step_body(batch, do_actor, polyak)
+            names = list(stats.keys())
+            out = torch.stack([stats[k].reshape(()).float() for k in names])
+        return [(graph, [])], names, out
+
+    def _capture_segments(self, batch, do_actor, polyak):
+        """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay
+        eager between the graph launches (no collective is ever captured).  Capturing records without
+        executing, so each segment is replayed right after its capture to carry the step forward."""
+        pool = torch.cuda.graph_pool_handle()
+        scale = 1.0 / world_size()
+        segments, names, out, gen = [], None, None, None
+        while names is None:
+            graph = torch.cuda.CUDAGraph()
+            exchange = []
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                try:
+                    if gen is None:     # batch preparation (DrQ: repeat + augmentation draws) belongs to the first segment
+                        args, kwargs = self._fused_args(batch, do_actor, polyak)
+                        gen = self._fused.steps(*args, **kwargs)
+                        exchange = next(gen)
+                    else:
+                        exchange = gen.send(scale)
+                except StopIteration as done:
+                    stats = done.value
+                    names = list(stats.keys())
+                    out = torch.stack([stats[k].reshape(()).float() for k in names])
+            graph.replay()
+            for t in exchange:
+                allreduce_sum_(t)
+            segments.append((graph, list(exchange)))
+        return segments, names, out
 
     def update_parameters(self, memory, updates):
         if self._flat is None:
