@@ -101,6 +101,16 @@ __device__ __forceinline__ unsigned allreduce_umax32(unsigned v) {
     return umax_(r[0], r[1]);
 }
 
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned allreduce_umin32(unsigned v) {
+    v = umin_(v, dpp_u<0xB1>(v));
+    v = umin_(v, dpp_u<0x4E>(v));
+    v = umin_(v, dpp_u<0x141>(v));
+    v = umin_(v, dpp_u<0x140>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return umin_(r[0], r[1]);
+}
+
 // Philox4x32-10 (Salmon et al. 2011); one call yields four 32-bit words.
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {

@@ -119,13 +119,25 @@ __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __
     constexpr int MB = C / 32;
     bool nan_pt;
     const float rstd = ln_center_rstd<C>(a, eps, &nan_pt);
+    // gamma/beta of the 16 channels of a row block are fetched with 8 back-to-back 16-byte LDS reads
+    // (one wait per block, the next block's reads already in flight) instead of a read + wait per pair.
+    const f32x4* s_gb = reinterpret_cast<const f32x4*>(s_ln);     // [channel pair] = {g0, b0, g1, b1}
+    f32x4 gb[2][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gb[0][q] = s_gb[(acc_chan(2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
+        if (mb + 1 < MB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                gb[(mb + 1) & 1][q] = s_gb[(acc_chan((mb + 1) * 16 + 2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-            const float2 gb = reinterpret_cast<const float2*>(s_ln)[ch];
-            const float y = __builtin_fmaf(a[mb][r] * rstd, gb.x, gb.y);
+            // register r of the block: channel pair (r & 3) / 2 of quad r >> 2 -> gb slot q = (r >> 2) * 2 + ((r & 3) >> 1)
+            const f32x4 g4 = gb[mb & 1][(r >> 2) * 2 + ((r & 3) >> 1)];
+            const float gam = (r & 1) ? g4[2] : g4[0], bet = (r & 1) ? g4[3] : g4[1];
+            const float y = __builtin_fmaf(a[mb][r] * rstd, gam, bet);
             if (INT_RELU) {
                 const int yi = __builtin_bit_cast(int, y);
                 a[mb][r] = __builtin_bit_cast(float, yi > 0 ? yi : 0);

@@ -127,13 +127,30 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             const unsigned inv_idx = ~(unsigned)pidx;
 #pragma unroll
             for (int mb = 0; mb < MB3; ++mb) {
+                // 16 independent reductions advance together: each DPP step of one register fills the
+                // wait states of the others, and the 16 conditional key updates are issued back to back.
+                unsigned m[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[r] = f2u(a2[mb][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0xB1>(m[r]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x4E>(m[r]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x141>(m[r]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x140>(m[r]));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
+                    m[r] = umax_(sw[0], sw[1]);
+                }
+                // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.
+                // An all-zero channel ties everywhere: only the tile's first point needs to report.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned v = f2u(a2[mb][r]);
-                    const unsigned m = allreduce_umax32(v);
-                    // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.
-                    // An all-zero channel ties everywhere: only the tile's first point needs to report.
-                    if (valid && v == m && (m != 0u || l31 == 0)) {
+                    if (valid && v == m[r] && (m[r] != 0u || l31 == 0)) {
                         const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
                         atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
                     }
