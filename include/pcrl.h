@@ -184,6 +184,9 @@ typedef struct pcrl_gemm_desc {
     int64_t c_ones_batch_stride;
 } pcrl_gemm_desc;
 int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
+/* Up to 4 INDEPENDENT problems in one launch (no problem may read what another writes): dW and dx of
+ * one layer, or the online and target Q heads of one layer.  Same per-problem semantics as above. */
+int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
 
 /* Row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1] = nn.LayerNorm(out), pointnet.py:110).
  * The result is written to n_dst <= 4 destinations (dst[i] with leading dimension ld_dst[i]): the

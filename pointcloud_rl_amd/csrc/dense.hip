@@ -7,10 +7,22 @@
 //     forward        Y  = act(X W^T + b)        A = X [M,K]      B[k][n] = W[n][k]
 //     data gradient  dX = (dY W) (.) relu-mask  A = dY [M,N']    B[k][n] = W[k][n]
 //     weight grad    dW = dY^T X, db = dY^T 1   A[m][k] = dY[k][m]  B = X (+ a virtual ones column)
-// The batch is small (M = 256 rows) so a 32x32 output tile is owned by one 4-wave workgroup that
-// splits K four ways (every CU gets work at N = 1024) and reduces in LDS in a fixed order.
-// Operands are read straight from L2 in MFMA operand order: a k-contiguous operand as one 16-byte
-// load per lane per 4 k-steps, an m/n-contiguous one as coalesced 4-byte loads.
+// and up to four independent problems (dW and dX of one layer, the online and the target Q heads)
+// share one launch, so that small ones overlap instead of paying a dispatch each.
+//
+// The batch is small (M = 256 rows): a 32x32 output tile is owned by one 8-wave workgroup that splits
+// K eight ways and reduces through LDS in a fixed order.  With only 64 MFMAs per wave at K = 1024 the
+// kernel lives or dies by its scalar overhead (measured: an earlier, more general version spent more
+// wave-cycles on addressing and guards than on MFMAs), hence:
+//   * operands are addressed as SGPR buffer resource + one 32-bit lane offset + scalar offset, rows
+//     clamped into range instead of guarded (out-of-range tile rows compute garbage that is never stored);
+//   * a k-contiguous operand is four 16-byte loads per lane per 32 k-steps (lane (i,h) holds
+//     k = k0 + 16h + 4t + j of row i -- any k order works as long as A and B agree), an m/n-contiguous
+//     one is sixteen coalesced 4-byte loads; two 32-k chunks are in flight per wave;
+//   * only the ragged K tail (K % 32) takes a guarded path, where out-of-range k reads as zero through
+//     the buffer bounds check;
+//   * the epilogue issues its bias / mask loads before the split-K barrier and stores through the
+//     buffer path with out-of-range rows / columns dropped by the bounds check.
 #include "common.h"
 
 namespace pcrl {
@@ -19,96 +31,176 @@ struct GemmParams {
     const float* A; const float* B; float* C;
     const float* bias;       // [N] added to every row (may be NULL)
     const float* mask;       // [M][ld_mask]: C = acc * (mask > 0) (ReLU backward; may be NULL)
+    float* C_ones;           // optional separate destination of column `ones_col`
+    long long a_bs, b_bs, c_bs, bias_bs, mask_bs, c_ones_bs;    // batch strides (elements)
+    unsigned a_sm4, a_sk4, b_sn4, b_sk4, ldc4, ld_mask4;        // strides in bytes
     int M, N, K;
-    long long a_sm, a_sk, b_sk, b_sn, ldc, ld_mask;
-    long long a_bs, b_bs, c_bs, bias_bs, mask_bs;    // batch strides (elements)
     int relu;                // C = max(acc + bias, 0)
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
-    float* C_ones;           // optional separate destination of column `ones_col`
-    long long c_ones_bs;
+    int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
+    int wg_n, wg_nm;         // n tiles, n tiles * m tiles
+    float inv_wg_n, inv_wg_nm;
+    int wg_begin;            // first workgroup of this problem inside the launch
 };
 
 constexpr int kGemmWaves = 8;
+constexpr int kGemmGroup = 4;
+constexpr unsigned kGemmOob = 0x80000000u;          // beyond every resource's num_records: loads give 0, stores are dropped
+constexpr unsigned kGemmRecords = 0x7FFFFFFFu;
+// wg_begin[] first: one scalar load finds the problem, a second clause fetches its whole descriptor
+struct GemmGroup { int wg_begin[kGemmGroup]; int n; int _pad[3]; GemmParams p[kGemmGroup]; };
 
-template <bool A_K4, bool B_K4>
-__device__ __forceinline__ void gemm_load_chunk(const GemmParams& p, const float* a_row, const float* b_col, int k,
-                                                bool m_ok, bool n_ok, bool n_ones, f32x4& a, f32x4& b) {
-    a = f32x4{0.f, 0.f, 0.f, 0.f};
-    b = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (A_K4 && k + 3 < p.K) {
-        if (m_ok) a = *reinterpret_cast<const f32x4*>(a_row + k);
-    } else if (m_ok) {
+// 32 k-steps of one operand for lane (i,h): v[t][j] = X[row i][32 sc + 16 h + 4 t + j].  `off` is the lane's byte
+// offset of (row i, k = 16 h).
+__device__ __forceinline__ void gemm_load_full(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned sk4, bool k4, int sc, f32x4 (&v)[4]) {
+    if (k4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k + j < p.K) a[j] = a_row[(long long)(k + j) * p.a_sk];
-    }
-    if (n_ones) {
+        for (int t = 0; t < 4; ++t) v[t] = buf_load_f4(rs, off + 16 * t, sc * 128);
+    } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = k + j < p.K ? 1.0f : 0.0f;
-    } else if (B_K4 && k + 3 < p.K) {
-        if (n_ok) b = *reinterpret_cast<const f32x4*>(b_col + k);
-    } else if (n_ok) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k + j < p.K) b[j] = b_col[(long long)(k + j) * p.b_sk];
+            for (int j = 0; j < 4; ++j) v[t][j] = buf_load_f1(rs, off, (unsigned)(32 * sc + 4 * t + j) * sk4);
     }
 }
+// The ragged last chunk: k >= K reads as zero (offset forced out of the resource's range).
+__device__ __forceinline__ void gemm_load_tail(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned sk4, int kbase, int K, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kbase + 4 * t + j;
+            v[t][j] = buf_load_f1(rs, k < K ? off + (unsigned)(k - (kbase & 16)) * sk4 : kGemmOob, 0);
+        }
+}
 
-template <bool A_K4, bool B_K4>
-__global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmParams p) {
+// A wave-uniform pointer as the compiler can prove it (keeps buffer resources in SGPRs).
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* ptr) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void gemm_mfma16(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[t][j], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmGroup g) {
     __shared__ __attribute__((aligned(16))) float s_red[kGemmWaves][16][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, bz = blockIdx.z;
-    const float* A = p.A + bz * p.a_bs;
-    const float* B = p.B + bz * p.b_bs;
-    const int m = m0 + i, n = n0 + i;
-    const bool m_ok = m < p.M, n_ok = n < p.N, n_ones = n == p.ones_col;
-    const int n_chunks = (p.K + 7) / 8;
-    const int per_wave = (n_chunks + kGemmWaves - 1) / kGemmWaves;
-    const int q_begin = wave * per_wave, q_end = min(q_begin + per_wave, n_chunks);
-    const float* a_row = A + (long long)m * p.a_sm;
-    const float* b_col = B + (long long)n * p.b_sn;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wg = blockIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int j = 1; j < kGemmGroup; ++j)
+        if (j < g.n && wg >= g.wg_begin[j]) gi = j;
+    const GemmParams p = g.p[gi];
+    // every field is needed within the next microsecond: one clause of scalar loads instead of dependent waits
+    asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.C), "s"(p.bias), "s"(p.mask), "s"(p.C_ones), "s"(p.a_bs), "s"(p.b_bs), "s"(p.c_bs),
+                 "s"(p.bias_bs), "s"(p.mask_bs), "s"(p.c_ones_bs));
+    asm volatile("" ::"s"(p.a_sm4), "s"(p.a_sk4), "s"(p.b_sn4), "s"(p.b_sk4), "s"(p.ldc4), "s"(p.ld_mask4), "s"(p.M), "s"(p.N), "s"(p.K),
+                 "s"(p.relu), "s"(p.ones_col), "s"(p.accumulate), "s"(p.a_k4), "s"(p.b_k4), "s"(p.wg_n), "s"(p.wg_nm), "s"(p.inv_wg_n),
+                 "s"(p.inv_wg_nm), "s"(p.wg_begin));
+    // tile decode without integer division (exact for < 2^20 workgroups; checked on the host)
+    const int local = wg - p.wg_begin;
+    const int bz = __builtin_amdgcn_readfirstlane((int)(((float)local + 0.5f) * p.inv_wg_nm));
+    const int rem = local - bz * p.wg_nm;
+    const int my = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * p.inv_wg_n));
+    const int nx = rem - my * p.wg_n;
+    const int m0 = my * 32, n0 = nx * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(uniform_ptr(p.A + bz * p.a_bs), kGemmRecords);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(uniform_ptr(p.B + bz * p.b_bs), kGemmRecords);
+    const int n = n0 + i;
+    int n_read = min(n, p.N - 1);
+    if (n_read == p.ones_col) n_read = 0;                       // that column is never read from memory
+    const unsigned a_off = (unsigned)min(m0 + i, p.M - 1) * p.a_sm4 + 16u * h * p.a_sk4;
+    const unsigned b_off = (unsigned)n_read * p.b_sn4 + 16u * h * p.b_sk4;
+    const bool a4 = p.a_k4 != 0, b4 = p.b_k4 != 0, ones = p.ones_col >= 0, n_ones = n == p.ones_col;
+    const int n_sc = (p.K + 31) >> 5, per = (n_sc + kGemmWaves - 1) / kGemmWaves;
+    const int sc_begin = wave * per, sc_end = min(sc_begin + per, n_sc), full_end = min(sc_end, p.K >> 5);
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // two chunks (8 MFMAs) in flight per iteration, next pair's loads issued before this pair's MFMAs
-    f32x4 a0, b0, a1, b1;
-    int q = q_begin;
-    if (q < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * q + 4 * h, m_ok, n_ok, n_ones, a0, b0);
-    if (q + 1 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 1) + 4 * h, m_ok, n_ok, n_ones, a1, b1);
-    for (; q < q_end; q += 2) {
-        const f32x4 ca0 = a0, cb0 = b0, ca1 = a1, cb1 = b1;
-        const bool second = q + 1 < q_end;
-        if (q + 2 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 2) + 4 * h, m_ok, n_ok, n_ones, a0, b0);
-        if (q + 3 < q_end) gemm_load_chunk<A_K4, B_K4>(p, a_row, b_col, 8 * (q + 3) + 4 * h, m_ok, n_ok, n_ones, a1, b1);
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    auto load = [&](int sc, f32x4 (&a)[4], f32x4 (&b)[4]) {
+        gemm_load_full(rs_a, a_off, p.a_sk4, a4, sc, a);
+        gemm_load_full(rs_b, b_off, p.b_sk4, b4, sc, b);
+        if (ones) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca0[j], cb0[j], acc, 0, 0, 0);
-        if (second) {
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca1[j], cb1[j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) b[t][j] = n_ones ? 1.0f : b[t][j];
         }
+    };
+    int sc = sc_begin;
+    if (sc < full_end) load(sc, a0, b0);
+    if (sc + 1 < full_end) load(sc + 1, a1, b1);
+    while (sc < full_end) {             // two 32-k chunks in flight
+        gemm_mfma16(a0, b0, acc);
+        if (sc + 2 < full_end) load(sc + 2, a0, b0);
+        if (++sc >= full_end) break;
+        gemm_mfma16(a1, b1, acc);
+        if (sc + 2 < full_end) load(sc + 2, a1, b1);
+        ++sc;
+    }
+    if (sc < sc_end) {                  // the ragged last chunk (K % 32 != 0), owned by one k-slice
+        const int kbase = 32 * sc + 16 * h;
+        gemm_load_tail(rs_a, a_off, p.a_sk4, kbase, p.K, a0);
+        gemm_load_tail(rs_b, b_off, p.b_sk4, kbase, p.K, b0);
+        if (ones) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[t][j] = n_ones ? (kbase + 4 * t + j < p.K ? 1.0f : 0.0f) : b0[t][j];
+        }
+        gemm_mfma16(a0, b0, acc);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
+
+    // Epilogue: thread (wave, lane) owns column n0 + (lane & 31) of accumulator rows r = wave and wave + 8.
+    const int col = n0 + (lane & 31);
+    const bool col_ok = col < p.N;
+    float bv = 0.0f, mv[2] = {1.0f, 1.0f}, old[2] = {0.0f, 0.0f};
+    unsigned c_off[2];
+    int row[2];
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(uniform_ptr(p.C + bz * p.c_bs), kGemmRecords);
+    if (p.bias) bv = (p.bias + bz * p.bias_bs)[min(col, p.N - 1)];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = wave + 8 * e;
+        row[e] = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        c_off[e] = (row[e] < p.M && col_ok) ? (unsigned)row[e] * p.ldc4 + 4u * col : kGemmOob;
+    }
+    if (p.mask) {
+        const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(uniform_ptr(p.mask + bz * p.mask_bs), kGemmRecords);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            mv[e] = buf_load_f1(rs_m, c_off[e] == kGemmOob ? kGemmOob : (unsigned)row[e] * p.ld_mask4 + 4u * col, 0);
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) old[e] = buf_load_f1(rs_c, c_off[e], 0);
+    }
     __syncthreads();
-    float* C = p.C + bz * p.c_bs;
-    const float* bias = p.bias ? p.bias + bz * p.bias_bs : nullptr;
-    const float* mask = p.mask ? p.mask + bz * p.mask_bs : nullptr;
 #pragma unroll
-    for (int e = 0; e < 1024 / (64 * kGemmWaves); ++e) {
-        const int idx = tid + 64 * kGemmWaves * e, r = idx >> 6, ln = idx & 63;
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), col = n0 + (ln & 31);
-        if (row < p.M && col < p.N) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < kGemmWaves; w += 2) v = v + (s_red[w][r][ln] + s_red[w + 1][r][ln]);
-            if (bias) v = v + bias[col];
-            if (p.relu) v = v > 0.0f ? v : 0.0f;
-            if (mask) v = mask[(long long)row * p.ld_mask + col] > 0.0f ? v : 0.0f;
-            float* dst = (p.C_ones && col == p.ones_col) ? p.C_ones + bz * p.c_ones_bs + row : C + (long long)row * p.ldc + col;
-            *dst = p.accumulate ? *dst + v : v;
+    for (int e = 0; e < 2; ++e) {
+        const int r = wave + 8 * e;
+        float v = ((s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane])) +
+                  ((s_red[4][r][lane] + s_red[5][r][lane]) + (s_red[6][r][lane] + s_red[7][r][lane]));
+        v = v + bv;
+        if (p.relu) v = v > 0.0f ? v : 0.0f;
+        v = mv[e] > 0.0f ? v : 0.0f;
+        v = old[e] + v;
+        if (p.C_ones && col == p.ones_col) {
+            if (c_off[e] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row[e]] = v;
+        } else {
+            buf_store_f1(rs_c, c_off[e], 0, v);
         }
     }
 }
@@ -213,32 +305,61 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
 
 using namespace pcrl;
 
-extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
-    if (!d || !d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
+static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total) {
+    if (!d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 1) return fail(PCRL_E_ARG, "bad GEMM shape");
-    if (d->M == 0 || d->N == 0) return PCRL_OK;
-    GemmParams p{};
-    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask;
-    p.M = d->M; p.N = d->N; p.K = d->K;
-    p.a_sm = d->a_stride_m; p.a_sk = d->a_stride_k; p.b_sk = d->b_stride_k; p.b_sn = d->b_stride_n;
-    p.ldc = d->ldc; p.ld_mask = d->ld_mask;
+    p = GemmParams{};
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.C_ones = d->C_ones;
     p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
-    p.bias_bs = d->bias_batch_stride; p.mask_bs = d->mask_batch_stride;
+    p.bias_bs = d->bias_batch_stride; p.mask_bs = d->mask_batch_stride; p.c_ones_bs = d->c_ones_batch_stride;
+    p.M = d->M; p.N = d->N; p.K = d->K;
     p.relu = d->relu; p.ones_col = d->ones_col; p.accumulate = d->accumulate;
-    p.C_ones = d->C_ones; p.c_ones_bs = d->c_ones_batch_stride;
+    // 32-bit byte offsets inside one batch element (buffer addressing)
+    const int64_t lim = 0x7FFFFFFF / 4;
+    auto span = [](int64_t rows, int64_t rs, int64_t cols, int64_t cs) {
+        return (rows > 0 ? (rows - 1) * rs : 0) + (cols > 0 ? (cols - 1) * cs : 0);
+    };
+    if (d->a_stride_m < 0 || d->a_stride_k < 0 || d->b_stride_k < 0 || d->b_stride_n < 0 || d->ldc < 0 || d->ld_mask < 0 ||
+        span(d->M, d->a_stride_m, d->K, d->a_stride_k) >= lim || span(d->N, d->b_stride_n, d->K, d->b_stride_k) >= lim ||
+        span(d->M, d->ldc, d->N, 1) >= lim || span(d->M, d->ld_mask, d->N, 1) >= lim)
+        return fail(PCRL_E_ARG, "GEMM operand strides must be non-negative and span < 2 GiB per batch element");
+    p.a_sm4 = 4u * (unsigned)d->a_stride_m; p.a_sk4 = 4u * (unsigned)d->a_stride_k;
+    p.b_sn4 = 4u * (unsigned)d->b_stride_n; p.b_sk4 = 4u * (unsigned)d->b_stride_k;
+    p.ldc4 = 4u * (unsigned)d->ldc; p.ld_mask4 = 4u * (unsigned)d->ld_mask;
     auto aligned = [](const float* ptr, long long sm, long long bs) {
         return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && sm % 4 == 0 && bs % 4 == 0;
     };
-    const bool a4 = p.a_sk == 1 && aligned(p.A, p.a_sm, p.a_bs);
-    const bool b4 = p.b_sk == 1 && aligned(p.B, p.b_sn, p.b_bs);
-    const dim3 grid((p.N + 31) / 32, (p.M + 31) / 32, d->batch);
-    hipStream_t st = (hipStream_t)stream;
-    if (a4 && b4) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(64 * kGemmWaves), 0, st, p);
-    else if (a4) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(64 * kGemmWaves), 0, st, p);
-    else if (b4) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(64 * kGemmWaves), 0, st, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(64 * kGemmWaves), 0, st, p);
+    p.a_k4 = d->a_stride_k == 1 && aligned(p.A, d->a_stride_m, p.a_bs);
+    p.b_k4 = d->b_stride_k == 1 && aligned(p.B, d->b_stride_n, p.b_bs);
+    p.wg_n = (p.N + 31) / 32;
+    p.wg_nm = p.wg_n * ((p.M + 31) / 32);
+    p.inv_wg_n = 1.0f / (float)(p.wg_n > 0 ? p.wg_n : 1);
+    p.inv_wg_nm = 1.0f / (float)(p.wg_nm > 0 ? p.wg_nm : 1);
+    p.wg_begin = wg_total;
+    wg_total += p.wg_nm * d->batch;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream) {
+    if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
+    GemmGroup g{};
+    int wg_total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = gemm_fill(&descs[i], g.p[g.n], wg_total);
+        if (rc != PCRL_OK) return rc;
+        g.wg_begin[g.n] = g.p[g.n].wg_begin;
+        if (descs[i].M > 0 && descs[i].N > 0) ++g.n;        // empty problems contribute no workgroups
+    }
+    if (g.n == 0 || wg_total == 0) return PCRL_OK;
+    if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), 0, (hipStream_t)stream, g);
     PCRL_CHECK_LAUNCH("gemm_f32_kernel");
     return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
+    if (!d) return fail(PCRL_E_ARG, "NULL argument");
+    return pcrl_gemm_group_f32(d, 1, stream);
 }
 
 extern "C" int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,

@@ -4,6 +4,7 @@ PyTorch is used for device memory and the current HIP stream only; every computa
 call into libpcrl_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -232,18 +233,35 @@ def _f(x):
     return ctypes.c_float(float(x))
 
 
-def gemm(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,
-         batch=1, batch_strides=(0, 0, 0, 0, 0), c_ones=None, c_ones_batch_stride=0):
-    """C[z] = epilogue(A[z] . B[z]); strides in elements; batch_strides = (A, B, C, bias, mask).  See include/pcrl.h."""
-    d = GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=C.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
-                 mask=mask.data_ptr() if mask is not None else None, M=M, N=N, K=K, batch=batch,
-                 a_stride_m=a_strides[0], a_stride_k=a_strides[1], b_stride_k=b_strides[0], b_stride_n=b_strides[1], ldc=ldc, ld_mask=ld_mask,
-                 a_batch_stride=batch_strides[0], b_batch_stride=batch_strides[1], c_batch_stride=batch_strides[2],
-                 bias_batch_stride=batch_strides[3], mask_batch_stride=batch_strides[4],
-                 relu=int(relu), ones_col=ones_col, accumulate=int(accumulate),
-                 C_ones=c_ones.data_ptr() if c_ones is not None else None, c_ones_batch_stride=c_ones_batch_stride)
-    with _span("gemm"):
-        check(lib().pcrl_gemm_f32(ctypes.byref(d), _stream()))
+_SPAN_SHAPES = bool(os.environ.get("PCRL_SPAN_SHAPES"))
+
+
+def gemm_desc(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,
+              batch=1, batch_strides=(0, 0, 0, 0, 0), c_ones=None, c_ones_batch_stride=0):
+    """Descriptor of C[z] = epilogue(A[z] . B[z]); strides in elements; batch_strides = (A, B, C, bias, mask).  See include/pcrl.h."""
+    return GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=C.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                    mask=mask.data_ptr() if mask is not None else None, M=M, N=N, K=K, batch=batch,
+                    a_stride_m=a_strides[0], a_stride_k=a_strides[1], b_stride_k=b_strides[0], b_stride_n=b_strides[1], ldc=ldc, ld_mask=ld_mask,
+                    a_batch_stride=batch_strides[0], b_batch_stride=batch_strides[1], c_batch_stride=batch_strides[2],
+                    bias_batch_stride=batch_strides[3], mask_batch_stride=batch_strides[4],
+                    relu=int(relu), ones_col=ones_col, accumulate=int(accumulate),
+                    C_ones=c_ones.data_ptr() if c_ones is not None else None, c_ones_batch_stride=c_ones_batch_stride)
+
+
+def gemm_group(descs):
+    """Launch up to 4 independent GEMMs (gemm_desc results; None entries are skipped) as one kernel."""
+    descs = [d for d in descs if d is not None]
+    if not descs:
+        return
+    arr = (GemmDesc * len(descs))(*descs)
+    name = "gemm " + " | ".join(f"M{d.M} N{d.N} K{d.K} b{d.batch}" for d in descs) if _SPAN_SHAPES else "gemm"
+    with _span(name):
+        check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
+
+
+def gemm(*args, **kwargs):
+    """One GEMM launch; arguments as gemm_desc."""
+    gemm_group([gemm_desc(*args, **kwargs)])
 
 
 def layernorm_rows_fwd(x, ldx, gamma, beta, M, F, eps, dsts, xhat=None, rstd=None):

@@ -41,41 +41,62 @@ class MlpView:
         return (buf if buf is not None else self.flat.data)[base + self.b[i]:]
 
 
-def mlp_forward(mv, params, base, X, ldx, M, outs, ld_out2, out2, out2_bs, x_bs=0):
-    """h1 = relu(X W0^T + b0), h2 = relu(h1 W1^T + b1), out = h2 W2^T + b2, batched over mv.nb heads.
-    outs = (h1, h2) buffers [nb][M][H]; out2 written with leading dim ld_out2 and batch stride out2_bs."""
+def mlp_forward_descs(mv, params, base, X, ldx, M, outs, ld_out2, out2, out2_bs, x_bs=0):
+    """GEMM descriptors, one per layer, of h1 = relu(X W0^T + b0), h2 = relu(h1 W1^T + b1), out = h2 W2^T + b2,
+    batched over mv.nb heads.  outs = (h1, h2) buffers [nb][M][H]; out2 written with leading dim ld_out2 and batch
+    stride out2_bs."""
     (k0, h), (_, _), (_, n2) = mv.dims
     nb, hs = mv.nb, mv.hs
     h1, h2 = outs
-    hip.gemm(X, mv.W(0, params, base), h1, M, h, k0, (ldx, 1), (1, k0), h, bias=mv.Bv(0, params, base), relu=True,
-             batch=nb, batch_strides=(x_bs, hs, M * h, hs, 0))
-    hip.gemm(h1, mv.W(1, params, base), h2, M, h, h, (h, 1), (1, h), h, bias=mv.Bv(1, params, base), relu=True,
-             batch=nb, batch_strides=(M * h, hs, M * h, hs, 0))
-    hip.gemm(h2, mv.W(2, params, base), out2, M, n2, h, (h, 1), (1, h), ld_out2, bias=mv.Bv(2, params, base),
-             batch=nb, batch_strides=(M * h, hs, out2_bs, hs, 0))
+    return [hip.gemm_desc(X, mv.W(0, params, base), h1, M, h, k0, (ldx, 1), (1, k0), h, bias=mv.Bv(0, params, base), relu=True,
+                          batch=nb, batch_strides=(x_bs, hs, M * h, hs, 0)),
+            hip.gemm_desc(h1, mv.W(1, params, base), h2, M, h, h, (h, 1), (1, h), h, bias=mv.Bv(1, params, base), relu=True,
+                          batch=nb, batch_strides=(M * h, hs, M * h, hs, 0)),
+            hip.gemm_desc(h2, mv.W(2, params, base), out2, M, n2, h, (h, 1), (1, h), ld_out2, bias=mv.Bv(2, params, base),
+                          batch=nb, batch_strides=(M * h, hs, out2_bs, hs, 0))]
 
 
-def mlp_backward(mv, X, ldx, M, h1, h2, dout, dout_strides, dout_bs, dh1, dh2, grad=None, dX=None, dx_cols=None, ld_dx=0, x_bs=0):
-    """Backward of mlp_forward.  dout[z][m][n] at dout + z*dout_bs + m*dout_strides[0] + n*dout_strides[1].
+def launch_layers(*mlps):
+    """Layer l of every given MLP (independent of each other) goes into one grouped launch."""
+    for layer in zip(*mlps):
+        hip.gemm_group([d for group in layer for d in (group if isinstance(group, (list, tuple)) else [group])])
+
+
+def mlp_forward(*args, **kwargs):
+    launch_layers(mlp_forward_descs(*args, **kwargs))
+
+
+def mlp_backward_descs(mv, X, ldx, M, h1, h2, dout, dout_strides, dout_bs, dh1, dh2, grad=None, dX=None, dx_cols=None, ld_dx=0, x_bs=0):
+    """Backward of mlp_forward as three stages of independent GEMMs [(dW2|db2, dh2), (dW1|db1, dh1), (dW0|db0, dX)].
+    dout[z][m][n] at dout + z*dout_bs + m*dout_strides[0] + n*dout_strides[1].
     grad: flat gradient buffer receiving dW|db of every layer (None: data gradients only).
     dX: receives dh1 @ W0[:, c0:c0+nc] for dx_cols = (c0, nc), shape [nb][M][ld_dx]."""
     (k0, h), (_, _), (_, n2) = mv.dims
     nb, hs = mv.nb, mv.hs
     sm, sn = dout_strides
+    stages = [[], [], []]
     if grad is not None:
-        hip.gemm(dout, h2, grad[mv.w[2]:], n2, h + 1, M, (sn, sm), (h, 1), h, ones_col=h, c_ones=grad[mv.b[2]:], c_ones_batch_stride=hs,
-                 batch=nb, batch_strides=(dout_bs, M * h, hs, 0, 0))
-    hip.gemm(dout, mv.W(2), dh2, M, h, n2, (sm, sn), (h, 1), h, mask=h2, ld_mask=h, batch=nb, batch_strides=(dout_bs, hs, M * h, 0, M * h))
+        stages[0].append(hip.gemm_desc(dout, h2, grad[mv.w[2]:], n2, h + 1, M, (sn, sm), (h, 1), h, ones_col=h, c_ones=grad[mv.b[2]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(dout_bs, M * h, hs, 0, 0)))
+    stages[0].append(hip.gemm_desc(dout, mv.W(2), dh2, M, h, n2, (sm, sn), (h, 1), h, mask=h2, ld_mask=h, batch=nb,
+                                   batch_strides=(dout_bs, hs, M * h, 0, M * h)))
     if grad is not None:
-        hip.gemm(dh2, h1, grad[mv.w[1]:], h, h + 1, M, (1, h), (h, 1), h, ones_col=h, c_ones=grad[mv.b[1]:], c_ones_batch_stride=hs,
-                 batch=nb, batch_strides=(M * h, M * h, hs, 0, 0))
-    hip.gemm(dh2, mv.W(1), dh1, M, h, h, (h, 1), (h, 1), h, mask=h1, ld_mask=h, batch=nb, batch_strides=(M * h, hs, M * h, 0, M * h))
+        stages[1].append(hip.gemm_desc(dh2, h1, grad[mv.w[1]:], h, h + 1, M, (1, h), (h, 1), h, ones_col=h, c_ones=grad[mv.b[1]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(M * h, M * h, hs, 0, 0)))
+    stages[1].append(hip.gemm_desc(dh2, mv.W(1), dh1, M, h, h, (h, 1), (h, 1), h, mask=h1, ld_mask=h, batch=nb,
+                                   batch_strides=(M * h, hs, M * h, 0, M * h)))
     if grad is not None:
-        hip.gemm(dh1, X, grad[mv.w[0]:], h, k0 + 1, M, (1, h), (ldx, 1), k0, ones_col=k0, c_ones=grad[mv.b[0]:], c_ones_batch_stride=hs,
-                 batch=nb, batch_strides=(M * h, x_bs, hs, 0, 0))
+        stages[2].append(hip.gemm_desc(dh1, X, grad[mv.w[0]:], h, k0 + 1, M, (1, h), (ldx, 1), k0, ones_col=k0, c_ones=grad[mv.b[0]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(M * h, x_bs, hs, 0, 0)))
     if dX is not None:
         c0, nc = dx_cols
-        hip.gemm(dh1, mv.W(0)[c0:], dX, M, nc, h, (h, 1), (k0, 1), ld_dx, batch=nb, batch_strides=(M * h, hs, M * ld_dx, 0, 0))
+        stages[2].append(hip.gemm_desc(dh1, mv.W(0)[c0:], dX, M, nc, h, (h, 1), (k0, 1), ld_dx, batch=nb,
+                                       batch_strides=(M * h, hs, M * ld_dx, 0, 0)))
+    return stages
+
+
+def mlp_backward(*args, **kwargs):
+    launch_layers(mlp_backward_descs(*args, **kwargs))
 
 
 class FusedStep:
@@ -133,17 +154,22 @@ class FusedStep:
         return self.bufs[key]
 
     # -- pieces -------------------------------------------------------------------------------------
-    def _features(self, pooled, M, tag, dsts, save=False):
-        """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153), scattered into `dsts`."""
+    def _features(self, jobs):
+        """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
+        jobs = [(pooled, M, tag, dsts, save)]; the Linear GEMMs share one launch.  Returns [(xhat, rstd)]."""
         fc, off, F, c3 = self.a._flat["critic"], self.off, self.F, self.c3
         pre = "values.0.backbone.visual_nn.final_mlp."
-        y = self._buf(f"feat_pre_{tag}", M, F)
-        hip.gemm(pooled, fc.data[off[pre + "0.weight"]:], y, M, F, c3, (c3, 1), (1, c3), F, bias=fc.data[off[pre + "0.bias"]:])
-        xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
-        rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
-        hip.layernorm_rows_fwd(y, F, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], M, F,
-                               self.a.encoder.final_mlp[1].eps, dsts, xhat, rstd)
-        return xhat, rstd
+        ys = [self._buf(f"feat_pre_{tag}", M, F) for _, M, tag, _, _ in jobs]
+        hip.gemm_group([hip.gemm_desc(pooled, fc.data[off[pre + "0.weight"]:], y, M, F, c3, (c3, 1), (1, c3), F, bias=fc.data[off[pre + "0.bias"]:])
+                        for (pooled, M, _, _, _), y in zip(jobs, ys)])
+        out = []
+        for (_, M, tag, dsts, save), y in zip(jobs, ys):
+            xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
+            rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
+            hip.layernorm_rows_fwd(y, F, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], M, F,
+                                   self.a.encoder.final_mlp[1].eps, dsts, xhat, rstd)
+            out.append((xhat, rstd))
+        return out
 
     def _state_into(self, state, bufs_cols):
         if state is not None:
@@ -193,28 +219,29 @@ class FusedStep:
         M = actions.shape[0]
         stats = {}
 
-        # ---- target: y = r + (1-d) gamma (min_h Q'(s', a') + alpha * (-log pi(a'|s')))  (sac.py:110-134) ----
+        # ---- target y = r + (1-d) gamma (min_h Q'(s', a') + alpha * (-log pi(a'|s')))  (sac.py:110-134) and q = Q(s, a)
+        # (sac.py:136).  Both encoder passes first, then the head GEMMs of the two independent branches pairwise in
+        # one launch each (feature Linear of s' and s; target Q heads on s' and online Q heads on s).
         vis_n, state_n = split(next_obs)
         pooled_n, _, _ = enc.encode_raw(vis_n)
-        XA_n, XQ_n = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq)
-        self._features(pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)])
+        vis_o, state_o = split(obs)
+        pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
+        XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
+        (_, _), (xhat, rstd) = self._features([(pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False),
+                                                (pooled_o, M, "o", [(XQ_o, 0, ldq)], True)])
         self._state_into(state_n, [(XA_n, F), (XQ_n, F)])
+        self._state_into(state_o, [(XQ_o, F)])
+        XQ_o[:, F + S:F + S + A].copy_(actions)
         _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
         tgt = a._target_flat.data
-        mlp_forward(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1)
-
-        # ---- critic: q = Q(s, a), loss, backward through heads, feature head and encoder (sac.py:136-148) ----
-        vis_o, state_o = split(obs)
-        pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
-        XQ_o = self._buf("XQ_o", M, ldq)
-        xhat, rstd = self._features(pooled_o, M, "o", [(XQ_o, 0, ldq)], save=True)
-        self._state_into(state_o, [(XQ_o, F)])
-        XQ_o[:, F + S:F + S + A].copy_(actions)
         q_h1, q_h2 = self._buf("q_h1", 2, M, H), self._buf("q_h2", 2, M, H)
         q = self._buf("q", M, 2)
-        mlp_forward(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1)
+        launch_layers(mlp_forward_descs(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1),
+                      mlp_forward_descs(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1))
+
+        # ---- critic loss, backward through heads, feature head and encoder (sac.py:137-148) ----
         q_target, dq = self._buf("q_target", M), self._buf("dq", M, 2)
         dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
         hip.sac_critic_loss(q_next, 2, nlp_n, rewards, dones_u8, a.log_alpha, a.gamma,
@@ -229,10 +256,10 @@ class FusedStep:
         hip.layernorm_rows_bwd(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd, fc.data[off[pre + "1.weight"]:], M, F,
                                dy, F, fc.grad[off[pre + "1.weight"]:], fc.grad[off[pre + "1.bias"]:], ws)
         c3 = self.c3
-        hip.gemm(dy, pooled_o, fc.grad[off[pre + "0.weight"]:], F, c3 + 1, M, (1, F), (c3, 1), c3, ones_col=c3,
-                 c_ones=fc.grad[off[pre + "0.bias"]:])
         dpooled = self._buf("dpooled", M, c3)
-        hip.gemm(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)
+        hip.gemm_group([hip.gemm_desc(dy, pooled_o, fc.grad[off[pre + "0.weight"]:], F, c3 + 1, M, (1, F), (c3, 1), c3, ones_col=c3,
+                                      c_ones=fc.grad[off[pre + "0.bias"]:]),
+                        hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
         scale = yield [fc.grad]
         stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak)
@@ -246,7 +273,7 @@ class FusedStep:
             Ma = M if actor_obs is None else vis_a["xyz"].shape[0]
             pooled_a, _, _ = enc.encode_raw(vis_a)                    # updated encoder weights, no gradient
             XA_a, XQ_a = self._buf("XA_a", Ma, lda), self._buf("XQ_a", Ma, ldq)
-            self._features(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)])
+            self._features([(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False)])
             self._state_into(state_a, [(XA_a, F), (XQ_a, F)])
             feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)

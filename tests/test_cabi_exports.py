@@ -17,7 +17,7 @@ def declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     names = declared_symbols()
-    for required in ("pcrl_encoder_fwd_f32", "pcrl_encoder_bwd_f32", "pcrl_encoder_pack_weights_f32", "pcrl_gemm_f32",
+    for required in ("pcrl_encoder_fwd_f32", "pcrl_encoder_bwd_f32", "pcrl_encoder_pack_weights_f32", "pcrl_gemm_f32", "pcrl_gemm_group_f32",
                      "pcrl_tanh_gaussian_fwd_f32", "pcrl_tanh_gaussian_bwd_f32", "pcrl_sac_critic_loss_f32",
                      "pcrl_sac_actor_loss_f32", "pcrl_adam_step_f32", "pcrl_polyak_f32", "pcrl_last_error", "pcrl_version"):
         assert required in names

@@ -71,7 +71,15 @@ def _worker(rank, world, port, graphs, out):
 def _run(graphs):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, _free_port(), graphs, out), nprocs=2, join=True)
+    for attempt in range(2):
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), graphs, out), nprocs=2, join=True)
+            break
+        except Exception as e:      # the probed port can be taken between the probe and the rendezvous: retry that, nothing else
+            text = str(e).lower()
+            if attempt == 0 and any(k in text for k in ("address already in use", "connect", "rendezvous", "timed out")):
+                continue
+            raise
     return out[0], out[1]
 
 

@@ -147,3 +147,32 @@ def test_critic_and_actor_loss(cuda, group):
     np.testing.assert_allclose(dn.item(), nl.grad[0].item(), rtol=1e-6)
     np.testing.assert_allclose(ag.item(), la.grad.item(), rtol=1e-5)
     np.testing.assert_allclose(st.cpu().numpy(), [aloss.item(), ent.item(), alpha_loss.item()], rtol=2e-5, atol=1e-6)
+
+
+def test_gemm_group_matches_single_launches(cuda):
+    """dW|db, dx and two unrelated shapes in one launch give the same bits as separate launches."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(5)
+    M, K, N = 256, 1024, 1024
+    dy, x, w = g.randn(M, N).astype(np.float32), g.randn(M, K).astype(np.float32), (g.randn(N, K) / 32).astype(np.float32)
+    x2, w2 = g.randn(70, 50).astype(np.float32), g.randn(33, 50).astype(np.float32)
+    DY, X, W, X2, W2 = T(dy, cuda), T(x, cuda), T(w, cuda), T(x2, cuda), T(w2, cuda)
+
+    def descs(dwb, dx, y2, y3):
+        return [hip.gemm_desc(DY, X, dwb, N, K + 1, M, (1, N), (K, 1), K + 1, ones_col=K),
+                hip.gemm_desc(DY, W, dx, M, K, N, (N, 1), (K, 1), K),
+                hip.gemm_desc(X2, W2, y2, 70, 33, 50, (50, 1), (1, 50), 33, relu=True),
+                hip.gemm_desc(X, W, y3, M, N, K, (K, 1), (1, K), N)]
+    outs_a = [torch.zeros(N, K + 1, device=cuda), torch.zeros(M, K, device=cuda), torch.zeros(70, 33, device=cuda), torch.zeros(M, N, device=cuda)]
+    outs_b = [torch.zeros_like(o) for o in outs_a]
+    hip.gemm_group(descs(*outs_a))
+    for d in descs(*outs_b):
+        hip.gemm_group([d])
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(outs_a[0][:, :K].cpu().numpy(), dy.T @ x, atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[0][:, K].cpu().numpy(), dy.sum(0), atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[1].cpu().numpy(), dy @ w, atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[2].cpu().numpy(), np.maximum(x2 @ w2.T, 0), atol=2e-5, rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        hip.gemm_group(descs(*outs_a) + descs(*outs_a)[:1])          # more than 4 problems
