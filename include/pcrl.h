@@ -213,6 +213,16 @@ int pcrl_tanh_gaussian_fwd_f32(const float* feat, int64_t ld_feat, const float* 
                                int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
                                float* action, int64_t ld_action, float* action2, int64_t ld_action2,
                                float* neg_logp, float* saved, void* stream);
+/* Same forward with the standard-normal draws made in the kernel (Philox4x32-10 keyed by `seed`, counter =
+ * (element, draw_id, *step_counter), Box-Muller) and returned in eps_out [B, A] for the backward.  The reference
+ * draws from torch's global generator (distributions.py:122-127); any N(0,1) stream is a valid replacement.
+ * step_counter is a device int32 that the caller advances between steps (the critic optimizer's step count),
+ * so a captured launch draws fresh noise on every hipGraph replay. */
+int pcrl_tanh_gaussian_sample_fwd_f32(const float* feat, int64_t ld_feat, uint64_t seed, const int32_t* step_counter, int32_t draw_id,
+                                      float* eps_out, const float* scale, const float* bias,
+                                      int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                                      float* action, int64_t ld_action, float* action2, int64_t ld_action2,
+                                      float* neg_logp, float* saved, void* stream);
 int pcrl_tanh_gaussian_bwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* saved, const float* scale,
                                int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
                                const float* d_action0, const float* d_action1, int64_t ld_d_action, const float* d_neglogp,
@@ -232,6 +242,10 @@ int pcrl_sac_critic_loss_f32(const float* q_next, int64_t ld_q_next, const float
 int pcrl_sac_actor_loss_f32(const float* q_pi, int64_t ld_q, const float* neg_logp, const float* log_alpha, float target_entropy,
                             int32_t B, int32_t H, float* dq, int64_t ld_dq, float* d_neglogp, float* alpha_grad, float* stats,
                             void* stream);
+
+/* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
+ * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196). */
+int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,19 @@ struct TgFwdParams {
     float* act0; long long ld0; float* act1; long long ld1;   // action written to up to two places
     float* neg_logp;                        // [B]
     float* saved;                           // [B][2A]: tanh(u) | std   (backward)
+    // eps == NULL: draws come from Philox4x32-10 keyed by `seed`, counter (element, draw_id, *step) and are
+    // written to eps_out (the backward needs them)
+    float* eps_out; unsigned seed_lo, seed_hi; const int* step; int draw_id;
 };
+
+// One N(0,1) draw per (element, draw, step): Box-Muller on two Philox words.
+__device__ __forceinline__ float philox_normal(unsigned elem, unsigned draw, unsigned step, unsigned k0, unsigned k1) {
+    uint32_t w[4];
+    philox4x32_10(elem, draw, step, 0x5AC0FFEEu, k0, k1, w);
+    const float u1 = ((float)(w[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float u2 = (float)(w[1] >> 8) * (1.0f / 16777216.0f);               // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
 
 __global__ __launch_bounds__(256) void tanh_gaussian_fwd_kernel(const TgFwdParams p) {
     // one wave per sample; lanes stride over the action dims
@@ -32,7 +44,9 @@ __global__ __launch_bounds__(256) void tanh_gaussian_fwd_kernel(const TgFwdParam
         const float mean = p.feat[(long long)b * p.ld_feat + j];
         const float ls = p.feat[(long long)b * p.ld_feat + p.A + j];
         const float std = expf(fminf(fmaxf(ls, p.ls_min), p.ls_max));
-        const float e = p.eps[(long long)b * p.A + j];
+        const float e = p.eps ? p.eps[(long long)b * p.A + j]
+                              : philox_normal((unsigned)(b * p.A + j), (unsigned)p.draw_id, (unsigned)p.step[0], p.seed_lo, p.seed_hi);
+        if (p.eps_out) p.eps_out[(long long)b * p.A + j] = e;
         const float u = mean + e * std;
         const float t = tanhf(u);
         const float s = p.scale[j];
@@ -185,9 +199,36 @@ __global__ __launch_bounds__(1024) void actor_loss_kernel(const ActorLossParams 
     }
 }
 
+// The scalars a step reports (losses, gradient norms, alpha = exp(log_alpha)) gathered into one array
+// with one launch, instead of one tiny copy / exp / stack launch each.
+constexpr int kMaxScalars = 16;
+struct ScalarListParams { const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n; };
+__global__ void gather_scalars_kernel(const ScalarListParams p) {
+    const int i = threadIdx.x;
+    if (i < p.n) {
+        const float v = p.src[i][0];
+        p.dst[i][0] = ((p.exp_mask >> i) & 1u) ? expf(v) : v;
+    }
+}
+
 }  // namespace pcrl
 
 using namespace pcrl;
+
+extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n, void* stream) {
+    if (!src || !dst || n < 0 || n > kMaxScalars) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
+    if (n == 0) return PCRL_OK;
+    ScalarListParams p{};
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i]) return fail(PCRL_E_ARG, "NULL scalar pointer");
+        p.src[i] = src[i]; p.dst[i] = dst[i];
+        if (take_exp && take_exp[i]) p.exp_mask |= 1u << i;
+    }
+    p.n = n;
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("gather_scalars_kernel");
+    return PCRL_OK;
+}
 
 extern "C" int pcrl_tanh_gaussian_fwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* scale, const float* bias,
                                           int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
@@ -195,7 +236,22 @@ extern "C" int pcrl_tanh_gaussian_fwd_f32(const float* feat, int64_t ld_feat, co
                                           float* neg_logp, float* saved, void* stream) {
     if (!feat || !eps || !scale || !bias || !action || !neg_logp) return fail(PCRL_E_ARG, "NULL argument");
     if (B == 0) return PCRL_OK;
-    TgFwdParams p{feat, ld_feat, eps, scale, bias, B, A, log_std_min, log_std_max, epsilon, action, ld_action, action2, ld_action2, neg_logp, saved};
+    TgFwdParams p{feat, ld_feat, eps, scale, bias, B, A, log_std_min, log_std_max, epsilon, action, ld_action, action2, ld_action2, neg_logp, saved,
+                  nullptr, 0u, 0u, nullptr, 0};
+    hipLaunchKernelGGL(tanh_gaussian_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("tanh_gaussian_fwd_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_tanh_gaussian_sample_fwd_f32(const float* feat, int64_t ld_feat, uint64_t seed, const int32_t* step_counter, int32_t draw_id,
+                                                 float* eps_out, const float* scale, const float* bias,
+                                                 int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                                                 float* action, int64_t ld_action, float* action2, int64_t ld_action2,
+                                                 float* neg_logp, float* saved, void* stream) {
+    if (!feat || !step_counter || !eps_out || !scale || !bias || !action || !neg_logp) return fail(PCRL_E_ARG, "NULL argument");
+    if (B == 0) return PCRL_OK;
+    TgFwdParams p{feat, ld_feat, nullptr, scale, bias, B, A, log_std_min, log_std_max, epsilon, action, ld_action, action2, ld_action2, neg_logp, saved,
+                  eps_out, (unsigned)seed, (unsigned)(seed >> 32), step_counter, draw_id};
     hipLaunchKernelGGL(tanh_gaussian_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("tanh_gaussian_fwd_kernel");
     return PCRL_OK;

@@ -287,6 +287,16 @@ def tanh_gaussian_fwd(feat, ld_feat, eps, scale, bias, B, A, ls_min, ls_max, eps
                                            _ptr(neg_logp), _ptr(saved), _stream()))
 
 
+def tanh_gaussian_sample_fwd(feat, ld_feat, seed, step_counter, draw_id, eps_out, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action,
+                             neg_logp, saved=None, action2_ptr=None, ld_action2=0):
+    """tanh_gaussian_fwd with in-kernel Philox draws (written to eps_out); step_counter: device int32 tensor."""
+    check(lib().pcrl_tanh_gaussian_sample_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(step_counter),
+                                                  int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
+                                                  _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
+                                                  ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
+                                                  _ptr(neg_logp), _ptr(saved), _stream()))
+
+
 def tanh_gaussian_bwd(feat, ld_feat, eps, saved, scale, B, A, ls_min, ls_max, epsilon, da0_ptr, da1_ptr, ld_da, d_neglogp, d_feat, ld_d_feat):
     check(lib().pcrl_tanh_gaussian_bwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(saved), _ptr(scale), B, A, _f(ls_min), _f(ls_max),
                                            _f(epsilon), ctypes.c_void_p(da0_ptr), ctypes.c_void_p(da1_ptr) if da1_ptr else None,
@@ -303,6 +313,15 @@ def sac_critic_loss(q_next, ld_qn, neg_logp_next, rewards, dones_u8, log_alpha, 
 def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld_dq, d_neglogp, alpha_grad, stats):
     check(lib().pcrl_sac_actor_loss_f32(_ptr(q_pi), ctypes.c_int64(ld_q), _ptr(neg_logp), _ptr(log_alpha), _f(target_entropy), B, H,
                                         _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
+
+
+def gather_scalars(entries):
+    """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars."""
+    n = len(entries)
+    src = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
+    dst = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries])
+    flags = (ctypes.c_int32 * n)(*[int(bool(e[2])) for e in entries])
+    check(lib().pcrl_gather_scalars_f32(src, dst, flags, n, _stream()))
 
 
 # ---- stand-alone memory-shaped kernels --------------------------------------------------------------

@@ -17,6 +17,11 @@ from ..networks.heads import TanhGaussianHead
 from ..networks.pointnet import PointNet
 
 
+class PackedStats(dict):
+    """name -> device scalar (views into `packed`, one contiguous float32 tensor in the same order)."""
+    packed = None
+
+
 def ceil4(x):
     return (x + 3) & ~3
 
@@ -146,6 +151,9 @@ class FusedStep:
         self.stats_c = torch.zeros(4, device=dev)
         self.stats_a = torch.zeros(3, device=dev)
         self.d_nlp = torch.zeros(1, device=dev)
+        # policy noise stream: torch's seed (torch.manual_seed controls it), decorrelated across data-parallel ranks
+        from ..utils.dist import rank as _rank
+        self.seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (_rank() + 1)) & (2 ** 64 - 1)
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -183,12 +191,18 @@ class FusedStep:
         feat = self._buf(f"pi_out_{tag}", M, 2 * A)
         mlp_forward(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
         head = a.actor.head
-        eps = head._standard_normal(self._buf(f"pi_eps_like_{tag}", M, A))
+        eps = self._buf(f"pi_eps_{tag}", M, A)
         act = self._buf(f"pi_act_{tag}", M, A)
         nlp = self._buf(f"pi_nlp_{tag}", M)
         saved = self._buf(f"pi_saved_{tag}", M, 2 * A) if save else None
-        hip.tanh_gaussian_fwd(feat, 2 * A, eps, head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
-                              act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+        if head.noise_override:          # parity tests inject the draws
+            eps = head._standard_normal(eps)
+            hip.tanh_gaussian_fwd(feat, 2 * A, eps, head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                  act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+        else:                            # drawn in the kernel; the critic optimizer's device step count advances the stream
+            hip.tanh_gaussian_sample_fwd(feat, 2 * A, self.seed, a.critic_optim.step_counter, 0 if tag == "n" else 1, eps,
+                                         head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                         act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
         return feat, eps, saved, nlp, h1, h2
 
     # -- the step -------------------------------------------------------------------------------------
@@ -295,7 +309,14 @@ class FusedStep:
             scale = yield ([fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
             stats["actor_grad"] = a._optim_step("actor", scale)
             a._optim_step("alpha", scale if a.sync_alpha else 1.0)
-            a._alpha_t.copy_(a.log_alpha.detach().exp())
-            stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2],
-                         new_alpha=a._alpha_t.reshape(()).clone())
-        return stats
+            stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
+        # one launch gathers every reported scalar (and alpha = exp(log_alpha), sac.py:196) into one array
+        names = list(stats.keys())
+        out = self._buf("stats_out", 16)
+        entries = [(a.log_alpha, out[i:], True) if k == "new_alpha" else (stats[k], out[i:], False) for i, k in enumerate(names)]
+        if "new_alpha" in stats:
+            entries.append((a.log_alpha, a._alpha_t, True))
+        hip.gather_scalars(entries)
+        packed = PackedStats((k, out[i]) for i, k in enumerate(names))
+        packed.packed = out[:len(names)]
+        return packed

@@ -323,10 +323,15 @@ class SAC(BaseAgent):
             stats["alpha_loss"] = torch.zeros((), device=self.device)
         stats["new_alpha"] = self._alpha_t.reshape(()).clone()
 
-    def _finish(self, stats, updates):
+    def _finish(self, stats, updates, host_values=None):
         """One device->host copy for every metric the reference reads with .item() (sac.py:140-203)."""
         keys = list(stats.keys())
-        vals = torch.stack([stats[k].reshape(()).float() for k in keys]).tolist()
+        if host_values is not None:
+            vals = host_values
+        elif getattr(stats, "packed", None) is not None:
+            vals = stats.packed.tolist()
+        else:
+            vals = torch.stack([stats[k].reshape(()).float() for k in keys]).tolist()
         got = dict(zip(keys, vals))
         pre = self.metric_prefix
         ret = {f"{pre}/critic_loss": got["critic_loss"], f"{pre}/max_critic_abs_err": got["max_critic_abs_err"],
@@ -416,15 +421,24 @@ class SAC(BaseAgent):
             graph.replay()
             for t in exchange:
                 allreduce_sum_(t)
+        if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
+            torch.cuda.current_stream().synchronize()
+            return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
         return self._finish(dict(zip(names, out.unbind(0))), updates)
 
     def _capture_whole(self, batch, do_actor, polyak):
         graph = torch.cuda.CUDAGraph()
+        host = None
+        pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
         with torch.cuda.graph(graph):
             stats = self._step_body(batch, do_actor, polyak)
             names = list(stats.keys())
-            out = torch.stack([stats[k].reshape(()).float() for k in names])
-        return [(graph, [])], names, out
+            packed = getattr(stats, "packed", None)
+            out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
+            if packed is not None:          # the metrics land in pinned host memory as the graph's last node
+                host = pinned[:len(names)]
+                host.copy_(out, non_blocking=True)
+        return [(graph, [])], names, (host if host is not None else out)
 
     def _capture_segments(self, batch, do_actor, polyak):
         """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay

@@ -13,6 +13,10 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def allreduce_sum_(flat_grad, enabled=True):
     """In-place SUM all-reduce of a flat gradient buffer.  Returns the scale (1/world) the caller must
     apply to obtain the mean, 1.0 when nothing was exchanged."""
