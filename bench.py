@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-process path with several ranks on one GPU)")
+    ap.add_argument("--replay", default="device", choices=["device", "fixed"], help="device: sample every step from a device-resident "
+                    "ring of synthetic transitions; fixed: the same resident batch every step")
+    ap.add_argument("--replay-capacity", type=int, default=2048)
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
     return ap.parse_args()
 
@@ -115,14 +118,24 @@ def main():
         from pointcloud_rl_amd.utils.dist import broadcast_parameters_
         broadcast_parameters_(agent)                      # replicas start identical (DDP's constructor broadcast)
         agent.to_ddp(device_ids=["cuda"])
-    # every rank generates the global batch with the same seed and keeps its shard resident in HBM
-    full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
-    from pointcloud_rl_amd.utils.dist import shard_slice
-    sl = shard_slice(wl["B"], rank, world)
-    shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
-    memory = SyntheticReplay.__new__(SyntheticReplay)
-    from pointcloud_rl_amd.utils.torch_utils import to_torch
-    memory.batch_np, memory.batch = shard, to_torch(shard, device=device)
+    if args.replay == "device":
+        # device-resident replay (pointcloud_rl_amd/replay.py): every rank owns a ring of synthetic transitions and each
+        # step samples its share of the batch from it (uniform with replacement, as OneStepTransition does) -- sampling is
+        # part of the timed step, the ring is resident in HBM before the timed region
+        from pointcloud_rl_amd.replay import DeviceReplay
+        from pointcloud_rl_amd.synthetic import make_batch_np
+        memory = DeviceReplay(args.replay_capacity, device=device, seed=1 + rank)
+        for lo in range(0, args.replay_capacity, 512):
+            memory.push_batch(make_batch_np(min(512, args.replay_capacity - lo), wl["N"], wl["A"], seed=1 + 1000 * rank + lo, agent=wl["S"], **wl["obs_kw"]))
+    else:
+        # one fixed batch: every rank generates the global batch with the same seed and keeps its shard resident in HBM
+        full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
+        from pointcloud_rl_amd.utils.dist import shard_slice
+        sl = shard_slice(wl["B"], rank, world)
+        shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
+        memory = SyntheticReplay.__new__(SyntheticReplay)
+        from pointcloud_rl_amd.utils.torch_utils import to_torch
+        memory.batch_np, memory.batch = shard, to_torch(shard, device=device)
     agent.train()
     if not args.no_graphs:
         agent.enable_graphs()
@@ -177,7 +190,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
-                       "hip_graphs": graphed},
+                       "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": achieved / 157.3, "traffic": None, "launches": n_fwd, "avg_launch_ms": ms_fwd,
                          "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),

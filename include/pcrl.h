@@ -243,6 +243,18 @@ int pcrl_sac_actor_loss_f32(const float* q_pi, int64_t ld_q, const float* neg_lo
                             int32_t B, int32_t H, float* dq, int64_t ld_dq, float* d_neglogp, float* alpha_grad, float* stats,
                             void* stream);
 
+/* ---- device-resident replay ------------------------------------------------------------------------
+ * dst_k[b] = src_k[idx[b]] for every stored key k in one launch (rows of row_bytes bytes; idx is a device
+ * array of B row numbers, clamped to [0, capacity)).  Replaces ReplayMemory.sample's per-key numpy take and
+ * the host->device copy of the batch (replay_buffer.py:297-322, sac.py:104). */
+typedef struct pcrl_gather_seg { const void* src; void* dst; int64_t row_bytes; } pcrl_gather_seg;
+int pcrl_replay_gather(const pcrl_gather_seg* segs, int32_t n_segs, const int32_t* idx, int32_t B, int64_t capacity, void* stream);
+/* Same gather with the B row numbers drawn in the kernel: uniform with replacement on [0, size) as
+ * OneStepTransition does with numpy (sampling_strategy.py:30-31), from Philox4x32-10 keyed by `seed` with counter
+ * (b, draw); `draw` is the host's sample-call count.  The rows used are written to idx_out (may be NULL). */
+int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t size, int64_t capacity,
+                              uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream);
+
 /* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
  * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196). */
 int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n, void* stream);

@@ -41,6 +41,10 @@ class EncoderWeights(ctypes.Structure):
                 ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
 
 
+class GatherSeg(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("mask", ctypes.c_void_p),
                 ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("batch", ctypes.c_int32),

@@ -315,6 +315,31 @@ def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld
                                         _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
 
 
+def gather_segments(pairs):
+    """ctypes segment table for replay_gather / replay_sample_gather (build once, reuse every step):
+    pairs = [(storage [capacity, ...], staging [B, ...])] contiguous tensors of equal row size."""
+    n = len(pairs)
+    segs = (_lib.GatherSeg * n)()
+    for i, (src, dst) in enumerate(pairs):
+        row = src[0].numel() * src.element_size()
+        assert src.is_contiguous() and dst.is_contiguous() and dst[0].numel() * dst.element_size() == row
+        segs[i].src, segs[i].dst, segs[i].row_bytes = src.data_ptr(), dst.data_ptr(), row
+    return segs
+
+
+def replay_gather(segs, idx, capacity):
+    """staging[b] = storage[idx[b]] for every key; idx int32 [B] on the device."""
+    with _span("replay_gather"):
+        check(lib().pcrl_replay_gather(segs, len(segs), _ptr(idx), idx.numel(), ctypes.c_int64(capacity), _stream()))
+
+
+def replay_sample_gather(segs, B, size, capacity, seed, draw, idx_out=None):
+    """Rows drawn in the kernel (uniform on [0, size), Philox keyed by seed / draw); idx_out int32 [B] receives them."""
+    with _span("replay_gather"):
+        check(lib().pcrl_replay_sample_gather(segs, len(segs), B, ctypes.c_int64(size), ctypes.c_int64(capacity),
+                                              ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(draw), _ptr(idx_out), _stream()))
+
+
 def gather_scalars(entries):
     """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars."""
     n = len(entries)

@@ -378,7 +378,9 @@ class SAC(BaseAgent):
         """Copy `batch` into buffers whose addresses the captured graphs refer to."""
         keys = ("obs", "next_obs", "actions", "rewards", "dones")
         if self._static_batch is None:
-            self._static_batch = {k: ({kk: vv.clone() for kk, vv in batch[k].items()} if isinstance(batch[k], dict) else batch[k].clone())
+            # a device replay hands out long-lived staging tensors: read them in place instead of cloning
+            keep = (lambda t: t) if getattr(batch, "persistent", False) else (lambda t: t.clone())
+            self._static_batch = {k: ({kk: keep(vv) for kk, vv in batch[k].items()} if isinstance(batch[k], dict) else keep(batch[k]))
                                   for k in keys}
             return self._static_batch
         for k in keys:

@@ -139,3 +139,93 @@ def test_acting_path(cuda):
     feat, _ = torch_ref.visuomotor(P, "actor.backbone.final_mlp.mlp.", tobs)
     want = torch.tanh(feat[:, :8]) * P["actor.head.scale"] + P["actor.head.bias"]
     np.testing.assert_allclose(mean_a.cpu().numpy(), want.numpy(), atol=1e-5)
+
+
+def test_device_replay_sampling_matches_numpy_take(cuda):
+    """push_batch (with wrap-around) + sample == the reference's numpy ring + take with the same RandomState."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A = 40, 33, 5
+    mem = DeviceReplay(cap, device=cuda, seed=7, host_rng=True)
+    ring = None
+    pos = count = 0
+    for i, n in enumerate((16, 16, 16)):                 # third push wraps
+        items = make_batch_np(n, N, A, seed=i, seg=1, agent=3)
+        mem.push_batch(items)
+        flat = {"obs/" + k: v for k, v in items["obs"].items()} | {"next_obs/" + k: v for k, v in items["next_obs"].items()} | \
+               {k: v for k, v in items.items() if not isinstance(v, dict)}
+        if ring is None:
+            ring = {k: np.zeros((cap,) + v.shape[1:], v.dtype) for k, v in flat.items()}
+        for j in range(n):
+            for k, v in flat.items():
+                ring[k][(pos + j) % cap] = v[j]
+        pos, count = (pos + n) % cap, count + n
+    assert len(mem) == cap
+    rs = np.random.RandomState(7)
+    first_ptrs = None
+    for _ in range(3):
+        batch = mem.sample(12).to_torch(device=cuda)
+        idx = rs.randint(0, cap, 12)
+        assert batch.persistent
+        ptrs = (batch["obs"]["xyz"].data_ptr(), batch["rewards"].data_ptr())
+        first_ptrs = first_ptrs or ptrs
+        assert ptrs == first_ptrs                         # staging keeps its addresses
+        for k, v in ring.items():
+            node = batch
+            for part in k.split("/"):
+                node = node[part]
+            np.testing.assert_array_equal(node.cpu().numpy(), v[idx], err_msg=k)
+        assert batch["is_valid"].all() and batch["worker_indices"].shape == (12, 1)
+    # rows drawn in the kernel: in range, uniform, different on every call, and the gathered data are those rows
+    dev = DeviceReplay(cap, device=cuda, seed=11)
+    dev.push_batch(make_batch_np(25, N, A, seed=3, seg=1, agent=3))        # partially filled ring: only rows [0, 25)
+    seen, prev = np.zeros(25), None
+    for _ in range(40):
+        batch = dev.sample(64).to_torch(device=cuda)
+        idx = dev.last_indices(64).cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < 25 and (prev is None or (idx != prev).any())
+        np.testing.assert_array_equal(batch["obs"]["xyz"].cpu().numpy(), dev.storage["obs/xyz"].cpu().numpy()[idx])
+        np.testing.assert_array_equal(batch["actions"].cpu().numpy(), dev.storage["actions"].cpu().numpy()[idx])
+        seen += np.bincount(idx, minlength=25)
+        prev = idx
+    assert seen.min() > 0.6 * seen.mean() and seen.max() < 1.4 * seen.mean()      # 2560 draws over 25 rows
+    with pytest.raises(RuntimeError):
+        DeviceReplay(8, device="cpu")
+
+
+def test_update_from_device_replay_reads_staging_in_place(cuda):
+    """With graphs on, the agent adopts the replay's staging tensors as graph inputs (no copies) and every replay sees the new sample."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 8, 64, 4
+    cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    mem = DeviceReplay(64, device=cuda, seed=3)
+    mem.push_batch(make_batch_np(64, N, A, seed=5))
+    agent.enable_graphs(warmup=1)
+    rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+    assert agent._graphs and agent._static_batch["obs"]["xyz"].data_ptr() == mem._staging[B][0]["obs/xyz"].data_ptr()
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    assert len({round(r["sac/q_target"], 6) for r in rets[4:]}) > 1      # different samples -> different statistics
+
+
+def test_policy_noise_in_kernel_is_standard_normal_and_advances(cuda):
+    from pointcloud_rl_amd import hip
+    B, A = 4096, 6
+    feat = torch.zeros(B, 2 * A, device=cuda)            # mean 0, log_std 0 -> u = eps
+    scale, bias = torch.ones(A, device=cuda), torch.zeros(A, device=cuda)
+    step = torch.zeros(1, dtype=torch.int32, device=cuda)
+    draws = []
+    for s, d in ((0, 0), (0, 1), (1, 0)):
+        step.fill_(s)
+        eps, act, nlp = torch.empty(B, A, device=cuda), torch.empty(B, A, device=cuda), torch.empty(B, device=cuda)
+        hip.tanh_gaussian_sample_fwd(feat, 2 * A, 1234, step, d, eps, scale, bias, B, A, -10.0, 2.0, 1e-6, act, A, nlp)
+        np.testing.assert_allclose(act.cpu().numpy(), np.tanh(eps.cpu().numpy()), atol=1e-6)
+        draws.append(eps.cpu().numpy().ravel())
+    for e in draws:
+        assert abs(e.mean()) < 0.03 and abs(e.std() - 1) < 0.03 and abs((e ** 3).mean()) < 0.08 and abs((e ** 4).mean() - 3) < 0.25
+    assert abs(np.corrcoef(draws[0], draws[1])[0, 1]) < 0.03 and abs(np.corrcoef(draws[0], draws[2])[0, 1]) < 0.03
