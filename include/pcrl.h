@@ -196,6 +196,17 @@ int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
 int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,
                                 float eps, float* const* dst, const int64_t* ld_dst, int32_t n_dst,
                                 float* xhat, float* rstd, void* stream);
+/* Up to 3 row batches through the same LayerNorm in one launch (features of s and s' in the critic phase), each
+ * optionally passing up to two blocks of columns through unchanged into a destination (robot state and replay
+ * actions of Visuomotor's concatenations, visuomotor.py:130-141): cat_dst[c][m][0..cat_n[c]) = cat_src[c][m][..]. */
+typedef struct pcrl_ln_job {
+    const float* x; int64_t ldx; int32_t M, n_dst;
+    float* dst[4]; int64_t ld_dst[4];
+    float* xhat; float* rstd;
+    const float* cat_src[2]; float* cat_dst[2]; int64_t cat_ld_src[2], cat_ld_dst[2]; int32_t cat_n[2];
+} pcrl_ln_job;
+int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_t n_jobs, const float* gamma, const float* beta, int32_t F,
+                                      float eps, void* stream);
 int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
                                 const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
                                 float* dgamma, float* dbeta, int32_t accumulate,

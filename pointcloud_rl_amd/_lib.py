@@ -41,6 +41,13 @@ class EncoderWeights(ctypes.Structure):
                 ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
 
 
+class LnJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
+                ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("cat_src", ctypes.c_void_p * 2), ("cat_dst", ctypes.c_void_p * 2), ("cat_ld_src", ctypes.c_int64 * 2),
+                ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2)]
+
+
 class GatherSeg(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
 

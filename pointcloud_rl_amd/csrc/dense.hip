@@ -208,18 +208,30 @@ __global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmGro
 // Row-wise LayerNorm over a short feature vector (PointNet.final_mlp[1]: nn.LayerNorm(out), eps 1e-5,
 // pointnet.py:110), one wave per row; the output may be scattered into several destination
 // buffers (the concatenated inputs of the actor and Q heads).
-struct LnParams {
+struct LnJob {
     const float* x; long long ldx;       // [M][F]
-    const float* gamma; const float* beta;
-    int M, F; float eps;
-    float* y[4]; long long ldy[4]; int n_dst;
+    int M, n_dst, blk_begin;
+    float* y[4]; long long ldy[4];
     float* xhat; float* rstd;            // saved for backward (may be NULL)
+    // optional pass-through columns (robot state / replay actions of Visuomotor's torch.cat, visuomotor.py:130-141):
+    // cat_dst[m][0..cat_n) = cat_src[m][0..cat_n)
+    const float* cat_src[2]; float* cat_dst[2]; long long cat_lds[2], cat_ldd[2]; int cat_n[2];
+};
+constexpr int kLnJobs = 3;
+struct LnParams {
+    const float* gamma; const float* beta; int F; float eps; int n_jobs;
+    LnJob job[kLnJobs];
 };
 
 __global__ __launch_bounds__(256) void layernorm_rows_fwd_kernel(const LnParams p) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= p.M) return;
-    const float* x = p.x + (long long)row * p.ldx;
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < kLnJobs; ++j)
+        if (j < p.n_jobs && (int)blockIdx.x >= p.job[j].blk_begin) ji = j;
+    const LnJob& jb = p.job[ji];
+    const int row = ((int)blockIdx.x - jb.blk_begin) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= jb.M) return;
+    const float* x = jb.x + (long long)row * jb.ldx;
     float v[4], s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; v[j] = f < p.F ? x[f] : 0.0f; s += v[j]; }
@@ -230,17 +242,21 @@ __global__ __launch_bounds__(256) void layernorm_rows_fwd_kernel(const LnParams 
     for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; const float d = f < p.F ? v[j] - mean : 0.0f; q += d * d; }
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
     const float rstd = 1.0f / __builtin_sqrtf(q / (float)p.F + p.eps);
-    if (p.rstd && lane == 0) p.rstd[row] = rstd;
+    if (jb.rstd && lane == 0) jb.rstd[row] = rstd;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int f = lane + 64 * j;
         if (f < p.F) {
             const float xh = (v[j] - mean) * rstd;
-            if (p.xhat) p.xhat[(long long)row * p.F + f] = xh;
+            if (jb.xhat) jb.xhat[(long long)row * p.F + f] = xh;
             const float y = xh * p.gamma[f] + p.beta[f];
-            for (int d = 0; d < p.n_dst; ++d) p.y[d][(long long)row * p.ldy[d] + f] = y;
+            for (int d = 0; d < jb.n_dst; ++d) jb.y[d][(long long)row * jb.ldy[d] + f] = y;
         }
     }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (jb.cat_src[c])
+            for (int f = lane; f < jb.cat_n[c]; f += 64) jb.cat_dst[c][(long long)row * jb.cat_ldd[c] + f] = jb.cat_src[c][(long long)row * jb.cat_lds[c] + f];
 }
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma, where dy is the
@@ -296,7 +312,15 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n) return;
     float a = 0.0f, c = 0.0f;
-    for (int b = 0; b < nblk; ++b) { a += part[((long long)b * 2 + 0) * n + f]; c += part[((long long)b * 2 + 1) * n + f]; }
+    int b = 0;
+    for (; b + 16 <= nblk; b += 16) {          // 32 independent loads in flight, summed in block order
+        float va[16], vc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { va[u] = part[((long long)(b + u) * 2 + 0) * n + f]; vc[u] = part[((long long)(b + u) * 2 + 1) * n + f]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a += va[u]; c += vc[u]; }
+    }
+    for (; b < nblk; ++b) { a += part[((long long)b * 2 + 0) * n + f]; c += part[((long long)b * 2 + 1) * n + f]; }
     out0[f] = accumulate ? out0[f] + a : a;
     out1[f] = accumulate ? out1[f] + c : c;
 }
@@ -362,19 +386,42 @@ extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
     return pcrl_gemm_group_f32(d, 1, stream);
 }
 
+extern "C" int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_t n_jobs, const float* gamma, const float* beta, int32_t F,
+                                                 float eps, void* stream) {
+    if (!jobs || !gamma || !beta) return fail(PCRL_E_ARG, "NULL argument");
+    if (F < 1 || F > 256 || n_jobs < 1 || n_jobs > kLnJobs) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, 1 <= n_jobs <= %d", kLnJobs);
+    LnParams p{};
+    p.gamma = gamma; p.beta = beta; p.F = F; p.eps = eps;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const pcrl_ln_job& s = jobs[j];
+        if (s.M == 0) continue;
+        if (!s.x || s.M < 0 || s.n_dst < 0 || s.n_dst > 4) return fail(PCRL_E_ARG, "bad LayerNorm job %d", j);
+        LnJob& d = p.job[p.n_jobs++];
+        d.x = s.x; d.ldx = s.ldx; d.M = s.M; d.n_dst = s.n_dst; d.blk_begin = blocks; d.xhat = s.xhat; d.rstd = s.rstd;
+        for (int i = 0; i < s.n_dst; ++i) { if (!s.dst[i]) return fail(PCRL_E_ARG, "NULL destination"); d.y[i] = s.dst[i]; d.ldy[i] = s.ld_dst[i]; }
+        for (int c = 0; c < 2; ++c) {
+            if (s.cat_n[c] > 0 && (!s.cat_src[c] || !s.cat_dst[c])) return fail(PCRL_E_ARG, "NULL pass-through columns");
+            d.cat_src[c] = s.cat_n[c] > 0 ? s.cat_src[c] : nullptr; d.cat_dst[c] = s.cat_dst[c];
+            d.cat_lds[c] = s.cat_ld_src[c]; d.cat_ldd[c] = s.cat_ld_dst[c]; d.cat_n[c] = s.cat_n[c];
+        }
+        blocks += (s.M + 3) / 4;
+    }
+    if (blocks == 0) return PCRL_OK;
+    hipLaunchKernelGGL(layernorm_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("layernorm_rows_fwd_kernel");
+    return PCRL_OK;
+}
+
 extern "C" int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,
                                            float eps, float* const* dst, const int64_t* ld_dst, int32_t n_dst,
                                            float* xhat, float* rstd, void* stream) {
-    if (!x || !gamma || !beta || !dst || !ld_dst) return fail(PCRL_E_ARG, "NULL argument");
-    if (F < 1 || F > 256 || n_dst < 1 || n_dst > 4) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, 1 <= n_dst <= 4");
-    if (M == 0) return PCRL_OK;
-    LnParams p{};
-    p.x = x; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.M = M; p.F = F; p.eps = eps; p.n_dst = n_dst;
-    for (int i = 0; i < n_dst; ++i) { p.y[i] = dst[i]; p.ldy[i] = ld_dst[i]; }
-    p.xhat = xhat; p.rstd = rstd;
-    hipLaunchKernelGGL(layernorm_rows_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
-    PCRL_CHECK_LAUNCH("layernorm_rows_fwd_kernel");
-    return PCRL_OK;
+    if (!x || !dst || !ld_dst) return fail(PCRL_E_ARG, "NULL argument");
+    if (n_dst < 1 || n_dst > 4) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, 1 <= n_dst <= 4");
+    pcrl_ln_job job{};
+    job.x = x; job.ldx = ldx; job.M = M; job.n_dst = n_dst; job.xhat = xhat; job.rstd = rstd;
+    for (int i = 0; i < n_dst; ++i) { job.dst[i] = dst[i]; job.ld_dst[i] = ld_dst[i]; }
+    return pcrl_layernorm_rows_fwd_multi_f32(&job, 1, gamma, beta, F, eps, stream);
 }
 
 extern "C" int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,

@@ -273,6 +273,22 @@ def layernorm_rows_fwd(x, ldx, gamma, beta, M, F, eps, dsts, xhat=None, rstd=Non
                                             _ptr(xhat), _ptr(rstd), _stream()))
 
 
+def layernorm_rows_fwd_multi(jobs, gamma, beta, F, eps):
+    """jobs: [dict(x=, ldx=, M=, dsts=[(tensor, column offset, leading dim)], xhat=None, rstd=None,
+    cats=[(src tensor [M, n] (row stride src.stride(0)), dst tensor, dst column offset, dst leading dim)])], one launch."""
+    arr = (_lib.LnJob * len(jobs))()
+    for j, job in zip(arr, jobs):
+        j.x, j.ldx, j.M, j.n_dst = job["x"].data_ptr(), job["ldx"], job["M"], len(job["dsts"])
+        for i, (t, off, ld) in enumerate(job["dsts"]):
+            j.dst[i], j.ld_dst[i] = t.data_ptr() + 4 * off, ld
+        j.xhat = job["xhat"].data_ptr() if job.get("xhat") is not None else None
+        j.rstd = job["rstd"].data_ptr() if job.get("rstd") is not None else None
+        for c, (src, dst, off, ld) in enumerate(job.get("cats", [])):
+            assert src.dtype == torch.float32 and src.stride(-1) == 1
+            j.cat_src[c], j.cat_dst[c], j.cat_ld_src[c], j.cat_ld_dst[c], j.cat_n[c] = src.data_ptr(), dst.data_ptr() + 4 * off, src.stride(0), ld, src.shape[1]
+    check(lib().pcrl_layernorm_rows_fwd_multi_f32(arr, len(jobs), _ptr(gamma), _ptr(beta), F, _f(eps), _stream()))
+
+
 def layernorm_rows_bwd(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, dgamma, dbeta, workspace, accumulate=False):
     check(lib().pcrl_layernorm_rows_bwd_f32(ctypes.c_void_p(dy0), ctypes.c_void_p(dy1) if dy1 else None, ctypes.c_int64(lddy), _ptr(xhat), _ptr(rstd),
                                             _ptr(gamma), M, F, _ptr(dx), ctypes.c_int64(lddx), _ptr(dgamma), _ptr(dbeta), int(accumulate),

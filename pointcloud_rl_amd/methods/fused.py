@@ -164,25 +164,26 @@ class FusedStep:
     # -- pieces -------------------------------------------------------------------------------------
     def _features(self, jobs):
         """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
-        jobs = [(pooled, M, tag, dsts, save)]; the Linear GEMMs share one launch.  Returns [(xhat, rstd)]."""
+        jobs = [(pooled, M, tag, dsts, save, cats)]; the Linear GEMMs share one launch and so do the LayerNorms, which
+        also drop the pass-through columns `cats` = [(src [M, n], dst buffer, dst column)] (robot state, replay actions:
+        Visuomotor's torch.cat, visuomotor.py:130-141) into the head inputs.  Returns [(xhat, rstd)]."""
         fc, off, F, c3 = self.a._flat["critic"], self.off, self.F, self.c3
         pre = "values.0.backbone.visual_nn.final_mlp."
-        ys = [self._buf(f"feat_pre_{tag}", M, F) for _, M, tag, _, _ in jobs]
+        ys = [self._buf(f"feat_pre_{tag}", M, F) for _, M, tag, _, _, _ in jobs]
         hip.gemm_group([hip.gemm_desc(pooled, fc.data[off[pre + "0.weight"]:], y, M, F, c3, (c3, 1), (1, c3), F, bias=fc.data[off[pre + "0.bias"]:])
-                        for (pooled, M, _, _, _), y in zip(jobs, ys)])
-        out = []
-        for (_, M, tag, dsts, save), y in zip(jobs, ys):
+                        for (pooled, M, _, _, _, _), y in zip(jobs, ys)])
+        out, ln_jobs = [], []
+        for (_, M, tag, dsts, save, cats), y in zip(jobs, ys):
             xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
             rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
-            hip.layernorm_rows_fwd(y, F, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], M, F,
-                                   self.a.encoder.final_mlp[1].eps, dsts, xhat, rstd)
+            pending = [(src if src.dtype == torch.float32 else src.float(), dst, col, dst.shape[1]) for src, dst, col in cats if src is not None]
+            while len(pending) > 2:                      # the kernel takes two pass-through blocks per job
+                src, dst, col, _ = pending.pop()
+                dst[:, col:col + src.shape[1]].copy_(src)
+            ln_jobs.append(dict(x=y, ldx=F, M=M, dsts=dsts, xhat=xhat, rstd=rstd, cats=pending))
             out.append((xhat, rstd))
+        hip.layernorm_rows_fwd_multi(ln_jobs, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps)
         return out
-
-    def _state_into(self, state, bufs_cols):
-        if state is not None:
-            for buf, col in bufs_cols:
-                buf[:, col:col + state.shape[1]].copy_(state)
 
     def _actor_forward(self, XA, M, tag, act_dst, ld_act, save):
         """Actor MLP + TanhGaussianHead mode="max-entropy"; the action goes straight into the Q input."""
@@ -241,11 +242,9 @@ class FusedStep:
         vis_o, state_o = split(obs)
         pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
         XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
-        (_, _), (xhat, rstd) = self._features([(pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False),
-                                                (pooled_o, M, "o", [(XQ_o, 0, ldq)], True)])
-        self._state_into(state_n, [(XA_n, F), (XQ_n, F)])
-        self._state_into(state_o, [(XQ_o, F)])
-        XQ_o[:, F + S:F + S + A].copy_(actions)
+        (_, _), (xhat, rstd) = self._features([
+            (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F), (state_n, XQ_n, F)]),
+            (pooled_o, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F), (actions, XQ_o, F + S)])])
         _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
@@ -287,8 +286,7 @@ class FusedStep:
             Ma = M if actor_obs is None else vis_a["xyz"].shape[0]
             pooled_a, _, _ = enc.encode_raw(vis_a)                    # updated encoder weights, no gradient
             XA_a, XQ_a = self._buf("XA_a", Ma, lda), self._buf("XQ_a", Ma, ldq)
-            self._features([(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False)])
-            self._state_into(state_a, [(XA_a, F), (XQ_a, F)])
+            self._features([(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False, [(state_a, XA_a, F), (state_a, XQ_a, F)])])
             feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)
             q_pi = self._buf("q_pi", Ma, 2)

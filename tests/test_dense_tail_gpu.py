@@ -176,3 +176,21 @@ def test_gemm_group_matches_single_launches(cuda):
     np.testing.assert_allclose(outs_a[2].cpu().numpy(), np.maximum(x2 @ w2.T, 0), atol=2e-5, rtol=1e-5)
     with pytest.raises(RuntimeError):
         hip.gemm_group(descs(*outs_a) + descs(*outs_a)[:1])          # more than 4 problems
+
+
+def test_layernorm_rows_multi_job_with_pass_through_columns(cuda):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(3)
+    Fd = 50
+    G, Bt = T(g.randn(Fd).astype(np.float32), cuda), T(g.randn(Fd).astype(np.float32), cuda)
+    jobs, wants = [], []
+    for M in (37, 256):
+        x, st, ac = g.randn(M, Fd).astype(np.float32), g.randn(M, 5).astype(np.float32), g.randn(M, 6).astype(np.float32)
+        X, ST, AC = T(x, cuda), T(st, cuda), T(ac, cuda)
+        dst = torch.zeros(M, 64, device=cuda)
+        jobs.append(dict(x=X, ldx=Fd, M=M, dsts=[(dst, 0, 64)], cats=[(ST, dst, Fd, 64), (AC, dst, Fd + 5, 64)], keep=(X, ST, AC, dst)))
+        ref = F.layer_norm(torch.from_numpy(x), (Fd,), G.cpu(), Bt.cpu(), 1e-5)
+        wants.append(np.concatenate([ref.numpy(), st, ac, np.zeros((M, 64 - Fd - 11), np.float32)], 1))
+    hip.layernorm_rows_fwd_multi(jobs, G, Bt, Fd, 1e-5)
+    for job, want in zip(jobs, wants):
+        np.testing.assert_allclose(job["keep"][3].cpu().numpy(), want, atol=2e-6, rtol=1e-5)
