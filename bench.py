@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--replay", default="device", choices=["device", "fixed"], help="device: sample every step from a device-resident "
                     "ring of synthetic transitions; fixed: the same resident batch every step")
     ap.add_argument("--replay-capacity", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=0, help="analysis only: override the global batch size (the JSON line then is NOT the "
+                    "BASELINE metric; used to look at the per-GPU share of a multi-GPU run on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
     return ap.parse_args()
 
@@ -92,7 +94,9 @@ def cpu_baseline(agent, wl, steps):
 
 def main():
     args = parse()
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["B"], wl["desc"] = args.batch, wl["desc"] + f" [batch overridden to {args.batch}]"
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))

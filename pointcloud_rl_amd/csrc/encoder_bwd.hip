@@ -81,6 +81,24 @@ __device__ __forceinline__ float allreduce_add32(float v) {
     return v;
 }
 
+// Sixteen independent 32-lane sums advanced together (the dependent DPP chains of one sum at a time cost ~100
+// cycles each); lane ^ 16 through v_permlane16_swap instead of ds_swizzle keeps the LDS pipe out of it.
+__device__ __forceinline__ void allreduce_add32_x16(float (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0xB1>(v[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x4E>(v[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x141>(v[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x140>(v[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        auto sw = __builtin_amdgcn_permlane16_swap(f2u(v[r]), f2u(v[r]), false, false);
+        v[r] = u2f(sw[0]) + u2f(sw[1]);
+    }
+}
+
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
 template <int C>
 __device__ __forceinline__ float ln_to_xhat(f32x16 (&a)[C / 32], float eps) {
@@ -194,7 +212,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     if (c < p.cl.C) buf_store_f1(r_ops, lane_off, 4u * (unsigned)(OL.xb() + c * 4), x[c]);
                 buf_store_f1(r_ops, lane_off + 16u * (unsigned)p.cl.C, 4u * (unsigned)OL.xb(), 1.0f);
             }
-
             // ---- forward recompute: conv0 + ReLU -------------------------------------------------
             f32x16 a0[MB1];
             unsigned mask0[MB1];
@@ -226,15 +243,17 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 [&](int t) { return a0[t >> 4][t & 15]; });
             const float rstd1 = ln_to_xhat<kC2>(a1, p.eps);
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
+            for (int mb = 0; mb < MB2; ++mb) {
+                float2 gbv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gbv[r] = reinterpret_cast<const float2*>(s_ln1)[acc_chan(mb * 16 + r, 0) + 4 * half];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     buf_store_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64), a1[mb][r]);
-                    const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-                    const float2 gb = reinterpret_cast<const float2*>(s_ln1)[ch];
-                    a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gb.x, gb.y));
+                    a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
                     buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
                 }
+            }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
 #pragma unroll
@@ -247,6 +266,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             const float rstd2 = ln_to_xhat<kC3>(a2, p.eps);
 
             // ---- max-pool + ReLU + LN2 backward ----------------------------------------------------
+            // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
+            // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
+            // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
             // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
             // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
             // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
@@ -309,23 +331,35 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             f32x16 xh1[MB2];
             s1 = 0.0f; s2 = 0.0f;
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
+            for (int mb = 0; mb < MB2; ++mb)           // all 64 reloads of xhat1 in flight at once
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xh1[mb][r] = buf_load_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64));
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb) {
+                float2 gbv[16]; float tg[16], tb[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gbv[r] = reinterpret_cast<const float2*>(s_ln1)[acc_chan(mb * 16 + r, 0) + 4 * half];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    xh1[mb][r] = buf_load_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64));
-                    const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-                    const float2 gb = reinterpret_cast<const float2*>(s_ln1)[ch];
-                    const float y = __builtin_fmaf(xh1[mb][r], gb.x, gb.y);
+                    const float y = __builtin_fmaf(xh1[mb][r], gbv[r].x, gbv[r].y);
                     const float dyl = y > 0.0f ? d1[mb][r] : 0.0f;
-                    // norm1.weight / norm1.bias gradients: sum over this tile's 32 points
-                    const float tg = allreduce_add32(dyl * xh1[mb][r]);
-                    const float tb = allreduce_add32(dyl);
-                    if (l31 == 0) { s_red[(wave * kC2 + ch) * 2 + 0] = tg; s_red[(wave * kC2 + ch) * 2 + 1] = tb; }
-                    const float dx = dyl * gb.x;
+                    tg[r] = dyl * xh1[mb][r];          // norm1.weight / norm1.bias gradients: summed over this tile's 32 points below
+                    tb[r] = dyl;
+                    const float dx = dyl * gbv[r].x;
                     d1[mb][r] = dx;
                     s1 = s1 + dx;
                     s2 = __builtin_fmaf(dx, xh1[mb][r], s2);
                 }
+                allreduce_add32_x16(tg);
+                allreduce_add32_x16(tb);
+                if (l31 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                        reinterpret_cast<float2*>(s_red)[wave * kC2 + ch] = float2{tg[r], tb[r]};
+                    }
+                }
+            }
             both_halves(s1, lo, hi);
             const float n1 = (lo + hi) / (float)kC2;
             both_halves(s2, lo, hi);
@@ -448,17 +482,29 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
 }
 
 // ---- reduce: grads[i] = sum_b pw[b][i], fixed order ---------------------------------------------
-__global__ void encoder_bwd_reduce_kernel(const float* __restrict__ pw, int B, int n, float* __restrict__ grads) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// HBM/L2-bound (B x n floats read once).  A 1024-thread block owns 64 consecutive elements; thread (g, c) sums the
+// clouds b = g, g + 16, ... of element c with four loads in flight, then the 16 partials are added in g order.
+__global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* __restrict__ pw, int B, int n, float* __restrict__ grads) {
+    __shared__ float s_part[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
-    int b = 0;
-    for (; b + 3 < B; b += 4) {
-        p0 = p0 + pw[(long long)(b + 0) * n + i]; p1 = p1 + pw[(long long)(b + 1) * n + i];
-        p2 = p2 + pw[(long long)(b + 2) * n + i]; p3 = p3 + pw[(long long)(b + 3) * n + i];
+    if (i < n) {
+        int b = g;
+        for (; b + 48 < B; b += 64) {
+            p0 = p0 + pw[(long long)(b + 0) * n + i]; p1 = p1 + pw[(long long)(b + 16) * n + i];
+            p2 = p2 + pw[(long long)(b + 32) * n + i]; p3 = p3 + pw[(long long)(b + 48) * n + i];
+        }
+        for (; b < B; b += 16) p0 = p0 + pw[(long long)b * n + i];
     }
-    for (; b < B; ++b) p0 = p0 + pw[(long long)b * n + i];
-    grads[i] = (p0 + p1) + (p2 + p3);
+    s_part[g][c] = (p0 + p1) + (p2 + p3);
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = acc + s_part[k][c];
+        grads[i] = acc;
+    }
 }
 
 static size_t bwd_lds_bytes(int T0, int C1) {
@@ -553,7 +599,7 @@ extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
     const int n = GL.total();
-    hipLaunchKernelGGL(encoder_bwd_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p.pw, p.cl.B, n, grads);
+    hipLaunchKernelGGL(encoder_bwd_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, p.pw, p.cl.B, n, grads);
     PCRL_CHECK_LAUNCH("encoder_bwd_reduce_kernel");
     if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
     return PCRL_OK;
