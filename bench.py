@@ -187,6 +187,13 @@ def main():
         # the launches of one step have different cloud counts only for DrQ; for SAC every launch encodes b_rank clouds
         flops_per_launch = f_pt * b_rank * wl["N"]
         achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
+        if os.path.exists(tpath) and not args.batch and world == 1:
+            # HBM bytes per encoder_fwd launch from the committed rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
         out = {
             "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
             "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -196,7 +203,8 @@ def main():
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
                        "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": None, "launches": n_fwd, "avg_launch_ms": ms_fwd,
+                         "frac": achieved / 157.3, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": b_rank * wl["N"] * (12 + 3 + (C - 6)) + 8 * b_rank * agent.encoder.mlp_spec[2], "launches": n_fwd, "avg_launch_ms": ms_fwd,
                          "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
                          "algorithmic_flops_per_launch": flops_per_launch},
             "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
