@@ -67,7 +67,9 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
         const int t_begin = seg * p.tiles_per_seg;
         const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
         __syncthreads();   // previous read-out of s_keys (and the prologue) is complete
-        for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0ull;
+        // {value +0.0, point 0}: what a channel that is zero everywhere (ReLU-dead) must report, so zero maxima never
+        // have to be written by anybody
+        for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0x00000000FFFFFFFFull;
         __syncthreads();
 
         for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
@@ -124,7 +126,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             }
 
             // ---- symmetric max-pool with first-index argmax --------------------------------
-            const unsigned inv_idx = ~(unsigned)pidx;
+            // lanes past N hold a copy of point N - 1 and report that index, so no validity test is needed below
+            const unsigned inv_idx = ~(unsigned)pc;
 #pragma unroll
             for (int mb = 0; mb < MB3; ++mb) {
                 // 16 independent reductions advance together: each DPP step of one register fills the
@@ -143,14 +146,14 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
-                    m[r] = umax_(sw[0], sw[1]);
+                    // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.  max(.., 1):
+                    // a zero maximum matches no lane (nobody reports it: the key's initial value already says so)
+                    m[r] = umax_(umax_(sw[0], sw[1]), 1u);
                 }
-                // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.
-                // An all-zero channel ties everywhere: only the tile's first point needs to report.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned v = f2u(a2[mb][r]);
-                    if (valid && v == m[r] && (m[r] != 0u || l31 == 0)) {
+                    if (v == m[r]) {
                         const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
                         atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
                     }
