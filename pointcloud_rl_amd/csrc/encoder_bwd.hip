@@ -234,10 +234,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
-#pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
             dense_layer_mfma<MB2, C1 / 8, 3>(
                 a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                 [&](int t) { return a0[t >> 4][t & 15]; });
@@ -256,10 +252,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
-#pragma unroll
-            for (int mb = 0; mb < MB3; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a2[mb][r] = 0.0f;
             dense_layer_mfma<MB3, kC2 / 8, 2>(
                 a2, [&](int mb, int tq) { return s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane]; },
                 [&](int t) { return a1[t >> 4][t & 15]; });
@@ -321,10 +313,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
-#pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) d1[mb][r] = 0.0f;
             dense_layer_mfma<MB2, kC3 / 8, 3>(
                 d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
                 [&](int t) { return a2[t >> 4][t & 15]; });
@@ -373,10 +361,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
-#pragma unroll
-            for (int mb = 0; mb < MB1; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) d0[mb][r] = 0.0f;
             dense_layer_mfma<MB1, kC2 / 8, 3>(
                 d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
                 [&](int t) { return d1[t >> 4][t & 15]; });

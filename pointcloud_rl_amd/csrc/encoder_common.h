@@ -174,7 +174,7 @@ __device__ __forceinline__ void stream_operands(LoadFn load, BodyFn body) {
 // operands of pair-group g + DEPTH are in flight while group g computes.
 // load(mb, tq) -> the f32x4 holding A operands of k-steps 4tq..4tq+3 of row block mb;
 // act(t) -> the B operand (activation register) of k-step t.
-template <int MB, int TQ, int DEPTH, class LoadFn, class ActFn>
+template <int MB, int TQ, int DEPTH, bool ZERO_START = true, class LoadFn, class ActFn>
 __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
     static_assert(MB % 2 == 0, "row blocks are processed in pairs");
     constexpr int NG = (MB / 2) * TQ;
@@ -193,8 +193,12 @@ __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float b = act(4 * tq + j);
-            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, acc[mb], 0, 0, 0);
-            acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, acc[mb + 1], 0, 0, 0);
+            // the first k-step takes the literal 0 as its C operand: the accumulators need no zero fill (on gfx950 a
+            // v_mov costs the same FP32 ALU cycles the MFMAs need -- tools/probes/mfma_valu_overlap.hip)
+            const bool first = ZERO_START && tq == 0 && j == 0;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, first ? zero : acc[mb], 0, 0, 0);
+            acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, first ? zero : acc[mb + 1], 0, 0, 0);
         }
     }
 }

@@ -97,10 +97,6 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
             // ---- conv1 + LN + ReLU --------------------------------------------------------
             f32x16 a1[MB2];
-#pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a1[mb][r] = 0.0f;
             dense_layer_mfma<MB2, C1 / 8, 3>(
                 a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                 [&](int t) { return a0[t >> 4][t & 15]; });
@@ -108,10 +104,6 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
-#pragma unroll
-            for (int mb = 0; mb < MB3; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a2[mb][r] = 0.0f;
             dense_layer_mfma<MB3, C2 / 8, 2>(
                 a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
                 [&](int t) { return a1[t >> 4][t & 15]; });
