@@ -72,6 +72,12 @@ __device__ __forceinline__ void buf_store_f1(__amdgpu_buffer_rsrc_t r, unsigned 
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 
+// lo for the lower wave half, hi for the upper one, as ONE bit-select (written as `half ? hi : lo` on two elements of a
+// vector the compiler turns it into a 15-deep compare/select chain over a run-time element index).
+__device__ __forceinline__ float half_select(float lo, float hi, unsigned half_mask) {
+    return u2f((f2u(hi) & half_mask) | (f2u(lo) & ~half_mask));
+}
+
 // ReLU that propagates NaN and maps -0 to +0 (torch.relu semantics).
 __device__ __forceinline__ float relu_nan(float x) { return !(x <= 0.0f) ? x : 0.0f; }
 

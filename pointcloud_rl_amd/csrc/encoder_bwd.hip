@@ -212,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     if (c < p.cl.C) buf_store_f1(r_ops, lane_off, 4u * (unsigned)(OL.xb() + c * 4), x[c]);
                 buf_store_f1(r_ops, lane_off + 16u * (unsigned)p.cl.C, 4u * (unsigned)OL.xb(), 1.0f);
             }
+            const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
             // ---- forward recompute: conv0 + ReLU -------------------------------------------------
             f32x16 a0[MB1];
             unsigned mask0[MB1];
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
 #pragma unroll
                 for (int t = 0; t < T0; ++t) {
-                    const float bop = half ? x[2 * t + 1] : x[2 * t];
+                    const float bop = half_select(x[2 * t], x[2 * t + 1], half_mask);
                     a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
                 }
                 mask0[mb] = 0u;

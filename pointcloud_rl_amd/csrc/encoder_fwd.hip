@@ -80,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             // ---- preprocess (+ augmentation) ---------------------------------------------
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
 
+            const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
             // ---- conv0 + bias + ReLU ------------------------------------------------------
             f32x16 a0[MB1];
 #pragma unroll
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
 #pragma unroll
                 for (int t = 0; t < T0; ++t) {
-                    const float bop = half ? x[2 * t + 1] : x[2 * t];
+                    const float bop = half_select(x[2 * t], x[2 * t + 1], half_mask);
                     a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
                 }
 #pragma unroll
