@@ -123,3 +123,34 @@ def test_fwd_bad_arguments_raise(cuda):
     from pointcloud_rl_amd._lib import PcrlError
     with pytest.raises(PcrlError):
         hip.encoder_packed_bytes(6, 64, 128, 1024)      # c3 = 1024 not supported by the fused kernel
+
+
+@pytest.mark.parametrize("name,B,N,extra,c1", [
+    ("K0 dmc_walker_walk: 3 frames x 512 points, xyz+rgb+pos_encoding", 4, 1536, dict(pos_encoding=3), 64),
+    ("K2/K3 ManiSkill MoveBucket: N=1200, xyz+rgb+seg, nets [128,128,256], 128 clouds per GPU", 128, 1200, dict(seg=1), 128),
+    ("K4 large-N stress: N=8192, 64 clouds per GPU, two-stage pool", 64, 8192, dict(), 64),
+])
+def test_fwd_baseline_config_shapes(cuda, name, B, N, extra, c1):
+    """BASELINE.json configs 1, 3/4 and 5 at their full per-GPU sizes: a slice of the batch against the oracle (bit-exact),
+    and the whole batch through size-independent properties (batch order invariance, point-permutation invariance)."""
+    from oracle import c_oracle
+    obs = make_obs(B, N, seed=11, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, c1, 128, 256, seed=2)
+    pooled, argmax = _run_hip(obs, w, cuda)
+    sel = sorted({0, B // 2, B - 1})
+    sub = {k: v[sel] for k, v in obs.items()}
+    pooled_ref, arg_ref = c_oracle.encoder_fwd(c_oracle.preprocess(sub), w)
+    assert np.array_equal(argmax[sel], arg_ref), name
+    assert np.array_equal(pooled[sel].view(np.uint32), pooled_ref.view(np.uint32)), name
+    assert argmax.min() >= 0 and argmax.max() < N
+    # clouds are independent: reversing the batch reverses the outputs bit for bit
+    rev = {k: np.ascontiguousarray(v[::-1]) for k, v in obs.items()}
+    pooled_r, argmax_r = _run_hip(rev, w, cuda)
+    assert np.array_equal(pooled_r[::-1].view(np.uint32), pooled.view(np.uint32)) and np.array_equal(argmax_r[::-1], argmax)
+    # the pool is symmetric: permuting the points keeps the pooled values bit for bit
+    perm = np.random.RandomState(3).permutation(N)
+    obs_p = {k: np.ascontiguousarray(v[:, :, perm]) for k, v in obs.items()}
+    pooled_p, argmax_p = _run_hip(obs_p, w, cuda)
+    assert np.array_equal(pooled_p.view(np.uint32), pooled.view(np.uint32))
+    assert argmax_p.min() >= 0 and argmax_p.max() < N
