@@ -71,7 +71,12 @@ typedef struct pcrl_cloud_desc {
  * Cloud b uses row (b * row_mul + row_add) of jitter_noise / affine / the Philox counter
  * (row_mul == 0 means 1), so a strided sub-batch (DrQ's actor step uses augmentation #0 of every
  * sample, drq.py:115) sees exactly the noise the full batch saw. */
-enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2 };
+/*  SUBSAMPLE : the cloud the encoder sees is points point_index[0..n_index) of the stored cloud, the same index for
+ *            every cloud and every key (RandomDownSample.process_single: one shared random permutation prefix,
+ *            pcd_aug.py:231-257 + array_ops.py:659-680); N becomes n_index and the returned argmax counts
+ *            positions of the subsampled cloud, as it does in the reference where the tensors are sliced.
+ *            Jitter noise / Philox counters are indexed by the subsampled position. */
+enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2, PCRL_AUG_SUBSAMPLE = 4 };
 typedef struct pcrl_aug_desc {
     int32_t flags, row_mul, row_add, _pad;
     const float* jitter_noise;
@@ -80,6 +85,8 @@ typedef struct pcrl_aug_desc {
     const float* affine;
     const uint64_t* offset_ptr;   /* device; when non-NULL the Philox offset is read from here at run
                                      time (a launch replayed from a hipGraph then draws fresh noise) */
+    const int32_t* point_index;   /* device [n_index], values in [0, N): PCRL_AUG_SUBSAMPLE */
+    int32_t n_index, _pad2;
 } pcrl_aug_desc;
 
 /* Weights of the shared per-point MLP in the reference's own state_dict layout

@@ -107,6 +107,52 @@ class RandomJitterPoints(_PointAug):
         return f"{type(self).__name__}(jitter_range={self.jitter_range},"
 
 
+@AUGMENTATIONS.register_module()
+class RandomDownSample:
+    """Keep a random subset of the points, the same subset for every cloud of the batch and every key
+    (pcd_aug.py:231-268: `batch_perm(data[:1, 0, :], 1, max_num_points)[0]` = the first k entries of
+    `rand(N).argsort()`, drawn once per call and applied to all `req_keys`).  With drop_ratio and
+    fixed_ratio=False the number of dropped points is itself random per call (`np.random.randint(int(N * ratio))`),
+    exactly as in the reference -- the cloud size then changes from step to step, which a captured hipGraph cannot
+    follow: use fixed_ratio=True (or max_num_points) together with `agent.enable_graphs()`.
+    Nothing is gathered: the index travels with the observation and the encoder reads point index[p] for position p."""
+
+    def __init__(self, main_key="inputs/xyz", req_keys=["input/xyz"], max_num_points=None, drop_ratio=None, fixed_ratio=True):
+        assert (drop_ratio is not None) ^ (max_num_points is not None)
+        self.main_key, self.req_keys = main_key, list(req_keys)
+        self.max_num_points, self.drop_ratio, self.fixed_ratio = max_num_points, drop_ratio, fixed_ratio
+        self.index_override = []       # parity tests queue explicit index tensors here
+
+    def __call__(self, data):
+        assert self.main_key in data, f"{self.main_key}, {list(data.keys())}"
+        point_keys = [k for k, v in data.items() if torch.is_tensor(v) and v.ndim == 3]
+        missing = [k for k in point_keys if k not in self.req_keys]
+        if missing:
+            raise NotImplementedError(f"RandomDownSample: point-cloud keys {missing} are not in req_keys {self.req_keys}; "
+                                      "the fused encoder reads every per-point key through the same index")
+        x = data[self.main_key]
+        N = x.shape[-1]
+        if self.drop_ratio is not None:
+            n_drop = int(N * self.drop_ratio) if self.fixed_ratio else int(np.random.randint(int(N * self.drop_ratio)))
+            k = N - n_drop
+        else:
+            k = min(self.max_num_points, N)
+        out = _as_augmented(data)
+        if self.index_override:
+            index = self.index_override.pop(0).to(device=x.device, dtype=torch.int32).contiguous()
+        elif k >= N:
+            return out
+        else:
+            index = torch.rand(N, device=x.device).argsort()[:k].to(torch.int32)
+        out.aug["point_index"] = index
+        return out
+
+    def __repr__(self):
+        if self.drop_ratio is not None:
+            return f"{type(self).__name__}(drop_ratio={self.drop_ratio}) (fixed_ratio={self.fixed_ratio})"
+        return f"{type(self).__name__}(max_num_points={self.max_num_points})"
+
+
 def batch_rot_with_axis(angle, rot_axis=2):
     """[.., 1] angles -> [.., 3, 3] rotations about `rot_axis` (reference pyrl/utils/torch/ops.py:171-183)."""
     assert angle.shape[-1] == 1

@@ -132,6 +132,7 @@ extern "C" int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t
     if (!xyz_in || !xyz_out || !aug) return fail(PCRL_E_ARG, "NULL argument");
     if (B < 0 || N < 1) return fail(PCRL_E_ARG, "bad shape");
     if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
+    if (aug->flags & PCRL_AUG_SUBSAMPLE) return fail(PCRL_E_ARG, "SUBSAMPLE is an index on the encoder's point load; slice the tensor for stand-alone use");
     if (B == 0) return PCRL_OK;
     AugParams p{xyz_in, xyz_out, B, N, aug->flags, aug->row_mul ? aug->row_mul : 1, aug->row_add, aug->jitter_lo, aug->jitter_hi,
                 aug->jitter_noise, aug->affine, aug->seed, aug->offset, reinterpret_cast<const unsigned long long*>(aug->offset_ptr)};

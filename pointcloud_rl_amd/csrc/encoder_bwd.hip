@@ -262,9 +262,6 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
             // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
             // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
-            // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
-            // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
-            // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
             unsigned long long own[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)wave);
@@ -274,7 +271,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch0 = acc_chan(mb * 16 + r, 0);
+#ifdef PCRL_ABLATE_POOL_BWD
+                    if (false) {
+#else
                     if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {      // channel ch0 or ch0 + 4 owned in this tile
+#endif
                         const int ch = ch0 + 4 * half;
                         const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
                         const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
@@ -301,7 +302,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 for (int r = 0; r < 16; ++r) {
                     const int ch0 = acc_chan(mb * 16 + r, 0);
                     float dz = __builtin_fmaf(a2[mb][r], cA, cB);
+#ifdef PCRL_ABLATE_POOL_BWD
+                    if (false) {
+#else
                     if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {
+#endif
                         const int ch = ch0 + 4 * half;
                         const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
                         const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);

@@ -25,6 +25,7 @@ struct CloudParams {
     const float* affine;
     unsigned long long seed, offset;
     const unsigned long long* offset_ptr;
+    const int* point_index;   // SUBSAMPLE: stored point of position n (N is then the subsampled count)
     ChanSrc ch[PCRL_MAX_CHANNELS];
 };
 
@@ -51,8 +52,9 @@ __device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, 
 template <int T0>
 __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc* s_desc, int b, int n) {
     f32x16 x;
+    const int n_src = p.point_index ? p.point_index[n] : n;
 #pragma unroll
-    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n) : 0.0f;
+    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n_src) : 0.0f;
     const long long row = (long long)b * p.row_mul + p.row_add;
     if (p.aug_flags & PCRL_AUG_AFFINE) {
         const float* M = p.affine + row * 12;

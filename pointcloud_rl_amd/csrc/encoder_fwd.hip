@@ -246,8 +246,14 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
     if (c != expect_channels) return fail(PCRL_E_ARG, "clouds carry %d channels, weights expect %d", c, expect_channels);
     p.C = c;
     if (aug && aug->flags) {
-        if (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32)
+        if ((aug->flags & (PCRL_AUG_JITTER | PCRL_AUG_AFFINE)) && (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32))
             return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
+        if (aug->flags & PCRL_AUG_SUBSAMPLE) {
+            if (!aug->point_index || aug->n_index < 1 || aug->n_index > clouds->N)
+                return fail(PCRL_E_ARG, "SUBSAMPLE needs point_index and 1 <= n_index <= N (got %d of %d)", aug->n_index, clouds->N);
+            p.point_index = aug->point_index;
+            p.N = aug->n_index;
+        }
         if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
         p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
         p.row_mul = aug->row_mul ? aug->row_mul : 1; p.row_add = aug->row_add;

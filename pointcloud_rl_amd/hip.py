@@ -128,7 +128,8 @@ def encoder_pack_weights(ew, packed):
     check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
 
 
-def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None):
+def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None,
+                  point_index=None):
     flags = 0
     aug = AugDesc()
     aug.row_mul, aug.row_add = int(row_mul), int(row_add)
@@ -144,6 +145,10 @@ def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine
     if affine is not None:
         flags |= _lib.AUG_AFFINE
         aug.affine = affine.data_ptr()
+    if point_index is not None:
+        assert point_index.dtype == torch.int32 and point_index.is_cuda and point_index.is_contiguous() and point_index.ndim == 1
+        flags |= _lib.AUG_SUBSAMPLE
+        aug.point_index, aug.n_index = point_index.data_ptr(), point_index.numel()
     aug.flags = flags
     return aug
 

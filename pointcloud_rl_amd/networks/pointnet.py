@@ -27,10 +27,13 @@ class AugmentedObs(dict):
 def materialize(obs):
     """Apply a pending augmentation of an AugmentedObs to its xyz tensor (for consumers other than the
     fused encoder, e.g. visualisation); returns a plain dict."""
-    aug = getattr(obs, "aug", None)
+    aug = dict(getattr(obs, "aug", None) or {})
     out = dict(obs)
+    index = aug.pop("point_index", None)
+    if index is not None:          # RandomDownSample: the same points of every key
+        out = {k: (v[..., index.long()] if torch.is_tensor(v) and v.ndim == 3 else v) for k, v in out.items()}
     if aug:
-        out["xyz"] = hip.augment_xyz(obs["xyz"].contiguous(), **aug)
+        out["xyz"] = hip.augment_xyz(out["xyz"].contiguous(), **aug)
     return out
 
 

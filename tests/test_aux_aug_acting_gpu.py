@@ -229,3 +229,61 @@ def test_policy_noise_in_kernel_is_standard_normal_and_advances(cuda):
     for e in draws:
         assert abs(e.mean()) < 0.03 and abs(e.std() - 1) < 0.03 and abs((e ** 3).mean()) < 0.08 and abs((e ** 4).mean() - 3) < 0.25
     assert abs(np.corrcoef(draws[0], draws[1])[0, 1]) < 0.03 and abs(np.corrcoef(draws[0], draws[2])[0, 1]) < 0.03
+
+
+def test_random_downsample_is_an_index_on_the_point_load(cuda):
+    """RandomDownSample (pcd_aug.py:231-268): encoding the stored cloud through the shared index equals encoding the
+    sliced tensors the reference would build -- forward bit for bit (argmax counts subsampled positions), backward too."""
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.augmentations import RandomDownSample
+    from pointcloud_rl_amd.networks.pointnet import materialize
+    B, N = 6, 300
+    obs = make_obs(B, N, seed=8, seg=1)
+    dobs = {k: torch.from_numpy(v).to(cuda) for k, v in obs.items()}
+    torch.manual_seed(5)
+    aug = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=True)
+    out = aug(dobs)
+    index = out.aug["point_index"]
+    assert index.dtype == torch.int32 and index.numel() == N - int(N * 0.3) and index.unique().numel() == index.numel()
+    sliced = materialize(out)
+    assert sliced["xyz"].shape == (B, 3, index.numel()) and torch.equal(sliced["rgb"], dobs["rgb"][..., index.long()])
+    w = make_encoder_weights(7, 128, 128, 256, seed=4)
+    wt = {k: torch.from_numpy(v).to(cuda) for k, v in w.items()}
+    ew, _ = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(7, 128, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    d1, k1 = hip.make_cloud_desc(dobs)
+    a1 = hip.make_aug_desc(**out.aug)
+    p1, i1 = hip.encoder_fwd(d1, ew, packed, aug=a1)
+    d2, k2 = hip.make_cloud_desc({k: v.contiguous() for k, v in sliced.items()})
+    p2, i2 = hip.encoder_fwd(d2, ew, packed)
+    assert torch.equal(p1, p2) and torch.equal(i1, i2) and int(i1.max()) < index.numel()
+    g = torch.randn_like(p1)
+    assert torch.equal(hip.encoder_bwd(d1, ew, packed, i1, g, aug=a1), hip.encoder_bwd(d2, ew, packed, i2, g))
+    # random drop count (fixed_ratio=False) and max_num_points variants
+    np.random.seed(0)
+    k_var = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=False)(dobs).aug["point_index"].numel()
+    assert N - int(N * 0.3) < k_var <= N
+    assert RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], max_num_points=100)(dobs).aug["point_index"].numel() == 100
+    with pytest.raises(NotImplementedError):
+        RandomDownSample(main_key="xyz", req_keys=["xyz"], max_num_points=100)(dobs)       # rgb / seg would keep all points
+    with pytest.raises(RuntimeError):
+        hip.encoder_fwd(d1, ew, packed, aug=hip.make_aug_desc(point_index=torch.zeros(N + 1, dtype=torch.int32, device=cuda)))
+
+
+def test_drq_step_with_random_downsample(cuda):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    cfg = configs.drq_dmc(6, 6, 8, head_hidden=64, obs_aug=dict(type="RandomDownSample", main_key="xyz", req_keys=["xyz", "rgb"],
+                                                                   drop_ratio=0.3, fixed_ratio=True))
+    cfg["env_params"] = configs.env_params({"xyz": [3, 128], "rgb": [3, 128]}, 6)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    agent.enable_graphs(warmup=1)
+    mem = SyntheticReplay(8, 128, 6, seed=2, device=cuda)
+    rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    assert agent._graphs and agent._fused is not None
+    losses = [r["drq/critic_loss"] for r in rets[4:]]
+    assert len(set(np.round(losses, 7))) == len(losses)        # every replay draws a new subset
