@@ -45,11 +45,24 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.check(-1)
 
 
-def test_struct_layouts_match_the_header():
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/pcrl.h as gcc lays it out == the ctypes mirror in _lib.py."""
+    import subprocess
     from pointcloud_rl_amd import _lib
-    # sizes the C compiler gives the structs of include/pcrl.h (LP64, natural alignment)
-    assert ctypes.sizeof(_lib.FeatSeg) == 48
-    assert ctypes.sizeof(_lib.CloudDesc) == 16 + 4 * 48
-    assert ctypes.sizeof(_lib.AugDesc) == 64
-    assert ctypes.sizeof(_lib.EncoderWeights) == 16 + 8 * 8 + 8
-    assert ctypes.sizeof(_lib.GemmDesc) == 5 * 8 + 4 * 4 + 11 * 8 + 4 * 4 + 8 + 8
+    pairs = [("pcrl_feat_seg", _lib.FeatSeg), ("pcrl_cloud_desc", _lib.CloudDesc), ("pcrl_aug_desc", _lib.AugDesc),
+             ("pcrl_encoder_weights", _lib.EncoderWeights), ("pcrl_gemm_desc", _lib.GemmDesc), ("pcrl_ln_job", _lib.LnJob),
+             ("pcrl_gather_seg", _lib.GatherSeg)]
+    lines = []
+    for cname, cls in pairs:
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pcrl.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
