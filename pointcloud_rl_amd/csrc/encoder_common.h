@@ -80,34 +80,41 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
     return x;
 }
 
+// Two accumulator registers at a time: gfx950's v_pk_{add,mul,fma}_f32 do two fp32 operations per VALU issue, and a
+// VALU issue costs the same FP32 ALU cycles as the MFMAs (tools/probes/mfma_valu_overlap.hip).  The element order of
+// the sums is unchanged (partial sums over registers r % 4, as in oracle/pcrl_oracle.c): results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PCRL_PAIR(v, r) (f32x2{(v)[(r)], (v)[(r) + 1]})
+
 template <int C>
 __device__ __forceinline__ float ln_center_rstd(f32x16 (&a)[C / 32], float eps, bool* var_is_nan) {
     // mean and variance in the canonical order (oracle/pcrl_oracle.c); `a` is replaced by a - mean.
     constexpr int MB = C / 32;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
-            p0 = p0 + a[mb][r + 0]; p1 = p1 + a[mb][r + 1];
-            p2 = p2 + a[mb][r + 2]; p3 = p3 + a[mb][r + 3];
+            p01 = p01 + PCRL_PAIR(a[mb], r);
+            p23 = p23 + PCRL_PAIR(a[mb], r + 2);
         }
     }
     float lo, hi;
-    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
     const float mean = (lo + hi) / (float)C;
-    p0 = p1 = p2 = p3 = 0.f;
+    const f32x2 mean2 = {mean, mean};
+    p01 = f32x2{0.f, 0.f}; p23 = f32x2{0.f, 0.f};
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
 #pragma unroll
         for (int r = 0; r < 16; r += 4) {
-            a[mb][r + 0] = a[mb][r + 0] - mean; a[mb][r + 1] = a[mb][r + 1] - mean;
-            a[mb][r + 2] = a[mb][r + 2] - mean; a[mb][r + 3] = a[mb][r + 3] - mean;
-            p0 = __builtin_fmaf(a[mb][r + 0], a[mb][r + 0], p0); p1 = __builtin_fmaf(a[mb][r + 1], a[mb][r + 1], p1);
-            p2 = __builtin_fmaf(a[mb][r + 2], a[mb][r + 2], p2); p3 = __builtin_fmaf(a[mb][r + 3], a[mb][r + 3], p3);
+            const f32x2 c01 = PCRL_PAIR(a[mb], r) - mean2, c23 = PCRL_PAIR(a[mb], r + 2) - mean2;
+            a[mb][r + 0] = c01[0]; a[mb][r + 1] = c01[1]; a[mb][r + 2] = c23[0]; a[mb][r + 3] = c23[1];
+            p01 = __builtin_elementwise_fma(c01, c01, p01);
+            p23 = __builtin_elementwise_fma(c23, c23, p23);
         }
     }
-    both_halves((p0 + p1) + (p2 + p3), lo, hi);
+    both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
     const float var = (lo + hi) / (float)C;
     *var_is_nan = var != var;
     return 1.0f / __builtin_sqrtf(var + eps);
@@ -115,15 +122,17 @@ __device__ __forceinline__ float ln_center_rstd(f32x16 (&a)[C / 32], float eps, 
 
 // Per-point LayerNorm (biased variance, eps inside the sqrt, affine) + ReLU on an accumulator
 // set (LayerNormkD.forward, reference pyrl/networks/modules/nn_layer.py:207-219).
+// s_ln holds, per channel pair (2j, 2j + 1), {gamma_2j, gamma_2j+1, beta_2j, beta_2j+1} (ln_pair_table).
 // Returns true for a point whose variance is NaN (all outputs NaN).
 template <int C, bool INT_RELU>
 __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
     constexpr int MB = C / 32;
     bool nan_pt;
     const float rstd = ln_center_rstd<C>(a, eps, &nan_pt);
+    const f32x2 rstd2 = {rstd, rstd};
     // gamma/beta of the 16 channels of a row block are fetched with 8 back-to-back 16-byte LDS reads
     // (one wait per block, the next block's reads already in flight) instead of a read + wait per pair.
-    const f32x4* s_gb = reinterpret_cast<const f32x4*>(s_ln);     // [channel pair] = {g0, b0, g1, b1}
+    const f32x4* s_gb = reinterpret_cast<const f32x4*>(s_ln);
     f32x4 gb[2][8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) gb[0][q] = s_gb[(acc_chan(2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
@@ -135,20 +144,31 @@ __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __
                 gb[(mb + 1) & 1][q] = s_gb[(acc_chan((mb + 1) * 16 + 2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // register r of the block: channel pair (r & 3) / 2 of quad r >> 2 -> gb slot q = (r >> 2) * 2 + ((r & 3) >> 1)
+        for (int r = 0; r < 16; r += 2) {
+            // registers r, r + 1 of the block: channel pair (r & 3) / 2 of quad r >> 2 -> gb slot q = (r >> 2) * 2 + ((r & 3) >> 1)
             const f32x4 g4 = gb[mb & 1][(r >> 2) * 2 + ((r & 3) >> 1)];
-            const float gam = (r & 1) ? g4[2] : g4[0], bet = (r & 1) ? g4[3] : g4[1];
-            const float y = __builtin_fmaf(a[mb][r] * rstd, gam, bet);
+            const f32x2 y = __builtin_elementwise_fma(PCRL_PAIR(a[mb], r) * rstd2, __builtin_shufflevector(g4, g4, 0, 1),
+                                                      __builtin_shufflevector(g4, g4, 2, 3));
+            const float y0 = y[0], y1 = y[1];
             if (INT_RELU) {
-                const int yi = __builtin_bit_cast(int, y);
-                a[mb][r] = __builtin_bit_cast(float, yi > 0 ? yi : 0);
+                const int i0 = __builtin_bit_cast(int, y0), i1 = __builtin_bit_cast(int, y1);
+                a[mb][r] = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+                a[mb][r + 1] = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
             } else {
-                a[mb][r] = relu_nan(y);
+                a[mb][r] = relu_nan(y0);
+                a[mb][r + 1] = relu_nan(y1);
             }
         }
     }
     return nan_pt;
+}
+
+// LDS image of a LayerNorm's affine parameters for ln_relu_acc from the packed image's [C][2] = (gamma, beta) rows.
+__device__ __forceinline__ void ln_pair_table(float* s_ln, const float* packed_ln, int C, int tid, int nthreads) {
+    for (int i = tid; i < 2 * C; i += nthreads) {
+        const int c = i >> 1, which = i & 1;             // packed_ln[i] = which ? beta_c : gamma_c
+        s_ln[4 * (c >> 1) + 2 * which + (c & 1)] = packed_ln[i];
+    }
 }
 
 // Streams the A operands of one dense layer through a register ring DEPTH groups deep: group g

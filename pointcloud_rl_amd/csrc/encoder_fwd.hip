@@ -54,8 +54,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
         for (int i = tid; i < C3 * C2 / 4; i += nthreads) s[i] = g[i];
         for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
-        for (int i = tid; i < 2 * C2; i += nthreads) s_ln1[i] = p.packed[L.ln1() + i];
-        for (int i = tid; i < 2 * C3; i += nthreads) s_ln2[i] = p.packed[L.ln2() + i];
+        ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
+        ln_pair_table(s_ln2, p.packed + L.ln2(), C3, tid, nthreads);
         if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
     }
     const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
