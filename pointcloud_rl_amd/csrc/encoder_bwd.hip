@@ -142,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        for (int i = tid; i < kC3 * kC2 / 4; i += 512) s[i] = g[i];
+        stage_to_lds<512, kC3 * kC2 / 4>(s, g, tid);
         for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
         for (int i = tid; i < 2 * kC2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     {   // prologue: weights -> LDS, once per workgroup
         const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        for (int i = tid; i < C3 * C2 / 4; i += nthreads) s[i] = g[i];
+        if (nthreads == 512) stage_to_lds<512, C3 * C2 / 4>(s, g, tid);
+        else for (int i = tid; i < C3 * C2 / 4; i += nthreads) s[i] = g[i];
         for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
         ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
