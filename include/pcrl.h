@@ -121,6 +121,15 @@ int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
                          const pcrl_encoder_weights* w, const void* packed,
                          float* pooled, int32_t* argmax,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* Mixed-precision forward (BASELINE.json config 3): conv1 and conv2 contract bf16 operands on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation -- weights rounded (RNE) once by pcrl_encoder_pack_weights_f32 into a second image, activations
+ * rounded as they are fed to the next layer; conv0 (raw coordinates), both LayerNorms, ReLU and the max-pool stay fp32.
+ * Same arguments and outputs as pcrl_encoder_fwd_f32; results differ from it by bf16 rounding (tests: |diff| <= 3e-2
+ * on O(1) outputs against a torch emulation of the same rounding points, argmax agreement >= 95 %). */
+int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug /* may be NULL */,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         float* pooled, int32_t* argmax,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Number of floats of the flat encoder gradient, laid out in the reference's parameter order
  * inside visual_nn.conv.mlp: conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias,

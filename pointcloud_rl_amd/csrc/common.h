@@ -47,11 +47,24 @@ struct PackedLayout {
     __host__ __device__ constexpr int ln2() const { return w2() + C3 * C2; }         // [C3][2]
     __host__ __device__ constexpr int w2t() const { return align4(ln2() + 2 * C3); } // [C2/32][C3/8][64][4]
     __host__ __device__ constexpr int w1t() const { return w2t() + C2 * C3; }        // [C1/32][C2/8][64][4]
-    __host__ __device__ constexpr int total() const { return align4(w1t() + C1 * C2); }
+    // bf16 images for the mixed-precision forward: [row block][16-channel group][64 lanes][8 bf16], two per float slot
+    __host__ __device__ constexpr int w1b() const { return align4(w1t() + C1 * C2); }    // conv1: C2 x C1 bf16
+    __host__ __device__ constexpr int w2b() const { return align4(w1b() + C1 * C2 / 2); } // conv2: C3 x C2 bf16
+    __host__ __device__ constexpr int total() const { return align4(w2b() + C2 * C3 / 2); }
     __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 bits, round to nearest even, NaN stays NaN (same rule as v_cvt_pk_bf16_f32 / torch.Tensor.bfloat16()).
+__host__ __device__ inline unsigned bf16_rne_bits(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
 
 // Buffer addressing: SGPR resource + one 32-bit VGPR byte offset + scalar/immediate offset.  Used
 // wherever a wave walks many constant-stride pieces of one array, so that no 64-bit VGPR address

@@ -83,7 +83,6 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
 // Two accumulator registers at a time: gfx950's v_pk_{add,mul,fma}_f32 do two fp32 operations per VALU issue, and a
 // VALU issue costs the same FP32 ALU cycles as the MFMAs (tools/probes/mfma_valu_overlap.hip).  The element order of
 // the sums is unchanged (partial sums over registers r % 4, as in oracle/pcrl_oracle.c): results are bit-identical.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PCRL_PAIR(v, r) (f32x2{(v)[(r)], (v)[(r) + 1]})
 
 template <int C>
@@ -237,6 +236,35 @@ __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load,
             acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, first ? zero : acc[mb], 0, 0, 0);
             acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, first ? zero : acc[mb + 1], 0, 0, 0);
         }
+    }
+}
+
+// Mixed-precision dense layer: acc[mb] (+)= W[32mb.., :] . act with bf16 operands on v_mfma_f32_32x32x16_bf16 and fp32
+// accumulation.  One MFMA contracts 16 input channels: the 8 accumulator registers 8g..8g+7 of BOTH wave halves, i.e.
+// channels acc_chan(8g + r, h) -- the weight image (PackedLayout::w1b/w2b) is packed in exactly that order, so the
+// activations still never leave registers: 8 fp32 registers -> 4 packed bf16 registers (v_cvt_pk_bf16_f32, RNE).
+// load(mb, g) -> 16 bytes = the 8 bf16 A operands of lane (i, h) for row block mb, channel group g; act(t) -> register t.
+template <int MB, int G, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_bf16(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    f32x4 w[2][MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) w[0][mb] = load(mb, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) w[(g + 1) & 1][mb] = load(mb, g + 1);
+        }
+        bf16x8 b;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const bf16x2 pr = __builtin_convertvector(f32x2{act(8 * g + r), act(8 * g + r + 1)}, bf16x2);
+            b[r] = pr[0]; b[r + 1] = pr[1];
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[g & 1][mb]), b, g == 0 ? zero : acc[mb], 0, 0, 0);
     }
 }
 

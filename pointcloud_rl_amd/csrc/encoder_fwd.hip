@@ -30,7 +30,9 @@ struct FwdParams {
     unsigned long long* partial;   // [B][S][C3] keys when S > 1
 };
 
-template <int T0, int C1, int C2, int C3>
+// BF16: conv1 / conv2 contract bf16 operands (weights rounded once by the pack kernel, activations rounded as they are
+// fed to the next layer) with fp32 accumulation; conv0, both LayerNorms and the max-pool are unchanged fp32 code.
+template <int T0, int C1, int C2, int C3, bool BF16>
 __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
     constexpr PackedLayout L{T0, C1, C2, C3};
     constexpr int MB1 = C1 / 32, MB2 = C2 / 32, MB3 = C3 / 32;
@@ -49,10 +51,11 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
 
     {   // prologue: weights -> LDS, once per workgroup
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        if (nthreads == 512) stage_to_lds<512, C3 * C2 / 4>(s, g, tid);
-        else for (int i = tid; i < C3 * C2 / 4; i += nthreads) s[i] = g[i];
+        constexpr int N16 = BF16 ? C3 * C2 / 8 : C3 * C2 / 4;
+        if (nthreads == 512) stage_to_lds<512, N16>(s, g, tid);
+        else for (int i = tid; i < N16; i += nthreads) s[i] = g[i];
         for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
         ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
@@ -99,16 +102,26 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
             // ---- conv1 + LN + ReLU --------------------------------------------------------
             f32x16 a1[MB2];
-            dense_layer_mfma<MB2, C1 / 8, 3>(
-                a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
-                [&](int t) { return a0[t >> 4][t & 15]; });
+            if (BF16)
+                dense_layer_bf16<MB2, C1 / 16>(
+                    a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, C1 / 8, 3>(
+                    a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
             ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
 
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
-            dense_layer_mfma<MB3, C2 / 8, 2>(
-                a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
-                [&](int t) { return a1[t >> 4][t & 15]; });
+            if (BF16)
+                dense_layer_bf16<MB3, C2 / 16>(
+                    a2, [&](int mb, int g) { return s_w2v[(mb * (C2 / 16) + g) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB3, C2 / 8, 2>(
+                    a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
             const bool nan_pt = ln_relu_acc<C3, true>(a2, s_ln2, half, p.eps);
             if (__builtin_expect(__ballot(nan_pt) != 0ull, 0)) {
                 // torch: a NaN wins the max and the first NaN's index is returned
@@ -220,6 +233,22 @@ __global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __res
         const int e = i - L.w1t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
         const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
         v = w.w1[acc_chan(4 * tq + j, ln >> 5) * w.c1 + 32 * mb + (ln & 31)];
+    } else if (i >= L.w1b() && i < L.w1b() + w.c1 * w.c2 / 2) {   // conv1, bf16: [mb][g][lane][8], two elements per slot
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w1b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c1 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
+        }
+        v = u2f(bits);
+    } else if (i >= L.w2b() && i < L.w2b() + w.c2 * w.c3 / 2) {   // conv2, bf16
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w2b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c2 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
+        }
+        v = u2f(bits);
     }
     out[i] = v;
 }
@@ -264,16 +293,16 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
     return PCRL_OK;
 }
 
-static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3) {
+static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 +
-           sizeof(float) * ((size_t)C3 * C2 + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
+           sizeof(float) * ((size_t)C3 * C2 / (bf16 ? 2 : 1) + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
 }
 
-template <int T0, int C1, int C2, int C3>
+template <int T0, int C1, int C2, int C3, bool BF16>
 static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
     static bool attr_set = false;
-    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3);
-    auto kern = encoder_fwd_kernel<T0, C1, C2, C3>;
+    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16);
+    auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16>;
     if (!attr_set) {
         PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -334,10 +363,10 @@ extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void
     return PCRL_OK;
 }
 
-extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
-                                    const pcrl_encoder_weights* w, const void* packed,
-                                    float* pooled, int32_t* argmax,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+static int encoder_fwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                            const pcrl_encoder_weights* w, const void* packed,
+                            float* pooled, int32_t* argmax,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (!clouds || !w || !packed || !pooled || !argmax) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
@@ -357,7 +386,7 @@ extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
     hipStream_t st = (hipStream_t)stream;
     int rc = PCRL_E_ARG;
 #define PCRL_FWD_CASE(T0_, C1_)                                                   \
-    if (T0 == T0_ && w->c1 == C1_) rc = launch_fwd<T0_, C1_, 128, 256>(p, grid, st);
+    if (T0 == T0_ && w->c1 == C1_) rc = bf16 ? launch_fwd<T0_, C1_, 128, 256, true>(p, grid, st) : launch_fwd<T0_, C1_, 128, 256, false>(p, grid, st);
     PCRL_FWD_CASE(2, 64) PCRL_FWD_CASE(3, 64) PCRL_FWD_CASE(4, 64) PCRL_FWD_CASE(5, 64)
     PCRL_FWD_CASE(2, 128) PCRL_FWD_CASE(3, 128) PCRL_FWD_CASE(4, 128) PCRL_FWD_CASE(5, 128)
 #undef PCRL_FWD_CASE
@@ -370,4 +399,18 @@ extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
         PCRL_CHECK_LAUNCH("encoder_merge_kernel");
     }
     return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                    const pcrl_encoder_weights* w, const void* packed,
+                                    float* pooled, int32_t* argmax,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(false, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                     const pcrl_encoder_weights* w, const void* packed,
+                                     float* pooled, int32_t* argmax,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(true, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
 }

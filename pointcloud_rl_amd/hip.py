@@ -153,8 +153,9 @@ def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine
     return aug
 
 
-def encoder_fwd(desc, ew, packed, aug=None, workspace=None):
-    """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device)."""
+def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False):
+    """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device).  bf16=True: conv1 / conv2 on
+    the bf16 matrix cores with fp32 accumulation (pcrl_encoder_fwd_bf16)."""
     B, c3 = desc.B, ew.c3
     dev = packed.device
     pooled = torch.empty((B, c3), dtype=torch.float32, device=dev)
@@ -165,7 +166,8 @@ def encoder_fwd(desc, ew, packed, aug=None, workspace=None):
     if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
         workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
     with _span("encoder_fwd"):
-        check(lib().pcrl_encoder_fwd_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
+        fn = lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
+        check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
                                          ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
                                          _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
     return pooled, argmax

@@ -9,7 +9,7 @@ from pointcloud_rl_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256); ap.add_argument("--N", type=int, default=1024)
 ap.add_argument("--c1", type=int, default=64); ap.add_argument("--seg", type=int, default=0)
-ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 obs_np = make_obs(a.B, a.N, seed=1, seg=a.seg)
@@ -20,11 +20,11 @@ packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4
 hip.encoder_pack_weights(ew, packed)
 obs = {k: torch.from_numpy(v).to(dev) for k, v in obs_np.items()}
 desc, keep = hip.make_cloud_desc(obs)
-for _ in range(5): hip.encoder_fwd(desc, ew, packed)
+for _ in range(5): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(a.iters): hip.encoder_fwd(desc, ew, packed)
+for _ in range(a.iters): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 flop = 2.0 * (C * a.c1 + a.c1 * 128 + 128 * 256) * a.B * a.N
