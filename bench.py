@@ -29,6 +29,9 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (B, N, pcd channels extras, action_dim, agent_dim, config builder)
     "k1": dict(B=256, N=1024, A=6, S=0, obs_kw={}, cfg="sac_dmc", desc="SAC PointNet, synthetic replay B=256 N=1024 C=6 (BASELINE config 2)"),
+    "k2": dict(B=256, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="drq_maniskill_bf16",
+               desc="DrQ pn_jitter, PointNet [128,128,256], B=256 x 2 augmentations, N=1200 C=7, jitter fused into the encoder load, "
+                    "bf16 conv1/conv2 with fp32 accumulate (BASELINE config 3)"),
     "k3": dict(B=1024, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="sac_maniskill",
                desc="SAC PointNet, ManiSkill shape B=1024 N=1200 C=7 (BASELINE config 4)"),
 }
@@ -60,6 +63,8 @@ def build_agent(wl, batch_per_rank, device):
     C = 6 + wl["obs_kw"].get("seg", 0) + wl["obs_kw"].get("pos_encoding", 0)
     if wl["cfg"] == "sac_dmc":
         cfg = configs.sac_dmc(C, wl["A"], batch_per_rank)
+    elif wl["cfg"] == "drq_maniskill_bf16":
+        cfg = configs.drq_maniskill(C, wl["A"], wl["S"], batch_per_rank, encoder_dtype="bf16")
     else:
         cfg = configs.sac_maniskill(C, wl["A"], wl["S"], batch_per_rank)
     obs_shape = {"xyz": [3, wl["N"]], "rgb": [3, wl["N"]]}
@@ -185,8 +190,13 @@ def main():
         f_pt = 2.0 * (C * agent.encoder.mlp_spec[0] + agent.encoder.mlp_spec[0] * agent.encoder.mlp_spec[1] +
                       agent.encoder.mlp_spec[1] * agent.encoder.mlp_spec[2])
         # the launches of one step have different cloud counts only for DrQ; for SAC every launch encodes b_rank clouds
-        flops_per_launch = f_pt * b_rank * wl["N"]
+        is_bf16 = getattr(agent.encoder, "compute_dtype", "f32") == "bf16"
+        num_aug = getattr(agent, "num_aug", 1)
+        # clouds per encoder launch, averaged over a step's 2.5 launches: SAC b; DrQ: s' and s on b*num_aug clouds, the actor pass on b
+        clouds_per_launch = b_rank * (2 * num_aug + 0.5) / 2.5
+        flops_per_launch = f_pt * clouds_per_launch * wl["N"]
         achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
+        peak = 2500.0 if is_bf16 else 157.3        # dense MFMA peaks of MI355X_MICROARCH.md (bf16 / fp32)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
         if os.path.exists(tpath) and not args.batch and world == 1:
@@ -198,18 +208,18 @@ def main():
             "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
             "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if getattr(agent.encoder, "compute_dtype", "f32") == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
                        "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
-            "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": b_rank * wl["N"] * (12 + 3 + (C - 6)) + 8 * b_rank * agent.encoder.mlp_spec[2], "launches": n_fwd, "avg_launch_ms": ms_fwd,
+            "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * agent.encoder.mlp_spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
                          "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
                          "algorithmic_flops_per_launch": flops_per_launch},
             "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
             out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps)
         print(json.dumps(out))
     if world > 1:

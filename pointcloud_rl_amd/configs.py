@@ -84,9 +84,11 @@ def drq_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, obs_
     return cfg
 
 
-def drq_maniskill(pcd_channels=7, action_dim=22, agent_dim=68, batch_size=256, head_hidden=1024, obs_aug=JITTER, num_aug=2):
-    """configs/mfrl/drq/maniskill/{base/pn_base.py, pn_jitter.py}"""
+def drq_maniskill(pcd_channels=7, action_dim=22, agent_dim=68, batch_size=256, head_hidden=1024, obs_aug=JITTER, num_aug=2,
+                  encoder_dtype="f32"):
+    """configs/mfrl/drq/maniskill/{base/pn_base.py, pn_jitter.py}; encoder_dtype="bf16" = BASELINE.json config 3."""
     cfg = _agent_cfg("DrQ", MANISKILL_NETS, pcd_channels, action_dim, agent_dim, batch_size, 0.95, head_hidden,
                      dict(num_aug=num_aug, svea=False, obs_aug=dict(obs_aug) if obs_aug else None))
     cfg["actor_cfg"]["nn_cfg"]["mlp_cfg"]["zero_out_indices"] = slice(action_dim, None, None)
+    cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"]["compute_dtype"] = encoder_dtype
     return cfg

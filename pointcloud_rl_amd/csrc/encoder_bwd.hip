@@ -116,7 +116,10 @@ __host__ __device__ constexpr unsigned op_off(int arr_floats, int mb, int r) {
     return 4u * (unsigned)(arr_floats + mb * 32 * kPiece + ((r & 3) + 8 * (r >> 2)) * 4);
 }
 
-template <int T0, int C1>
+// BF16: the forward recompute contracts bf16 operands exactly as encoder_fwd_kernel<.., true> does (so that the LayerNorm
+// inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`); the gradient GEMMs stay fp32
+// against the fp32 master weights (straight-through for the roundings).
+template <int T0, int C1, bool BF16>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + L.w2());
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        stage_to_lds<512, kC3 * kC2 / 4>(s, g, tid);
+        stage_to_lds<512, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
         for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
         for (int i = tid; i < 2 * kC2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
@@ -235,9 +238,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
-            dense_layer_mfma<MB2, C1 / 8, 3>(
-                a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
-                [&](int t) { return a0[t >> 4][t & 15]; });
+            if (BF16)
+                dense_layer_bf16<MB2, C1 / 16>(
+                    a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, C1 / 8, 3>(
+                    a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
             const float rstd1 = ln_to_xhat<kC2>(a1, p.eps);
 #pragma unroll
             for (int mb = 0; mb < MB2; ++mb) {
@@ -253,9 +261,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
-            dense_layer_mfma<MB3, kC2 / 8, 2>(
-                a2, [&](int mb, int tq) { return s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane]; },
-                [&](int t) { return a1[t >> 4][t & 15]; });
+            if (BF16)
+                dense_layer_bf16<MB3, kC2 / 16>(
+                    a2, [&](int mb, int g) { return s_w2v[(mb * (kC2 / 16) + g) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB3, kC2 / 8, 2>(
+                    a2, [&](int mb, int tq) { return s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
             const float rstd2 = ln_to_xhat<kC3>(a2, p.eps);
 
             // ---- max-pool + ReLU + LN2 backward ----------------------------------------------------
@@ -502,11 +515,11 @@ static size_t bwd_lds_bytes(int T0, int C1) {
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + (size_t)kC3 * kC2);
 }
 
-template <int T0, int C1>
+template <int T0, int C1, bool BF16>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
     static bool attr_set = false;
     const size_t lds = bwd_lds_bytes(T0, C1);
-    auto kern = encoder_bwd_points_kernel<T0, C1>;
+    auto kern = encoder_bwd_points_kernel<T0, C1, BF16>;
     if (!attr_set) {
         PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -554,11 +567,11 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     return PCRL_OK;
 }
 
-extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
-                                    const pcrl_encoder_weights* w, const void* packed,
-                                    const int32_t* argmax, const float* grad_pooled,
-                                    float* grads, int32_t* n_active,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
+static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                            const pcrl_encoder_weights* w, const void* packed,
+                            const int32_t* argmax, const float* grad_pooled,
+                            float* grads, int32_t* n_active,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     if (!clouds || !w || !packed || !argmax || !grad_pooled || !grads) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
@@ -582,7 +595,7 @@ extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
     const int T0 = (p.cl.C + 1) / 2;
     int rc = PCRL_E_ARG;
 #define PCRL_BWD_CASE(T0_, C1_) \
-    if (T0 == T0_ && w->c1 == C1_) rc = launch_bwd<T0_, C1_>(p, grid, st);
+    if (T0 == T0_ && w->c1 == C1_) rc = bf16 ? launch_bwd<T0_, C1_, true>(p, grid, st) : launch_bwd<T0_, C1_, false>(p, grid, st);
     PCRL_BWD_CASE(2, 64) PCRL_BWD_CASE(3, 64) PCRL_BWD_CASE(4, 64) PCRL_BWD_CASE(5, 64)
     PCRL_BWD_CASE(2, 128) PCRL_BWD_CASE(3, 128) PCRL_BWD_CASE(4, 128) PCRL_BWD_CASE(5, 128)
 #undef PCRL_BWD_CASE
@@ -593,4 +606,20 @@ extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
     PCRL_CHECK_LAUNCH("encoder_bwd_reduce_kernel");
     if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
     return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                    const pcrl_encoder_weights* w, const void* packed,
+                                    const int32_t* argmax, const float* grad_pooled,
+                                    float* grads, int32_t* n_active,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_bwd_impl(false, clouds, aug, w, packed, argmax, grad_pooled, grads, n_active, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                     const pcrl_encoder_weights* w, const void* packed,
+                                     const int32_t* argmax, const float* grad_pooled,
+                                     float* grads, int32_t* n_active,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_bwd_impl(true, clouds, aug, w, packed, argmax, grad_pooled, grads, n_active, workspace, workspace_bytes, stream);
 }

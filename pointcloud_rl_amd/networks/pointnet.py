@@ -63,7 +63,7 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, net, desc, keep, aug, *weights):
         ew, packed = net._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
-        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=net._workspace("fwd"))
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=net._workspace("fwd"), bf16=net.compute_dtype == "bf16")
         ctx.net, ctx.desc, ctx.keep, ctx.aug_desc, ctx.aug = net, desc, keep, aug_desc, aug
         ctx.ew, ctx.packed = ew, packed
         ctx.save_for_backward(argmax)
@@ -76,7 +76,7 @@ class _EncoderFn(torch.autograd.Function):
         (argmax,) = ctx.saved_tensors
         net = ctx.net
         flat, n_active = hip.encoder_bwd(ctx.desc, ctx.ew, ctx.packed, argmax, grad_pooled, aug=ctx.aug_desc,
-                                         workspace=net._workspace("bwd", ctx.desc.B), want_n_active=True)
+                                         workspace=net._workspace("bwd", ctx.desc.B), want_n_active=True, bf16=net.compute_dtype == "bf16")
         net.last_n_active = n_active
         views = hip.encoder_grad_views(flat, ctx.ew)
         return (None, None, None, None) + tuple(views[k] for k in ("conv0.weight", "conv0.bias", "conv1.weight", "norm1.weight",
@@ -86,8 +86,14 @@ class _EncoderFn(torch.autograd.Function):
 @NETWORK.register_module()
 class PointNet(ExtendedModule):
     def __init__(self, feat_dim, mlp_spec=[64, 128, 1024], out_channels=None, global_feat=True, feature_transform=[1],
-                 norm_cfg=dict(type="LN1d", eps=1e-6), act_cfg=dict(type="ReLU"), ignore_first_ln=False, num_patch=1, **kwargs):
+                 norm_cfg=dict(type="LN1d", eps=1e-6), act_cfg=dict(type="ReLU"), ignore_first_ln=False, num_patch=1,
+                 compute_dtype="f32", **kwargs):
         super().__init__()
+        # compute_dtype (not a reference keyword): "bf16" runs conv1 / conv2 of the per-point MLP on the bf16 matrix cores
+        # with fp32 accumulation, fp32 master weights and fp32 gradient GEMMs (BASELINE.json config 3); "f32" is exact.
+        if compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         # The fused kernel implements the configuration every shipped point-cloud SAC/DrQ config uses
         # (configs/mfrl/{sac,drq}/*/pn*.py): no T-Nets, LN1d + ReLU, first LayerNorm dropped.
         if len(feature_transform) > 0:
@@ -162,13 +168,14 @@ class PointNet(ExtendedModule):
         desc, keep = hip.make_cloud_desc(inputs)
         ew, packed = self._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
-        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"))
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16")
         return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed)
 
     def backward_raw(self, ctx, argmax, grad_pooled, out):
         """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
         desc, keep, aug, aug_desc, ew, packed = ctx
-        hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out)
+        hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out,
+                        bf16=self.compute_dtype == "bf16")
 
     def forward(self, inputs, object_feature=True, concat_state=None, **kwargs):
         feature, _ = self.pooled(inputs)

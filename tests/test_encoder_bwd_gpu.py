@@ -108,3 +108,48 @@ def test_bwd_is_deterministic_and_linear(cuda):
     ref, _, _ = torch_reference_grads(obs_s, w, g1[sel])
     got, _, _, _ = hip_grads(obs_s, w, g1[sel], cuda)
     assert_grads_close(got, ref)
+
+
+def _bf16_reference_grads(obs_np, w_np, gpool_np, eps=1e-6):
+    """Autograd through the rounding emulation of the mixed-precision forward, roundings straight-through."""
+    import torch.nn.functional as F
+    from oracle import c_oracle
+    x = torch.from_numpy(c_oracle.preprocess(obs_np))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in w_np.items()}
+    st = lambda a: a + (a.to(torch.bfloat16).to(torch.float32) - a).detach()
+    h0 = F.relu(torch.einsum("oc,bcn->bon", t["w0"], x) + t["b0"][None, :, None])
+    z1 = torch.einsum("oc,bcn->bon", st(t["w1"]), st(h0))
+    h1 = F.relu(F.layer_norm(z1.permute(0, 2, 1), (z1.shape[1],), t["g1"], t["be1"], eps).permute(0, 2, 1))
+    z2 = torch.einsum("oc,bcn->bon", st(t["w2"]), st(h1))
+    h2 = F.relu(F.layer_norm(z2.permute(0, 2, 1), (z2.shape[1],), t["g2"], t["be2"], eps).permute(0, 2, 1))
+    return t, h2
+
+
+@pytest.mark.parametrize("B,N,extra,c1", [(3, 200, dict(), 64), (2, 1200, dict(seg=1), 128)])
+def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, c1):
+    """Mixed-precision backward: gradients w.r.t. the fp32 master weights of the function the bf16 forward computes.
+    The kernel's own argmax is used to pick the pooled points of the emulation (a rounding tie may move an argmax, which
+    is a different -- equally valid -- subgradient).  Tolerance: 3e-2 of each tensor's largest gradient entry."""
+    from pointcloud_rl_amd import hip
+    obs = make_obs(B, N, seed=23, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, c1, 128, 256, seed=6)
+    gpool = np.random.RandomState(N).randn(B, 256).astype(np.float32)
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda) for k, v in w.items()}
+    ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep = hip.make_cloud_desc({k: torch.from_numpy(v).to(cuda) for k, v in obs.items()})
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=True)
+    flat = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True)
+    got = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
+    t, h2 = _bf16_reference_grads(obs, w, gpool)
+    picked = torch.gather(h2, 2, argmax.cpu().long()[:, :, None])[:, :, 0]
+    np.testing.assert_allclose(pooled.cpu().numpy(), picked.detach().numpy(), atol=3e-2, rtol=0)
+    (picked * torch.from_numpy(gpool)).sum().backward()
+    for name, k in NAMES.items():
+        g, r = got[name].reshape(-1), t[k].grad.numpy().reshape(-1)
+        scale = max(np.abs(r).max(), 1e-6)
+        assert np.abs(g - r).max() / scale < 3e-2, f"{name}: {np.abs(g - r).max() / scale:.3e}"
+    # bitwise reproducible
+    assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True))

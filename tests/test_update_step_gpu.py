@@ -140,3 +140,42 @@ def test_graph_replay_matches_eager(cuda):
             assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
     for n in p_eager:
         assert torch.allclose(p_eager[n], p_graph[n], atol=1e-6, rtol=0), n
+
+
+def test_drq_mixed_precision_step_tracks_the_fp32_step(cuda):
+    """BASELINE config 3 (DrQ, jitter, bf16 encoder): same batch, same injected policy / jitter noise -- the bf16 agent's
+    losses stay within 5e-2 (relative) of the fp32 agent's over a few updates; parameters: Adam moves an entry by at most lr
+    per step whatever the gradient's size, so an entry whose tiny gradient changes sign under bf16 rounding can end up
+    2 * lr * steps = 8e-3 away -- the bound on the worst entry -- while the mean distance stays below 3e-4.  The
+    graph-replayed step runs."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A, S = 8, 160, 5, 7
+    agents = {}
+    for dt in ("f32", "bf16"):
+        cfg = configs.drq_maniskill(7, A, S, B, head_hidden=64, encoder_dtype=dt)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N], "seg": [1, N], "agent": S}, A)
+        torch.manual_seed(0)
+        agents[dt] = build_agent(cfg).to(cuda)
+    assert agents["bf16"].encoder.compute_dtype == "bf16" and agents["f32"].encoder.compute_dtype == "f32"
+    mem = SyntheticReplay(B, N, A, seed=4, device=cuda, seg=1, agent=S)
+    g = torch.Generator().manual_seed(7)
+    rets = {"f32": [], "bf16": []}
+    for u in range(1, 5):
+        eps = [torch.randn(2 * B, A, generator=g), torch.randn(B, A, generator=g)]
+        jit = [torch.empty(2 * B, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)]
+        for dt, agent in agents.items():
+            agent.actor.head.noise_override = [e.to(cuda) for e in eps][:2 if u % 2 == 0 else 1]
+            agent.obs_aug[0].noise_override = [j.to(cuda) for j in jit]
+            rets[dt].append(agent.update_parameters(mem, u))
+    for a, b in zip(rets["f32"], rets["bf16"]):
+        for k in ("drq/critic_loss", "drq/q", "drq/q_target"):
+            assert abs(a[k] - b[k]) <= 5e-2 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    pa, pb = dict(agents["f32"].named_parameters()), dict(agents["bf16"].named_parameters())
+    diffs = torch.cat([(pa[n].detach() - pb[n].detach()).abs().reshape(-1) for n in pa])
+    assert 0 < float(diffs.max()) <= 8.5e-3 and float(diffs.mean()) < 3e-4, (float(diffs.max()), float(diffs.mean()))
+    bf = agents["bf16"]
+    bf.enable_graphs(warmup=1)
+    more = [bf.update_parameters(mem, u) for u in range(5, 11)]
+    assert bf._graphs and all(np.isfinite(list(r.values())).all() for r in more)

@@ -31,16 +31,16 @@ flop = 2.0 * (C * a.c1 + a.c1 * 128 + 128 * 256) * a.B * a.N
 print(f"encoder_fwd B={a.B} N={a.N} C={C} c1={a.c1}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s ({flop/ms/1e9/157.3*100:.1f}% of 157.3 fp32 MFMA peak)")
 
 # ---- backward (sparse exact backward through the max-pool) ----
-pooled, argmax = hip.encoder_fwd(desc, ew, packed)
+pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
 gp = torch.randn_like(pooled)
 import ctypes
 need = ctypes.c_size_t()
 hip.check(hip.lib().pcrl_encoder_bwd_workspace_bytes(a.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
 ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
 out = torch.empty(hip.encoder_num_grads(ew), device=dev)
-for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out)
+for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16)
 torch.cuda.synchronize()
 e0.record()
-for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out)
+for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16)
 e1.record(); torch.cuda.synchronize()
 print(f"encoder_bwd B={a.B} N={a.N}: {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us (points + wgrad + reduce kernels)")
