@@ -150,8 +150,10 @@ int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
                          float* grads, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of pcrl_encoder_fwd_bf16: the forward of the active points is recomputed with the same bf16 contractions (so
- * LayerNorm inputs, ReLU masks and argmax relations are the forward's), the gradient GEMMs run in fp32 against the fp32
- * master weights (the roundings are treated as identity: straight-through).  `argmax` must come from the bf16 forward. */
+ * LayerNorm inputs, ReLU masks and argmax relations are the forward's) and the two data-gradient GEMMs contract bf16 too
+ * (gradients rounded as they enter, fp32 accumulate); the weight-gradient GEMMs are fp32 on the unrounded operands and the
+ * result is the gradient w.r.t. the fp32 master weights (roundings straight-through).  `argmax` must come from the bf16
+ * forward. */
 int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
                          const int32_t* argmax, const float* grad_pooled,

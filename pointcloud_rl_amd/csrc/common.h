@@ -50,7 +50,9 @@ struct PackedLayout {
     // bf16 images for the mixed-precision forward: [row block][16-channel group][64 lanes][8 bf16], two per float slot
     __host__ __device__ constexpr int w1b() const { return align4(w1t() + C1 * C2); }    // conv1: C2 x C1 bf16
     __host__ __device__ constexpr int w2b() const { return align4(w1b() + C1 * C2 / 2); } // conv2: C3 x C2 bf16
-    __host__ __device__ constexpr int total() const { return align4(w2b() + C2 * C3 / 2); }
+    __host__ __device__ constexpr int w2tb() const { return align4(w2b() + C2 * C3 / 2); } // conv2 transposed: C2 rows x C3 k, bf16
+    __host__ __device__ constexpr int w1tb() const { return align4(w2tb() + C2 * C3 / 2); } // conv1 transposed: C1 rows x C2 k, bf16
+    __host__ __device__ constexpr int total() const { return align4(w1tb() + C1 * C2 / 2); }
     __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
 };
 

@@ -117,8 +117,9 @@ __host__ __device__ constexpr unsigned op_off(int arr_floats, int mb, int r) {
 }
 
 // BF16: the forward recompute contracts bf16 operands exactly as encoder_fwd_kernel<.., true> does (so that the LayerNorm
-// inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`); the gradient GEMMs stay fp32
-// against the fp32 master weights (straight-through for the roundings).
+// inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`) and so do the two data-gradient
+// GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
+// through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
 template <int T0, int C1, bool BF16>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
@@ -332,9 +333,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
-            dense_layer_mfma<MB2, kC3 / 8, 3>(
-                d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
-                [&](int t) { return a2[t >> 4][t & 15]; });
+            if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
+                dense_layer_bf16<MB2, kC3 / 16>(
+                    d1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2tb() + (mb * (kC3 / 16) + g) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, kC3 / 8, 3>(
+                    d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
             f32x16 xh1[MB2];
             s1 = 0.0f; s2 = 0.0f;
 #pragma unroll
@@ -380,9 +386,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
-            dense_layer_mfma<MB1, kC2 / 8, 3>(
-                d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
-                [&](int t) { return d1[t >> 4][t & 15]; });
+            if (BF16)
+                dense_layer_bf16<MB1, kC2 / 16>(
+                    d0, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1tb() + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB1, kC2 / 8, 3>(
+                    d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
 #pragma unroll
             for (int mb = 0; mb < MB1; ++mb)
 #pragma unroll

@@ -249,6 +249,22 @@ __global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __res
             bits |= bf16_rne_bits(w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
         }
         v = u2f(bits);
+    } else if (i >= L.w2tb() && i < L.w2tb() + w.c2 * w.c3 / 2) {  // conv2 transposed, bf16: rows = c2, k = c3
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w2tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c3 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w2[acc_chan(8 * g + r, ln >> 5) * w.c2 + 32 * mb + (ln & 31)]) << (16 * k);
+        }
+        v = u2f(bits);
+    } else if (i >= L.w1tb() && i < L.w1tb() + w.c1 * w.c2 / 2) {  // conv1 transposed, bf16: rows = c1, k = c2
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w1tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c2 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w1[acc_chan(8 * g + r, ln >> 5) * w.c1 + 32 * mb + (ln & 31)]) << (16 * k);
+        }
+        v = u2f(bits);
     }
     out[i] = v;
 }
