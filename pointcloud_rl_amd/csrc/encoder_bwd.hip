@@ -421,11 +421,23 @@ __device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, const 
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const f32x4* a4 = reinterpret_cast<const f32x4*>(A) + (long long)mb * 32 * 64 + lane;
     const f32x4* b4 = reinterpret_cast<const f32x4*>(Bm) + lane;
+    // the operands of octet q + 1 are in flight while the 4 * NB MFMAs of octet q issue
+    f32x4 a_nxt = {0.f, 0.f, 0.f, 0.f}, b_nxt[NB];
+    if (n_oct > 0) {
+        a_nxt = a4[0];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) b_nxt[n] = b4[((nb0 + n) * 32) * 64];
+    }
     for (int q = 0; q < n_oct; ++q) {
-        const f32x4 a = a4[q * 64];
+        const f32x4 a = a_nxt;
         f32x4 bv[NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bv[n] = b4[((nb0 + n) * 32 + q) * 64];
+        for (int n = 0; n < NB; ++n) bv[n] = b_nxt[n];
+        if (q + 1 < n_oct) {
+            a_nxt = a4[(q + 1) * 64];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) b_nxt[n] = b4[((nb0 + n) * 32 + q + 1) * 64];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
