@@ -170,12 +170,17 @@ int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* au
  *   can be replayed from a hipGraph; grad_norm_out (device float, optional) <- ||g||_2;
  *   target (optional): for target_begin <= i < target_end,
  *   target[i - target_begin] <- (1 - tau) * target[..] + tau * param_new[i]. */
+/* A pass whose second half (sum of the per-block partial sums of grad^2 -> grad_norm_out, step_counter += 1) has been
+ * deferred: filled by pcrl_adam_step_f32 when defer_finalize != NULL and handed to pcrl_gather_scalars_f32 at the end of
+ * the step, which saves one dependent launch per optimizer per step.  Until then the step counter still holds the
+ * number of COMPLETED steps, and the workspace must stay untouched. */
+typedef struct pcrl_adam_pending { const float* partial; int32_t n_partial, _pad; float* grad_norm_out; int32_t* step_counter; } pcrl_adam_pending;
 int pcrl_adam_workspace_bytes(size_t n, size_t* bytes);
 int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                        float lr, float beta1, float beta2, float eps, float grad_scale,
                        int32_t* step_counter, float* grad_norm_out,
                        float* target, size_t target_begin, size_t target_end, float tau,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream);
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 
@@ -293,8 +298,10 @@ int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32
                               uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream);
 
 /* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
- * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196). */
-int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n, void* stream);
+ * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196).  Up to 4 deferred optimizer
+ * passes (pcrl_adam_pending) are finished first, so their gradient norms can be among the gathered scalars. */
+int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                            const pcrl_adam_pending* pending, int32_t n_pending, void* stream);
 
 #ifdef __cplusplus
 }

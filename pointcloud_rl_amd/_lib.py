@@ -41,6 +41,11 @@ class EncoderWeights(ctypes.Structure):
                 ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
 
 
+class AdamPending(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("n_partial", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("grad_norm_out", ctypes.c_void_p), ("step_counter", ctypes.c_void_p)]
+
+
 class LnJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
                 ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),

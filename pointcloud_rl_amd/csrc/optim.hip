@@ -127,7 +127,7 @@ extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_av
                                   float lr, float beta1, float beta2, float eps, float grad_scale,
                                   int32_t* step_counter, float* grad_norm_out,
                                   float* target, size_t target_begin, size_t target_end, float tau,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return fail(PCRL_E_ARG, "NULL argument");
     if (n == 0) return PCRL_OK;
     if (target && !(target_begin <= target_end && target_end <= n)) return fail(PCRL_E_ARG, "bad Polyak range");
@@ -138,6 +138,11 @@ extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_av
                  target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace)};
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p);
     PCRL_CHECK_LAUNCH("adam_kernel");
+    if (defer_finalize) {       // the caller's end-of-step pcrl_gather_scalars_f32 launch sums the partials and advances the step count
+        defer_finalize->partial = p.partial; defer_finalize->n_partial = grid;
+        defer_finalize->grad_norm_out = grad_norm_out; defer_finalize->step_counter = step_counter;
+        return PCRL_OK;
+    }
     hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, p.partial, grid, grad_norm_out, step_counter);
     PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
     return PCRL_OK;

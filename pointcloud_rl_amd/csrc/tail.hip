@@ -200,10 +200,33 @@ __global__ __launch_bounds__(1024) void actor_loss_kernel(const ActorLossParams 
 }
 
 // The scalars a step reports (losses, gradient norms, alpha = exp(log_alpha)) gathered into one array
-// with one launch, instead of one tiny copy / exp / stack launch each.
+// with one launch, instead of one tiny copy / exp / stack launch each.  The same launch can finish up to
+// four deferred optimizer passes (pcrl_adam_step_f32 with defer_finalize): gradient norm = sqrt of the fixed-order
+// sum of the pass's per-block partial sums, step count += 1 -- before the scalars are copied, so a norm can be one
+// of them.
 constexpr int kMaxScalars = 16;
-struct ScalarListParams { const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n; };
-__global__ void gather_scalars_kernel(const ScalarListParams p) {
+constexpr int kMaxFinalize = 4;
+struct ScalarListParams {
+    const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n;
+    const float* partial[kMaxFinalize]; int n_partial[kMaxFinalize]; float* norm[kMaxFinalize]; int* step[kMaxFinalize]; int n_fin;
+};
+__global__ __launch_bounds__(256) void gather_scalars_kernel(const ScalarListParams p) {
+    __shared__ float s_part[4];
+    for (int f = 0; f < p.n_fin; ++f) {
+        // thread t sums partial[t], partial[t + 256], ... then a fixed-order tree (the order gradnorm_finalize_kernel uses)
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < p.n_partial[f]; i += 256) s += p.partial[f][i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (p.norm[f]) p.norm[f][0] = __builtin_sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+            p.step[f][0] += 1;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
     const int i = threadIdx.x;
     if (i < p.n) {
         const float v = p.src[i][0];
@@ -215,9 +238,12 @@ __global__ void gather_scalars_kernel(const ScalarListParams p) {
 
 using namespace pcrl;
 
-extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n, void* stream) {
-    if (!src || !dst || n < 0 || n > kMaxScalars) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
-    if (n == 0) return PCRL_OK;
+extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                                       const pcrl_adam_pending* pending, int32_t n_pending, void* stream) {
+    if (n < 0 || n > kMaxScalars || (n > 0 && (!src || !dst))) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
+    if (n_pending < 0 || n_pending > kMaxFinalize || (n_pending > 0 && !pending))
+        return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n_pending <= %d", kMaxFinalize);
+    if (n == 0 && n_pending == 0) return PCRL_OK;
     ScalarListParams p{};
     for (int i = 0; i < n; ++i) {
         if (!src[i] || !dst[i]) return fail(PCRL_E_ARG, "NULL scalar pointer");
@@ -225,7 +251,13 @@ extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* ds
         if (take_exp && take_exp[i]) p.exp_mask |= 1u << i;
     }
     p.n = n;
-    hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    for (int f = 0; f < n_pending; ++f) {
+        if (!pending[f].partial || !pending[f].step_counter || pending[f].n_partial < 1) return fail(PCRL_E_ARG, "bad pending optimizer pass %d", f);
+        p.partial[f] = pending[f].partial; p.n_partial[f] = pending[f].n_partial;
+        p.norm[f] = pending[f].grad_norm_out; p.step[f] = pending[f].step_counter;
+    }
+    p.n_fin = n_pending;
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("gather_scalars_kernel");
     return PCRL_OK;
 }

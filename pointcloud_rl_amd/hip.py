@@ -223,13 +223,18 @@ def adam_workspace_bytes(n):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, workspace,
-              target=None, target_begin=0, target_end=0, tau=0.0):
+              target=None, target_begin=0, target_end=0, tau=0.0, defer=False):
+    """defer=True: returns an AdamPending that must be passed to gather_scalars(..., pending=[...]) later in the step (it sums
+    the gradient norm and advances the step count); otherwise a second launch does that right away and None is returned."""
+    pending = _lib.AdamPending() if defer else None
     with _span("adam_step"):
         check(lib().pcrl_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
                                        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
                                        ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(grad_norm_out),
                                        _ptr(target), ctypes.c_size_t(target_begin), ctypes.c_size_t(target_end), ctypes.c_float(tau),
-                                       _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
+                                       _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()),
+                                       ctypes.byref(pending) if defer else None, _stream()))
+    return pending
 
 
 def polyak(target, src, tau):
@@ -364,13 +369,15 @@ def replay_sample_gather(segs, B, size, capacity, seed, draw, idx_out=None):
                                               ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(draw), _ptr(idx_out), _stream()))
 
 
-def gather_scalars(entries):
-    """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars."""
+def gather_scalars(entries, pending=()):
+    """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars;
+    pending: AdamPending objects of deferred adam_step calls, finished by the same launch before the copies."""
     n = len(entries)
+    pend = (_lib.AdamPending * max(len(pending), 1))(*pending)
     src = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
     dst = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries])
     flags = (ctypes.c_int32 * n)(*[int(bool(e[2])) for e in entries])
-    check(lib().pcrl_gather_scalars_f32(src, dst, flags, n, _stream()))
+    check(lib().pcrl_gather_scalars_f32(src, dst, flags, n, pend, len(pending), _stream()))
 
 
 # ---- stand-alone memory-shaped kernels --------------------------------------------------------------

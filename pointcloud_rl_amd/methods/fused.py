@@ -275,7 +275,8 @@ class FusedStep:
                         hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
         scale = yield [fc.grad]
-        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak)
+        pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
+        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)
         enc.invalidate_packed()
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
 
@@ -305,8 +306,8 @@ class FusedStep:
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
             scale = yield ([fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
-            stats["actor_grad"] = a._optim_step("actor", scale)
-            a._optim_step("alpha", scale if a.sync_alpha else 1.0)
+            stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
+            a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
         # one launch gathers every reported scalar (and alpha = exp(log_alpha), sac.py:196) into one array
         names = list(stats.keys())
@@ -314,7 +315,7 @@ class FusedStep:
         entries = [(a.log_alpha, out[i:], True) if k == "new_alpha" else (stats[k], out[i:], False) for i, k in enumerate(names)]
         if "new_alpha" in stats:
             entries.append((a.log_alpha, a._alpha_t, True))
-        hip.gather_scalars(entries)
+        hip.gather_scalars(entries, pending=pending)
         packed = PackedStats((k, out[i]) for i, k in enumerate(names))
         packed.packed = out[:len(names)]
         return packed

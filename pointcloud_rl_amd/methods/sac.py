@@ -88,11 +88,12 @@ class HipAdam:
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
-    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0):
+    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False):
+        """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...)."""
         g = self.param_groups[0]
-        hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
-                      g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
-                      target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau)
+        return hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
+                             g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
+                             target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer)
 
     def _views(self, flat_tensor):
         return self.flat.views(flat_tensor)
@@ -224,14 +225,18 @@ class SAC(BaseAgent):
         """Sum the flat gradient over the ranks (RCCL); the 1/world factor is applied by the optimizer kernel."""
         return allreduce_sum_(tensor, enabled=self._be_data_parallel)
 
-    def _optim_step(self, name, scale, polyak=False):
+    def _optim_step(self, name, scale, polyak=False, pending=None):
+        """pending: a list -> the optimizer's second half (gradient norm, step count) is deferred and appended to it."""
         opt = getattr(self, f"{name}_optim")
         fb = self._flat[name]
         if isinstance(opt, HipAdam):
+            defer = pending is not None
             if polyak and self._target_flat is not None:
-                opt.step(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau)
+                pend = opt.step(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau, defer=defer)
             else:
-                opt.step(scale)
+                pend = opt.step(scale, defer=defer)
+            if defer:
+                pending.append(pend)
             return opt.grad_norm.reshape(())
         if scale != 1.0:
             fb.grad.mul_(scale)

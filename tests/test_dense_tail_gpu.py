@@ -194,3 +194,36 @@ def test_layernorm_rows_multi_job_with_pass_through_columns(cuda):
     hip.layernorm_rows_fwd_multi(jobs, G, Bt, Fd, 1e-5)
     for job, want in zip(jobs, wants):
         np.testing.assert_allclose(job["keep"][3].cpu().numpy(), want, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["finalize-now", "finalize-in-gather"])
+def test_fused_adam_polyak_gradnorm_matches_torch(cuda, defer):
+    """pcrl_adam_step_f32 == torch.optim.Adam (+ soft_update on a parameter range, + grad 2-norm, + device step count),
+    with the pass's second half either launched right away or deferred into pcrl_gather_scalars_f32."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(2)
+    n, t0, t1, tau = 10_007, 4_000, 10_007, 0.01
+    w0 = g.randn(n).astype(np.float32)
+    p_ref = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = torch.optim.Adam([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    tgt_ref = torch.from_numpy(g.randn(t1 - t0).astype(np.float32))
+    P, M, V = T(w0, cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    TG = tgt_ref.clone().to(cuda)
+    step, norm = torch.zeros(1, dtype=torch.int32, device=cuda), torch.zeros(1, device=cuda)
+    ws = torch.empty(hip.adam_workspace_bytes(n), dtype=torch.uint8, device=cuda)
+    seen = torch.zeros(2, device=cuda)
+    for it in range(3):
+        grad = g.randn(n).astype(np.float32) * (10.0 ** -it)
+        p_ref.grad = torch.from_numpy(grad * 0.5)
+        opt.step()
+        tgt_ref = tgt_ref * (1 - tau) + p_ref.detach()[t0:t1] * tau
+        pend = hip.adam_step(P, T(grad, cuda), M, V, 1e-3, 0.9, 0.999, 1e-8, 0.5, step, norm, ws, target=TG, target_begin=t0,
+                             target_end=t1, tau=tau, defer=defer)
+        if defer:
+            assert pend is not None and int(step.item()) == it         # the count advances only when the pass is finished
+            hip.gather_scalars([(norm, seen[0:], False), (P[5:], seen[1:], True)], pending=[pend])
+            assert abs(float(seen[0]) - float(norm)) == 0 and abs(float(seen[1]) - np.exp(float(P[5]))) < 1e-6
+        assert int(step.item()) == it + 1
+        np.testing.assert_allclose(float(norm), np.linalg.norm(grad * 0.5), rtol=1e-5)
+        np.testing.assert_allclose(P.cpu().numpy(), p_ref.detach().numpy(), atol=2e-6, rtol=0)
+        np.testing.assert_allclose(TG.cpu().numpy(), tgt_ref.numpy(), atol=2e-6, rtol=0)
