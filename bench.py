@@ -48,8 +48,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-process path with several ranks on one GPU)")
-    ap.add_argument("--replay", default="device", choices=["device", "fixed"], help="device: sample every step from a device-resident "
-                    "ring of synthetic transitions; fixed: the same resident batch every step")
+    ap.add_argument("--replay", default="device", choices=["device", "fixed", "host"], help="device: sample every step from a device-resident "
+                    "ring of synthetic transitions; fixed: the same resident batch every step; host: the batch comes from pinned host "
+                    "memory every step (PCIe-inclusive rate, reported in DESIGN.md, never the headline value)")
     ap.add_argument("--replay-capacity", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=0, help="analysis only: override the global batch size (the JSON line then is NOT the "
                     "BASELINE metric; used to look at the per-GPU share of a multi-GPU run on one GPU)")
@@ -136,6 +137,16 @@ def main():
         memory = DeviceReplay(args.replay_capacity, device=device, seed=1 + rank)
         for lo in range(0, args.replay_capacity, 512):
             memory.push_batch(make_batch_np(min(512, args.replay_capacity - lo), wl["N"], wl["A"], seed=1 + 1000 * rank + lo, agent=wl["S"], **wl["obs_kw"]))
+    elif args.replay == "host":
+        # the reference's arrangement: the sampled batch sits in host memory and crosses PCIe inside update_parameters
+        # (`memory.sample(...).to_torch(device=..., non_blocking=True)`, sac.py:104); pinned here, pageable in the reference
+        full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
+        from pointcloud_rl_amd.utils.dist import shard_slice
+        sl = shard_slice(wl["B"], rank, world)
+        pin = lambda a: torch.from_numpy(a[sl].copy()).pin_memory()
+        memory = SyntheticReplay.__new__(SyntheticReplay)
+        memory.batch_np = None
+        memory.batch = {k: ({kk: pin(vv) for kk, vv in v.items()} if isinstance(v, dict) else pin(v)) for k, v in full.batch_np.items()}
     else:
         # one fixed batch: every rank generates the global batch with the same seed and keeps its shard resident in HBM
         full = SyntheticReplay(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
