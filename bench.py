@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--workload", default="k1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the cpu_baseline leg (0: every CPU the box grants this process; the "
+                    "reference ships torch.set_num_threads(1), pyrl/utils/meta/__init__.py:38-49)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-process path with several ranks on one GPU)")
     ap.add_argument("--replay", default="device", choices=["device", "fixed", "host"], help="device: sample every step from a device-resident "
@@ -74,7 +76,20 @@ def build_agent(wl, batch_per_rank, device):
     return _build(cfg).to(device), C
 
 
-def cpu_baseline(agent, wl, steps):
+def usable_cpus():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box shows 256 logical
+    CPUs but grants e.g. cpu.max = 1600000/100000 = 16; torch's default of 128 threads on 16 CPUs only adds contention)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(agent, wl, steps, threads=0):
     """The reference's update step restated op for op (six encoder passes, permute LayerNorm, per-tensor
     Adam groups), timed on the host: 1 warm-up + `steps` timed steps of the full B=256 batch."""
     from oracle import torch_ref
@@ -86,6 +101,7 @@ def cpu_baseline(agent, wl, steps):
                              update_coeff=agent.update_coeff["default"], mirror_redundancy=True)
     batch = make_batch_np(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
     tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch.items()}
+    torch.set_num_threads(threads if threads else usable_cpus())
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
     eps = lambda: [torch.randn(wl["B"], wl["A"], generator=g), torch.randn(wl["B"], wl["A"], generator=g)]
@@ -95,7 +111,8 @@ def cpu_baseline(agent, wl, steps):
         ref.update_parameters(tb, u, eps())
     dt = (time.perf_counter() - t0) / steps
     return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full update steps (B={wl['B']}, N={wl['N']}) after 1 warm-up, torch {torch.__version__} CPU, {cores} threads"}
+            "sample": f"{steps} full update steps (B={wl['B']}, N={wl['N']}) after 1 warm-up, torch {torch.__version__} CPU, {cores} threads "
+                      f"(box grants {usable_cpus()} of {os.cpu_count()} logical CPUs)"}
 
 
 def main():
@@ -231,7 +248,7 @@ def main():
             "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
         }
         if world == 1 and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
-            out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
