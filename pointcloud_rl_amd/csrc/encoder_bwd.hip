@@ -412,21 +412,23 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 
 // ---- kernel B: per-cloud weight-gradient GEMMs ------------------------------------------------
 // out[32 x 32 block (mb, nb)] = sum over slots of A[32mb + i][slot] * Bm[32nb + j][slot]
-template <int NB>
-__device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, const float* __restrict__ Bm, int mb, int nb0,
+// b_block_stride: distance between two column blocks of the B operand in 16-byte units (32 * 64 in the global workspace,
+// n_oct * 64 in the compact LDS copy).
+template <int NB, class BPtr>
+__device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, BPtr b4_base, int b_block_stride, int mb, int nb0,
                                              int n_oct, int lane, f32x16 (&acc)[NB]) {
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const f32x4* a4 = reinterpret_cast<const f32x4*>(A) + (long long)mb * 32 * 64 + lane;
-    const f32x4* b4 = reinterpret_cast<const f32x4*>(Bm) + lane;
+    const auto b4 = b4_base + lane;
     // the operands of octet q + 1 are in flight while the 4 * NB MFMAs of octet q issue
     f32x4 a_nxt = {0.f, 0.f, 0.f, 0.f}, b_nxt[NB];
     if (n_oct > 0) {
         a_nxt = a4[0];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) b_nxt[n] = b4[((nb0 + n) * 32) * 64];
+        for (int n = 0; n < NB; ++n) b_nxt[n] = b4[(nb0 + n) * b_block_stride];
     }
     for (int q = 0; q < n_oct; ++q) {
         const f32x4 a = a_nxt;
@@ -436,7 +438,7 @@ __device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, const 
         if (q + 1 < n_oct) {
             a_nxt = a4[(q + 1) * 64];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) b_nxt[n] = b4[((nb0 + n) * 32 + q + 1) * 64];
+            for (int n = 0; n < NB; ++n) b_nxt[n] = b4[(nb0 + n) * b_block_stride + (q + 1) * 64];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -461,14 +463,24 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
     constexpr int MB1 = C1 / 32;
     constexpr OpsLayout OL{MB1};
     const GradLayout GL{p.cl.C, C1};
+    extern __shared__ __attribute__((aligned(16))) f32x4 s_h1[];      // [4][n_oct][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x) {
         const float* ops = p.ops + (long long)b * OL.total();
         float* pw = p.pw + (long long)b * GL.total();
         const int n_oct = ((p.n_act[b] + 31) / 32) * 4;
-        {   // conv2.weight [256][128]: wave w owns row block w, all 4 column blocks
+        {   // conv2.weight [256][128]: wave w owns row block w, all 4 column blocks.  Every wave contracts against the whole
+            // of h1, so the cloud's h1 operand (4 blocks x n_oct KB) is staged in LDS once instead of being fetched from L2
+            // by each of the 8 waves.
+            __syncthreads();
+            const f32x4* h1g = reinterpret_cast<const f32x4*>(ops + OL.h1());
+            for (int i = tid; i < 4 * n_oct * 64; i += 512) {
+                const int nb = i / (n_oct * 64), r = i - nb * (n_oct * 64);
+                s_h1[i] = h1g[nb * 32 * 64 + r];
+            }
+            __syncthreads();
             f32x16 acc[4];
-            wgrad_blocks<4>(ops + OL.dz2(), ops + OL.h1(), wave, 0, n_oct, lane, acc);
+            wgrad_blocks<4>(ops + OL.dz2(), (const f32x4*)s_h1, n_oct * 64, wave, 0, n_oct, lane, acc);
 #pragma unroll
             for (int n = 0; n < 4; ++n) store_tile(pw + GL.w2(), kC2, wave, n, kC2, acc[n], lane);
         }
@@ -476,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
             constexpr int NB = MB1 / 2;     // column blocks per wave (1 or 2)
             f32x16 acc[NB];
             const int mb = wave >> 1, nb0 = (wave & 1) * NB;
-            wgrad_blocks<NB>(ops + OL.dz1(), ops + OL.h0(), mb, nb0, n_oct, lane, acc);
+            wgrad_blocks<NB>(ops + OL.dz1(), reinterpret_cast<const f32x4*>(ops + OL.h0()), 32 * 64, mb, nb0, n_oct, lane, acc);
 #pragma unroll
             for (int n = 0; n < NB; ++n) store_tile(pw + GL.w1(), C1, mb, nb0 + n, C1, acc[n], lane);
         }
@@ -549,7 +561,14 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
-    hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid), dim3(512), 0, stream, p);
+    constexpr size_t wgrad_lds = 4 * 32 * 64 * sizeof(f32x4);        // h1 operand of one cloud: 128 KB at 256 active points
+    static bool wgrad_attr_set = false;
+    if (!wgrad_attr_set) {
+        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bwd_wgrad_kernel<C1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)wgrad_lds));
+        wgrad_attr_set = true;
+    }
+    hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid), dim3(512), wgrad_lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_wgrad_kernel");
     return PCRL_OK;
 }
