@@ -58,8 +58,13 @@ def _span(name):
     return TIMER.span(name) if TIMER is not None else _NoSpan()
 
 
+def raw_stream():
+    """hipStream_t of torch's current stream as an int (the C calls skip the torch.cuda.Stream object: ~8 us -> < 1 us)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def _ptr(t):

@@ -429,7 +429,10 @@ class SAC(BaseAgent):
             for t in exchange:
                 allreduce_sum_(t)
         if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
-            torch.cuda.current_stream().synchronize()
+            stream = self.__dict__.get("_sync_stream")
+            if stream is None or stream.cuda_stream != hip.raw_stream():
+                stream = self.__dict__["_sync_stream"] = torch.cuda.current_stream()
+            stream.synchronize()
             return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
         return self._finish(dict(zip(names, out.unbind(0))), updates)
 
