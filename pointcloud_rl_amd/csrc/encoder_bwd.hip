@@ -140,7 +140,8 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     float* s_b0 = s_ln2 + 2 * kC3;
     float* s_w0 = s_b0 + C1;
     float* s_red = s_w0 + MB1 * T0 * 64;                                          // [8][kC2][2]
-    float* s_w2 = s_red + 8 * kC2 * 2;
+    float2* s_dgb = reinterpret_cast<float2*>(s_red + 8 * kC2 * 2);               // [256] norm2 (dgamma, dbeta), left by the owning lane
+    float* s_w2 = reinterpret_cast<float*>(s_dgb + kC3);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -295,10 +296,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                         const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
                         const bool mine = (unsigned)s_slot[ch] == s_match;
                         const float dyl = (mine && y > 0.0f) ? s_g[ch] : 0.0f;
-                        if (mine) {                                     // exactly one point per channel contributes
-                            pw[GL.g2() + ch] = dyl * a2[mb][r];
-                            pw[GL.be2() + ch] = dyl;
-                        }
+                        // exactly one point per channel contributes; the pair goes to LDS (a global store here needs the
+                        // spilled base address back and with it a wait for every store in flight) and out after the tiles
+                        if (mine) s_dgb[ch] = float2{dyl * a2[mb][r], dyl};
                         const float dx = dyl * gb.x;
                         s1 = s1 + dx;
                         s2 = __builtin_fmaf(dx, a2[mb][r], s2);
@@ -406,6 +406,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             float acc = 0.0f;
             for (int w = 0; w < 8; ++w) acc = acc + s_red[(w * kC2 + ch) * 2 + which];
             pw[(which ? GL.be1() : GL.g1()) + ch] = acc;
+        }
+        if (tid < kC3) {       // norm2 gradients: every channel was written by the lane holding its argmax point
+            const float2 d = s_dgb[tid];
+            pw[GL.g2() + tid] = d.x;
+            pw[GL.be2() + tid] = d.y;
         }
     }
 }
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* _
 
 static size_t bwd_lds_bytes(int T0, int C1) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kSlots + 16 + kC3 + 4 * (size_t)kC3 +
-           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + (size_t)kC3 * kC2);
+           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + (size_t)kC3 * kC2);
 }
 
 template <int T0, int C1, bool BF16>
