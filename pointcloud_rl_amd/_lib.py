@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcrl_hip.so")
+LIB_PATH = os.environ.get("PCRL_HIP_LIB") or os.path.join(_HERE, "libpcrl_hip.so")     # env override: A/B builds during kernel work
 
 PCRL_MAX_SEG = 4
 PCRL_MAX_CHANNELS = 16
