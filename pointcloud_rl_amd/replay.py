@@ -6,7 +6,8 @@ OneStepTransition's uniform with-replacement sampling (pyrl/env/sampling_strateg
 `np_random.randint(0, len, batch_size)`), but the ring lives in HBM: `sample()` is ONE HIP launch that
 draws the B row numbers (Philox keyed by the buffer's seed and the sample-call count; with
 `host_rng=True` they come from numpy's RandomState exactly as in the reference and are shipped as B
-int32) and gathers every key into a persistent staging batch.  The staging tensors keep their addresses from call to
+int32; `with_replacement=False` walks a shuffled epoch order the same way) and gathers every key into a
+persistent staging batch.  The staging tensors keep their addresses from call to
 call, so an agent replaying its update step from a hipGraph reads them in place -- no per-step
 numpy gather, no pageable host->device copy of 2*B point clouds, no copy into graph inputs.
 
@@ -51,8 +52,9 @@ class DeviceReplay:
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("DeviceReplay keeps the ring in MI355X HBM: device must be a CUDA/HIP device")
+        self.with_replacement = bool(with_replacement)
         if not with_replacement:
-            raise NotImplementedError("DeviceReplay implements OneStepTransition with_replacement=True (every shipped SAC/DrQ config)")
+            host_rng = True            # the shuffled epoch order is drawn on the host exactly as the reference draws it
         self.capacity, self.device = int(capacity), device
         self.seed = np.random.randint(0, 2 ** 32 - 1) if seed is None else seed
         self.np_random = np.random.RandomState(self.seed)          # sampling_strategy.py:18-19
@@ -61,6 +63,7 @@ class DeviceReplay:
         self._staging = {}             # batch_size -> (flat key -> tensor [B, ...], nested mapping, idx device, pinned idx x2)
         self._flip = 0
         self.host_rng, self.draws = host_rng, 0
+        self.items, self.item_index, self.need_update = None, 0, False    # without-replacement state (sampling_strategy.py:21-24)
 
     # -- ring ------------------------------------------------------------------------------------------
     def __len__(self):
@@ -68,6 +71,7 @@ class DeviceReplay:
 
     def reset(self):
         self.position = self.running_count = 0
+        self.items, self.item_index = None, 0
 
     def _as_tensor(self, v):
         t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
@@ -92,6 +96,7 @@ class DeviceReplay:
                 self.storage[k][:n - first].copy_(v[first:])
         self.running_count += n
         self.position = (self.position + n) % self.capacity
+        self.need_update = True                              # OneStepTransition.push_batch (sampling_strategy.py:80-83)
 
     def get_all(self):
         return self._nest({k: v[:len(self)] for k, v in self.storage.items()})
@@ -124,18 +129,43 @@ class DeviceReplay:
             self._staging[batch_size] = (flat, _DeviceSample(self._nest(flat)), idx, pinned, segs)
         return self._staging[batch_size]
 
-    def sample_indices(self, batch_size):
-        return self.np_random.randint(low=0, high=len(self), size=batch_size)                        # sampling_strategy.py:30-31
+    def sample_indices(self, batch_size, drop_last=True, auto_restart=True):
+        """SamplingStrategy.get_index (sampling_strategy.py:26-48): uniform with replacement, or consecutive slices of a
+        shuffled epoch order that is re-drawn after a push or when exhausted (None when exhausted and not auto_restart)."""
+        capacity = len(self)
+        if self.with_replacement:
+            return self.np_random.randint(low=0, high=capacity, size=batch_size)
+        if self.items is None or self.need_update:
+            self.need_update = False
+            self.items = np.arange(capacity)
+            self.np_random.shuffle(self.items)
+            self.item_index = 0
+        min_query_size = batch_size if drop_last else 1
+        if self.item_index + min_query_size > capacity:
+            if not auto_restart:
+                return None
+            self.np_random.shuffle(self.items)
+            self.item_index = 0
+        else:
+            batch_size = min(batch_size, capacity - self.item_index)
+        index = self.items[self.item_index:self.item_index + batch_size]
+        self.item_index += batch_size
+        return index
 
     def sample(self, batch_size, auto_restart=True, drop_last=True):
         size = len(self)
         if size == 0:
             raise RuntimeError("sampling from an empty replay buffer")
+        if self.host_rng:
+            index = self.sample_indices(batch_size, drop_last, auto_restart)
+            if index is None:
+                return None
+            batch_size = len(index)                     # a short last batch when drop_last is False
         flat, sample, idx, pinned, segs = self._stage(batch_size)
         if self.host_rng:
             host = pinned[self._flip]
             self._flip ^= 1
-            host.numpy()[:] = self.sample_indices(batch_size)
+            host.numpy()[:] = index
             idx.copy_(host, non_blocking=True)
             hip.replay_gather(segs, idx, self.capacity)
         else:

@@ -287,3 +287,26 @@ def test_drq_step_with_random_downsample(cuda):
     assert agent._graphs and agent._fused is not None
     losses = [r["drq/critic_loss"] for r in rets[4:]]
     assert len(set(np.round(losses, 7))) == len(losses)        # every replay draws a new subset
+
+
+def test_device_replay_without_replacement_walks_the_reference_epoch_order(cuda):
+    """with_replacement=False: the index stream equals SamplingStrategy.get_index's (sampling_strategy.py:32-48) for the same
+    seed -- shuffled epoch order, re-shuffled when exhausted, re-drawn after a push -- and every epoch visits each row once."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A, B = 24, 16, 3, 5
+    mem = DeviceReplay(cap, device=cuda, seed=3, with_replacement=False)
+    mem.push_batch(make_batch_np(cap, N, A, seed=1))
+    rs = np.random.RandomState(3)
+    items = np.arange(cap); rs.shuffle(items); pos = 0
+    seen = []
+    for _ in range(9):                      # 4 batches per epoch (drop_last), then a re-shuffle
+        if pos + B > cap:
+            rs.shuffle(items); pos = 0
+        want = items[pos:pos + B]; pos += B
+        batch = mem.sample(B).to_torch(device=cuda)
+        np.testing.assert_array_equal(mem.last_indices(B).cpu().numpy(), want)
+        np.testing.assert_array_equal(batch["rewards"].cpu().numpy(), mem.storage["rewards"].cpu().numpy()[want])
+        seen.append(want)
+    assert len(np.unique(np.concatenate(seen[:4]))) == 4 * B
+    assert mem.sample(cap + 1, auto_restart=False) is None      # cannot be served without a restart
