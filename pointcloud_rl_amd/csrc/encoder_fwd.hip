@@ -135,34 +135,59 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             // ---- symmetric max-pool with first-index argmax --------------------------------
             // lanes past N hold a copy of point N - 1 and report that index, so no validity test is needed below
             const unsigned inv_idx = ~(unsigned)pc;
+            if (tile == t_begin + wave) {
+                // The wave's first tile of this cloud segment: the keys hold (almost) nothing yet, so reduce across the 32
+                // lanes first and let only the winner of each half touch the key.
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb) {
-                // 16 independent reductions advance together: each DPP step of one register fills the
-                // wait states of the others, and the 16 conditional key updates are issued back to back.
-                unsigned m[16];
+                for (int mb = 0; mb < MB3; ++mb) {
+                    // 16 independent reductions advance together: each DPP step of one register fills the
+                    // wait states of the others, and the 16 conditional key updates are issued back to back.
+                    unsigned m[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = f2u(a2[mb][r]);
+                    for (int r = 0; r < 16; ++r) m[r] = f2u(a2[mb][r]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0xB1>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0xB1>(m[r]));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x4E>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x4E>(m[r]));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x141>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x141>(m[r]));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x140>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x140>(m[r]));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
-                    // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.  max(.., 1):
-                    // a zero maximum matches no lane (nobody reports it: the key's initial value already says so)
-                    m[r] = umax_(umax_(sw[0], sw[1]), 1u);
+                    for (int r = 0; r < 16; ++r) {
+                        auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
+                        // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.  max(.., 1):
+                        // a zero maximum matches no lane (nobody reports it: the key's initial value already says so)
+                        m[r] = umax_(umax_(sw[0], sw[1]), 1u);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned v = f2u(a2[mb][r]);
+                        if (v == m[r]) {
+                            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                            atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                        }
+                    }
                 }
+            } else {
+                // Later tiles: a point can only matter if it reaches the value already in the channel's key (which only
+                // grows, so a stale read errs on the safe side; equality passes for the first-index rule).  That is rare
+                // -- the k-th tile of a cloud holds the running maximum with probability ~1/k -- so the cross-lane
+                // reduction is skipped and the few qualifying lanes update the key themselves: one LDS read and two
+                // compares per register instead of four DPP steps, a lane swap and three more instructions.
+                const unsigned* s_key_hi = reinterpret_cast<const unsigned*>(s_keys) + 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned v = f2u(a2[mb][r]);
-                    if (v == m[r]) {
-                        const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-                        atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                for (int mb = 0; mb < MB3; ++mb) {
+                    unsigned cur[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[r] = s_key_hi[2 * (acc_chan(mb * 16 + r, 0) + 4 * half)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned v = f2u(a2[mb][r]);
+                        if (v >= umax_(cur[r], 1u)) {
+                            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                            atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                        }
                     }
                 }
             }
