@@ -94,3 +94,26 @@ def test_segmented_graph_replay_keeps_replicas_identical(cuda):
     for n in p0:
         assert torch.equal(p0[n], p1[n]), n
         assert torch.isfinite(p0[n]).all()
+
+
+def test_bench_two_ranks_prints_the_contract_line(cuda):
+    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, one rank per GPU), here with two ranks sharing the
+    test box's GPU over gloo: rank 0 prints exactly one JSON line with the contract's keys, strong scaling at global B=256."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--replay-capacity", "512"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 128
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3 * 1e3
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
