@@ -188,9 +188,13 @@ class SAC(BaseAgent):
         }
         self._flat["alpha"] = FlatBuffer([("log_alpha", self.log_alpha)])
         for name in ("critic", "actor", "alpha"):      # torch.optim.Adam (one group per tensor) -> one fused launch
-            hp = _plain_adam(getattr(self, f"{name}_optim"))
+            old = getattr(self, f"{name}_optim")
+            hp = _plain_adam(old)
             if hp is not None:
-                setattr(self, f"{name}_optim", HipAdam(self._flat[name], **hp))
+                fused = HipAdam(self._flat[name], **hp)
+                if old.state:                          # a checkpoint was loaded before the first update: keep moments and step
+                    fused.load_state_dict(old.state_dict())
+                setattr(self, f"{name}_optim", fused)
         # Polyak: the target's own (non-shared) parameters mirror a tail range of the critic buffer
         online = {id(p) for p in self.critic.parameters()}
         tgt = [(n, p) for n, p in self.target_critic.named_parameters() if id(p) not in online]

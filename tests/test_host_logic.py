@@ -212,3 +212,56 @@ def test_tanh_gaussian_head_matches_restatement():
     assert torch.allclose(a, a_ref) and torch.allclose(nlp, nlp_ref)
     assert torch.allclose(head(feat, mode="eval"), torch.tanh(feat[:, :6]) * head.scale + head.bias)
     assert head(feat, mode="explore").shape == (5, 6)
+
+
+def test_checkpoint_roundtrip_in_the_reference_format(tmp_path):
+    """save_checkpoint / load_checkpoint (pyrl/utils/torch/checkpoint_utils.py:25-96,148-179,215-269): optimizers travel under
+    their attribute names inside state_dict, tensors are on the CPU, loading is non-strict and adapts a one-dimension mismatch."""
+    import torch
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from collections import OrderedDict
+    from pointcloud_rl_amd.utils.checkpoint import get_state_dict, load_checkpoint, load_state_dict, save_checkpoint
+
+    def make(seed, C=6):
+        cfg = configs.sac_dmc(C, 4, 8, head_hidden=32)
+        cfg["env_params"] = configs.env_params({"xyz": [3, 16], "rgb": [3, 16]}, 4)
+        torch.manual_seed(seed)
+        return build_agent(cfg)
+
+    a = make(0)
+    for p in a.actor.parameters():                          # give the optimizers some state
+        p.grad = torch.randn_like(p)
+    a.actor_optim.step()
+    sd = get_state_dict(a)
+    assert {"actor_optim", "critic_optim", "alpha_optim", "log_alpha"} <= set(sd)
+    assert "actor.backbone.visual_nn.conv.mlp.conv0.weight" in sd and sd["actor_optim"]["state"]
+    path = tmp_path / "ckpt" / "model_1.ckpt"
+    save_checkpoint(a, str(path), meta=dict(step=1))
+    raw = torch.load(str(path), weights_only=False)
+    assert set(raw) == {"meta", "state_dict"} and raw["meta"] == dict(step=1)
+    assert all(v.device.type == "cpu" for v in raw["state_dict"].values() if torch.is_tensor(v))
+    b = make(1)
+    load_checkpoint(b, str(path), map_location="cpu", strict=True)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p, q), n
+    sa, sb = a.actor_optim.state_dict(), b.actor_optim.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    assert all(torch.equal(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]) for k in sa["state"])
+    # "module." prefix of a DDP-wrapped save, and a bare state_dict file
+    torch.save(OrderedDict(("module." + k, v) for k, v in raw["state_dict"].items() if torch.is_tensor(v)), str(tmp_path / "ddp.ckpt"))
+    c = make(2)
+    load_checkpoint(c, str(tmp_path / "ddp.ckpt"), map_location="cpu", logger=None)
+    assert torch.equal(dict(c.named_parameters())["log_alpha"], dict(a.named_parameters())["log_alpha"])
+    # a network with more input channels takes the common part of conv0.weight (the reference's one-dimension adaptation)
+    d = make(3, C=9)
+    msgs = []
+    class L:                                               # noqa: E306
+        warning = staticmethod(msgs.append)
+        info = staticmethod(msgs.append)
+    load_state_dict(d, {k: v for k, v in raw["state_dict"].items() if torch.is_tensor(v)}, strict=False, logger=L)
+    w_new = dict(d.named_parameters())["actor.backbone.visual_nn.conv.mlp.conv0.weight"]
+    w_old = dict(a.named_parameters())["actor.backbone.visual_nn.conv.mlp.conv0.weight"]
+    assert w_new.shape[1] == 9 and torch.equal(w_new[:, :6], w_old) and any("adapt weight" in m for m in msgs)
+    with pytest.raises(RuntimeError):
+        load_state_dict(make(4), {"nonsense": torch.zeros(1)}, strict=True)

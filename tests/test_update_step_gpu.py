@@ -179,3 +179,47 @@ def test_drq_mixed_precision_step_tracks_the_fp32_step(cuda):
     bf.enable_graphs(warmup=1)
     more = [bf.update_parameters(mem, u) for u in range(5, 11)]
     assert bf._graphs and all(np.isfinite(list(r.values())).all() for r in more)
+
+
+def test_checkpoint_resume_continues_bit_for_bit(cuda, tmp_path):
+    """Train 4 steps, save in the reference's checkpoint format, load into a freshly built agent, train 4 more: parameters,
+    Adam moments and step counts equal those of 8 uninterrupted steps exactly (same injected policy noise)."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    from pointcloud_rl_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    B, N, A = 8, 96, 4
+
+    def make(seed):
+        cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(seed)
+        return build_agent(cfg).to(cuda)
+
+    mem = SyntheticReplay(B, N, A, seed=6, device=cuda)
+    g = torch.Generator().manual_seed(11)
+    eps = [[torch.randn(B, A, generator=g).to(cuda) for _ in range(2)] for _ in range(8)]
+
+    def run(agent, lo, hi):
+        for u in range(lo, hi + 1):
+            agent.actor.head.noise_override = list(eps[u - 1][:2 if u % 2 == 0 else 1])
+            agent.update_parameters(mem, u)
+
+    whole = make(0)
+    run(whole, 1, 8)
+    first = make(0)
+    run(first, 1, 4)
+    path = str(tmp_path / "model_4.ckpt")
+    save_checkpoint(first, path)
+    resumed = make(123)                                     # different init: everything must come from the file
+    load_checkpoint(resumed, path, map_location="cpu", strict=True)
+    run(resumed, 5, 8)
+    for (n, p), (_, q) in zip(whole.named_parameters(), resumed.named_parameters()):
+        assert torch.equal(p, q), n
+    for name in ("critic_optim", "actor_optim", "alpha_optim"):
+        a, b = getattr(whole, name), getattr(resumed, name)
+        assert int(a.step_counter) == int(b.step_counter) > 0
+        assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq), name
+    # the target network's own (non-shared) parameters travel too
+    for (n, p), (_, q) in zip(whole.target_critic.named_parameters(), resumed.target_critic.named_parameters()):
+        assert torch.equal(p, q), n
