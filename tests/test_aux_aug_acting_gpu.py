@@ -1,5 +1,7 @@
 """GPU tests: stand-alone segmented max / augmentation kernels, the fused augmentations of the encoder
 (explicit noise, affine, in-kernel Philox statistics) and the acting path."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -310,3 +312,48 @@ def test_device_replay_without_replacement_walks_the_reference_epoch_order(cuda)
         seen.append(want)
     assert len(np.unique(np.concatenate(seen[:4]))) == 4 * B
     assert mem.sample(cap + 1, auto_restart=False) is None      # cannot be served without a restart
+
+
+@pytest.mark.parametrize("mode", ["with", "without"])
+def test_device_replay_reproduces_the_reference_replay_memory(cuda, mode):
+    """tests/golden/ref_replay.npz was produced by the reference's ReplayMemory + OneStepTransition (tools/gen_golden_replay.py):
+    the same pushes (the third wraps around the ring) and the same seed give the same ten sampled batches, key by key."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_replay.npz"))
+    mem = DeviceReplay(40, device=cuda, seed=7, with_replacement=(mode == "with"), host_rng=True)
+    for i in range(3):
+        items = {}
+        for k in z.files:
+            if k.startswith(f"push{i}/"):
+                node, parts = items, k.split("/")[1:]
+                for part in parts[:-1]:
+                    node = node.setdefault(part, {})
+                node[parts[-1]] = z[k]
+        mem.push_batch(items)
+    assert [len(mem), mem.position] == z[f"{mode}/len_position"].tolist()
+    for s in range(10):
+        batch = mem.sample(6).to_torch(device=cuda)
+        keys = [k for k in z.files if k.startswith(f"{mode}/sample{s}/")]
+        assert keys
+        for k in keys:
+            node = batch
+            for part in k.split("/")[2:]:
+                node = node[part]
+            np.testing.assert_array_equal(node.cpu().numpy(), z[k], err_msg=k)
+
+
+@pytest.mark.parametrize("tag,kw", [("ratio", dict(drop_ratio=0.3, fixed_ratio=True)), ("maxpts", dict(max_num_points=17))])
+def test_random_downsample_matches_the_reference_class(cuda, tag, kw):
+    """tests/golden/ref_downsample.npz: what the reference's RandomDownSample returned (tools/gen_golden_downsample.py).  With the
+    reference's index injected, this class keeps the same number of points and `materialize` yields the same tensors for every key."""
+    from pointcloud_rl_amd.augmentations import RandomDownSample
+    from pointcloud_rl_amd.networks.pointnet import materialize
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_downsample.npz"))
+    obs = {k: torch.from_numpy(z[f"in/{k}"]).to(cuda) for k in ("xyz", "rgb", "seg")}
+    aug = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], **kw)
+    torch.manual_seed(0)
+    assert aug(obs).aug["point_index"].numel() == int(z[f"{tag}/n"])          # same count from the same keywords
+    aug.index_override = [torch.from_numpy(z[f"{tag}/index"])]
+    got = materialize(aug(obs))
+    for k in ("xyz", "rgb", "seg"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), z[f"{tag}/out/{k}"], err_msg=k)
