@@ -296,3 +296,27 @@ def test_reference_written_checkpoint_loads_and_key_sets_match(tmp_path):
     save_checkpoint(agent, out, meta=dict(updates=2))
     mine = torch.load(out, weights_only=False)
     assert set(mine) == set(ck) and list(mine["state_dict"].keys()) == list(ref.keys())
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("rot_scale_trans", dict(rot_range=[-0.15, 0.15], rot_axis="z", scale_ratio_range=[0.9, 1.1], translation_range=[0.04, 0.0, 0.04], shift_height=False)),
+    ("rot_y_only", dict(rot_range=0.5, rot_axis="y", scale_ratio_range=None, translation_range=None, shift_height=False)),
+    ("shift_only", dict(rot_range=None, rot_axis="z", scale_ratio_range=None, translation_range=[0.1, 0.2, 0.3], shift_height=True)),
+])
+def test_global_rot_scale_trans_draws_the_reference_matrices(tag, kw):
+    """tests/golden/ref_rotscaletrans.npz: matrices and outputs of the reference's GlobalRotScaleTrans under torch.manual_seed
+    (tools/gen_golden_rotscaletrans.py).  Same seed -> the same draws in the same order -> the same [R|t]; applying it as the
+    encoder kernel does (R x + t) gives the reference's xyz."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_rotscaletrans.npz"))
+    xyz = torch.from_numpy(z["in/xyz"])
+    torch.manual_seed(int(z[f"{tag}/seed"]))
+    aug = GlobalRotScaleTrans(main_key="xyz", req_keys=["xyz"], **kw)
+    out = aug({"xyz": xyz})
+    mat = out.aug["affine"]
+    ref = torch.from_numpy(z[f"{tag}/mat"])
+    if kw["rot_range"] is not None:
+        assert torch.equal(mat[:, :, :3], ref[:, :3, :3])
+    if kw["translation_range"] is not None:
+        assert torch.equal(mat[:, :, 3], ref[:, :3, 3])
+    got = torch.einsum("bji,bin->bjn", mat[:, :, :3], xyz) + mat[:, :, 3:]
+    np.testing.assert_allclose(got.numpy(), z[f"{tag}/out_xyz"], atol=1e-6, rtol=0)
