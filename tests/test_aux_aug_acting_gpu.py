@@ -357,3 +357,25 @@ def test_random_downsample_matches_the_reference_class(cuda, tag, kw):
     got = materialize(aug(obs))
     for k in ("xyz", "rgb", "seg"):
         np.testing.assert_array_equal(got[k].cpu().numpy(), z[f"{tag}/out/{k}"], err_msg=k)
+
+
+def test_acting_matches_the_reference_agent_loaded_from_its_checkpoint(cuda):
+    """The reference agent that wrote tests/golden/ref_sac_dmc_small.ckpt also acted on a small observation
+    (tools/gen_golden_checkpoint.py -> ref_sac_dmc_small_acting.npz).  Loading its checkpoint here and acting on the same
+    observation gives the same actions (1e-5) in the deterministic modes."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.utils.checkpoint import load_checkpoint
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    cfg = configs.sac_dmc(6, 6, 8, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 64], "rgb": [3, 64]}, 6)
+    agent = build_agent(cfg)
+    load_checkpoint(agent, os.path.join(gold, "ref_sac_dmc_small.ckpt"), map_location="cpu", strict=True)
+    agent = agent.to(cuda).eval()
+    z = np.load(os.path.join(gold, "ref_sac_dmc_small_acting.npz"))
+    obs = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("obs/")}
+    for mode in ("eval", "mean"):
+        got = agent(obs, mode=mode)
+        np.testing.assert_allclose(got.cpu().numpy(), z[mode], atol=1e-5, rtol=0, err_msg=mode)
+    acts, states = agent(obs, mode="eval", rnn_mode="with_states")
+    assert states is None and torch.equal(acts, agent(obs, mode="eval"))

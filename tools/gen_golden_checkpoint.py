@@ -39,5 +39,15 @@ if __name__ == "__main__":
                 return DictArray(copy.deepcopy(batch))
         agent.update_parameters(Mem(), u)
     save_checkpoint(agent, OUT, meta=dict(updates=2))
+    # acting path of the same agent (BaseAgent.forward, module_utils.py:147-159): deterministic modes on a small observation
+    agent.eval()
+    obs = make_obs(g, 3, N)
+    acting = {f"obs/{k}": v for k, v in obs.items()}
+    with torch.no_grad():
+        acting["eval"] = agent(copy.deepcopy(obs), mode="eval").numpy()
+        acting["mean"] = agent(copy.deepcopy(obs), mode="mean").numpy()
+        acts, states = agent(copy.deepcopy(obs), mode="eval", rnn_mode="with_states")
+        assert states is None
+    np.savez_compressed(OUT.replace(".ckpt", "_acting.npz"), **acting)
     ck = torch.load(OUT, weights_only=False)
     print(OUT, f"{os.path.getsize(OUT) / 1e6:.2f} MB", sorted(k for k in ck["state_dict"] if not torch.is_tensor(ck["state_dict"][k])))
