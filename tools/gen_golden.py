@@ -211,6 +211,9 @@ if __name__ == "__main__":
     }
     gen_step("sac_dmc_small", f"{REF}/configs/mfrl/sac/dm_control/pn.py", small_heads, {}, B=8, N=64, A=6, n_updates=4, seed=0)
     gen_step("drq_dmc_jitter_small", f"{REF}/configs/mfrl/drq/dm_control/pn_jitter.py", small_heads, {}, B=4, N=64, A=6, n_updates=4, seed=1)
+    # BASELINE config 1 layout (dmc_walker_walk: 3 stacked frames, C = 9 = xyz + rgb + one-hot frame id)
+    gen_step("sac_dmc_k0_posenc_small", f"{REF}/configs/mfrl/sac/dm_control/pn.py", small_heads, dict(pos_encoding=3), B=4, N=96, A=6,
+             n_updates=2, seed=3)
     ms_heads = {
         "agent_cfg.actor_cfg.nn_cfg.mlp_cfg.mlp_spec": ["128 + agent_shape", 64, 64, "action_shape * 2"],
         "agent_cfg.critic_cfg.nn_cfg.mlp_cfg.mlp_spec": ["128 + agent_shape + action_shape", 64, 64, 1],
