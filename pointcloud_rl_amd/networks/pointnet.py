@@ -66,17 +66,18 @@ class _EncoderFn(torch.autograd.Function):
         pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=net._workspace("fwd"), bf16=net.compute_dtype == "bf16")
         ctx.net, ctx.desc, ctx.keep, ctx.aug_desc, ctx.aug = net, desc, keep, aug_desc, aug
         ctx.ew, ctx.packed = ew, packed
-        ctx.save_for_backward(argmax)
+        ctx.save_for_backward(argmax, pooled)
         ctx.mark_non_differentiable(argmax)
         net.last_argmax = argmax
         return pooled, argmax
 
     @staticmethod
     def backward(ctx, grad_pooled, _grad_argmax):
-        (argmax,) = ctx.saved_tensors
+        argmax, pooled = ctx.saved_tensors
         net = ctx.net
         flat, n_active = hip.encoder_bwd(ctx.desc, ctx.ew, ctx.packed, argmax, grad_pooled, aug=ctx.aug_desc,
-                                         workspace=net._workspace("bwd", ctx.desc.B), want_n_active=True, bf16=net.compute_dtype == "bf16")
+                                         workspace=net._workspace("bwd", ctx.desc.B), want_n_active=True, bf16=net.compute_dtype == "bf16",
+                                         pooled=pooled)
         net.last_n_active = n_active
         views = hip.encoder_grad_views(flat, ctx.ew)
         return (None, None, None, None) + tuple(views[k] for k in ("conv0.weight", "conv0.bias", "conv1.weight", "norm1.weight",
@@ -169,13 +170,13 @@ class PointNet(ExtendedModule):
         ew, packed = self._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
         pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16")
-        return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed)
+        return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed, pooled)
 
     def backward_raw(self, ctx, argmax, grad_pooled, out):
         """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
-        desc, keep, aug, aug_desc, ew, packed = ctx
+        desc, keep, aug, aug_desc, ew, packed, pooled = ctx
         hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out,
-                        bf16=self.compute_dtype == "bf16")
+                        bf16=self.compute_dtype == "bf16", pooled=pooled)
 
     def forward(self, inputs, object_feature=True, concat_state=None, **kwargs):
         feature, _ = self.pooled(inputs)

@@ -28,7 +28,7 @@ def torch_reference_grads(obs_np, w_np, gpool_np, jitter=None):
     return {n: P[torch_ref.ENC + "conv.mlp." + n].grad.numpy() for n in NAMES}, idx.numpy().astype(np.int32), pooled.detach().numpy()
 
 
-def hip_grads(obs_np, w_np, gpool_np, dev, jitter=None):
+def hip_grads(obs_np, w_np, gpool_np, dev, jitter=None, with_pooled=True):
     from pointcloud_rl_amd import hip
     wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in w_np.items()}
     ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
@@ -41,7 +41,8 @@ def hip_grads(obs_np, w_np, gpool_np, dev, jitter=None):
         jt = torch.from_numpy(jitter).to(dev)
         aug = hip.make_aug_desc(jitter_noise=jt)
     pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug)
-    flat, n_act = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool_np).to(dev), aug=aug, want_n_active=True)
+    flat, n_act = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool_np).to(dev), aug=aug, want_n_active=True,
+                                  pooled=pooled if with_pooled else None)
     views = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
     torch.cuda.synchronize()
     return views, argmax.cpu().numpy(), pooled.cpu().numpy(), n_act.cpu().numpy()
@@ -74,6 +75,9 @@ def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
     np.testing.assert_allclose(pooled, pooled_ref, atol=1e-5, rtol=0)
     assert np.array_equal(n_act, [len(np.unique(r)) for r in idx_ref])
     assert_grads_close(got, ref)
+    # the same without the forward's pooled values (dense search for the owned channels)
+    got_dense, _, _, _ = hip_grads(obs, w, gpool, cuda, with_pooled=False)
+    assert_grads_close(got_dense, ref)
 
 
 def test_bwd_with_jitter_noise(cuda):
@@ -153,3 +157,17 @@ def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, 
         assert np.abs(g - r).max() / scale < 3e-2, f"{name}: {np.abs(g - r).max() / scale:.3e}"
     # bitwise reproducible
     assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True))
+
+
+def test_bwd_zero_gamma_falls_back_to_the_dense_path(cuda):
+    """norm2.weight == 0 on some channels: xhat cannot be recovered from pooled there, the kernel must take the dense path for
+    the cloud and still match autograd."""
+    obs = make_obs(2, 150, seed=31)
+    w = make_encoder_weights(6, 64, 128, 256, seed=7)
+    w["g2"] = w["g2"].copy(); w["g2"][::5] = 0.0
+    w["be2"] = np.abs(w["be2"]) + 0.1                     # y = beta > 0 on those channels: they are live
+    gpool = np.random.RandomState(5).randn(2, 256).astype(np.float32)
+    ref, idx_ref, _ = torch_reference_grads(obs, w, gpool)
+    got, idx, _, _ = hip_grads(obs, w, gpool, cuda)
+    assert np.array_equal(idx, idx_ref)
+    assert_grads_close(got, ref)

@@ -9,7 +9,7 @@ from pointcloud_rl_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256); ap.add_argument("--N", type=int, default=1024)
 ap.add_argument("--c1", type=int, default=64); ap.add_argument("--seg", type=int, default=0)
-ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true")
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--no-pooled", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 obs_np = make_obs(a.B, a.N, seed=1, seg=a.seg)
@@ -38,9 +38,9 @@ need = ctypes.c_size_t()
 hip.check(hip.lib().pcrl_encoder_bwd_workspace_bytes(a.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
 ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
 out = torch.empty(hip.encoder_num_grads(ew), device=dev)
-for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16)
+for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, pooled=None if a.no_pooled else pooled)
 torch.cuda.synchronize()
 e0.record()
-for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16)
+for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, pooled=None if a.no_pooled else pooled)
 e1.record(); torch.cuda.synchronize()
 print(f"encoder_bwd B={a.B} N={a.N}: {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us (points + wgrad + reduce kernels)")
