@@ -19,6 +19,8 @@ timed with HIP events inside the timed region; `cpu_baseline` is the op-for-op P
 restatement of the reference (oracle/torch_ref.py) timed on this box's host cores, rank 0, N=1 only.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -37,7 +39,17 @@ WORKLOADS = {
                     "bf16 conv1/conv2 with fp32 accumulate (BASELINE config 3)"),
     "k3": dict(B=1024, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="sac_maniskill",
                desc="SAC PointNet, ManiSkill shape B=1024 N=1200 C=7 (BASELINE config 4)"),
+    "k4": dict(B=512, N=8192, A=6, S=0, obs_kw={}, cfg="sac_dmc", capacity=1024,
+               desc="SAC PointNet, large-N stress B=512 N=8192 C=6, clouds split over workgroups + two-stage pool (BASELINE config 5)"),
 }
+
+
+def kernel_source_sha():
+    """Hash of the sources the dominant kernel (encoder_fwd_kernel) is compiled from; tags profiles/*_pmc_traffic_*.json."""
+    h = hashlib.sha256()
+    for name in ("encoder_fwd.hip", "encoder_common.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "pointcloud_rl_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -56,7 +68,7 @@ def parse():
     ap.add_argument("--replay", default="device", choices=["device", "fixed", "host"], help="device: sample every step from a device-resident "
                     "ring of synthetic transitions; fixed: the same resident batch every step; host: the batch comes from pinned host "
                     "memory every step (PCIe-inclusive rate, reported in DESIGN.md, never the headline value)")
-    ap.add_argument("--replay-capacity", type=int, default=2048)
+    ap.add_argument("--replay-capacity", type=int, default=0, help="transitions in the device ring (0: 2048, or the workload's own default)")
     ap.add_argument("--batch", type=int, default=0, help="analysis only: override the global batch size (the JSON line then is NOT the "
                     "BASELINE metric; used to look at the per-GPU share of a multi-GPU run on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
@@ -92,9 +104,11 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(agent, wl, steps, threads=0):
+def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0):
     """The reference's update step restated op for op (six encoder passes, permute LayerNorm, per-tensor
-    Adam groups), timed on the host: 1 warm-up + `steps` timed steps of the full B=256 batch."""
+    Adam groups), timed on the host: 1 warm-up + `steps` timed steps.  sample_batch > 0 bounds the work: the step is
+    timed on the first `sample_batch` transitions of the batch and the rate is scaled by sample_batch / B (> 99 % of
+    the reference's step is per-cloud encoder work, BASELINE.md section 2, so the step time is linear in the batch)."""
     from oracle import torch_ref
     from pointcloud_rl_amd.synthetic import make_batch_np
     params = {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}
@@ -102,25 +116,30 @@ def cpu_baseline(agent, wl, steps, threads=0):
                              target_entropy=agent.target_entropy, actor_update_interval=agent.actor_update_interval,
                              target_update_interval=agent.target_update_interval,
                              update_coeff=agent.update_coeff["default"], mirror_redundancy=True)
-    batch = make_batch_np(wl["B"], wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
+    Bs = min(sample_batch, wl["B"]) if sample_batch else wl["B"]
+    batch = make_batch_np(Bs, wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
     tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch.items()}
     torch.set_num_threads(threads if threads else usable_cpus())
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
-    eps = lambda: [torch.randn(wl["B"], wl["A"], generator=g), torch.randn(wl["B"], wl["A"], generator=g)]
+    eps = lambda: [torch.randn(Bs, wl["A"], generator=g), torch.randn(Bs, wl["A"], generator=g)]
     ref.update_parameters(tb, 1, eps())
     t0 = time.perf_counter()
     for u in range(2, 2 + steps):
         ref.update_parameters(tb, u, eps())
-    dt = (time.perf_counter() - t0) / steps
+    dt = (time.perf_counter() - t0) / steps * (wl["B"] / Bs)
+    what = f"{steps} full update steps (B={wl['B']}, N={wl['N']})" if Bs == wl["B"] else \
+        f"{steps} update steps on a {Bs}-transition slice of the B={wl['B']}, N={wl['N']} batch, time scaled by {wl['B']}/{Bs}"
     return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full update steps (B={wl['B']}, N={wl['N']}) after 1 warm-up, torch {torch.__version__} CPU, {cores} threads "
+            "sample": f"{what} after 1 warm-up, torch {torch.__version__} CPU, {cores} threads "
                       f"(box grants {usable_cpus()} of {os.cpu_count()} logical CPUs)"}
 
 
 def main():
     args = parse()
     wl = dict(WORKLOADS[args.workload])
+    if not args.replay_capacity:
+        args.replay_capacity = wl.get("capacity", 2048)
     if args.batch:
         wl["B"], wl["desc"] = args.batch, wl["desc"] + f" [batch overridden to {args.batch}]"
     rank = int(os.environ.get("RANK", 0))
@@ -145,9 +164,7 @@ def main():
     from pointcloud_rl_amd.synthetic import SyntheticReplay
     agent, C = build_agent(wl, b_rank, device)
     if world > 1:
-        from pointcloud_rl_amd.utils.dist import broadcast_parameters_
-        broadcast_parameters_(agent)                      # replicas start identical (DDP's constructor broadcast)
-        agent.to_ddp(device_ids=["cuda"])
+        agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
         # device-resident replay (pointcloud_rl_amd/replay.py): every rank owns a ring of synthetic transitions and each
         # step samples its share of the batch from it (uniform with replacement, as OneStepTransition does) -- sampling is
@@ -237,12 +254,17 @@ def main():
         achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
         peak = 2500.0 if is_bf16 else 157.3        # dense MFMA peaks of MI355X_MICROARCH.md (bf16 / fp32)
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{args.workload}.json")
-        if os.path.exists(tpath) and not args.batch and world == 1:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.workload}.json")))
+        if cands and not args.batch and world == 1:
             # HBM bytes per encoder_fwd launch from the committed rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process
-            tj = json.load(open(tpath))
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(tpath, ROOT)
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process.
+            # The file names the hash of the kernel's sources it was measured on: a figure from another kernel is not reported.
+            tj = json.load(open(cands[-1]))
+            if tj.get("kernel_source_sha") == kernel_source_sha():
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], ROOT)
+            else:
+                traffic_src = f"{os.path.relpath(cands[-1], ROOT)} is stale (measured on kernel sources {tj.get('kernel_source_sha')}, " \
+                              f"now {kernel_source_sha()}): not reported"
         out = {
             "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
             "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,7 +281,15 @@ def main():
             "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
         }
         if world == 1 and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
-            out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps, args.cpu_threads)
+            # bounded samples (about 10-30 s of CPU work each): every granted core on a slice of the batch that takes a few
+            # seconds per step, and the reference's shipped single-thread setting (pyrl/utils/meta/__init__.py:38-49) on a
+            # smaller slice
+            points = wl["B"] * wl["N"]
+            all_cores_b = wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points))
+            out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps, args.cpu_threads, sample_batch=all_cores_b)
+            if not args.cpu_threads:
+                one_b = max(4, int(wl["B"] * 24_000 / points))
+                out["cpu_baseline_1thread"] = cpu_baseline(agent, wl, 2, 1, sample_batch=one_b)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

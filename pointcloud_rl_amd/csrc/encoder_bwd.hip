@@ -211,7 +211,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             const float2 gb = reinterpret_cast<const float2*>(s_ln2)[tid];
             const bool live = y > 0.0f;
             const float dyl = live ? s_g[tid] : 0.0f;
-            if (live && gb.x == 0.0f) s_misc[5] = 1;            // xhat not recoverable through a zero gamma: dense path for this cloud
+            // xhat = (y - beta) / gamma loses |beta| / |gamma| ulps by cancellation and is not recoverable at all through a
+            // zero gamma; a non-finite y carries no xhat either.  In those cases the whole cloud takes the dense path, which
+            // recomputes xhat at the point itself (the default affine, gamma ~ 1 / beta ~ 0, never gets here).
+            const bool lossy = __builtin_fabsf(gb.x) < 1e-3f || __builtin_fabsf(gb.y) > 8.0f * __builtin_fabsf(gb.x);
+            if ((live && lossy) || !(__builtin_fabsf(y) <= 3.0e38f)) s_misc[5] = 1;
             const float xh = (live && gb.x != 0.0f) ? (y - gb.y) / gb.x : 0.0f;
             s_dx[tid] = dyl * gb.x;
             s_xh[tid] = xh;

@@ -313,8 +313,15 @@ def layernorm_rows_bwd(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, dgamma
                                             _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
 
 
+def _check_f32_vec(t, n, what):
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() >= n):
+        raise TypeError(f"{what} must be a contiguous float32 device tensor of {n} elements, got "
+                        f"{(t.dtype, tuple(t.shape), t.device) if torch.is_tensor(t) else type(t)}")
+
+
 def tanh_gaussian_fwd(feat, ld_feat, eps, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action, neg_logp, saved=None,
                       action2_ptr=None, ld_action2=0):
+    _check_f32_vec(scale, A, "scale"), _check_f32_vec(bias, A, "bias")
     check(lib().pcrl_tanh_gaussian_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
                                            _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
                                            ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
@@ -324,6 +331,7 @@ def tanh_gaussian_fwd(feat, ld_feat, eps, scale, bias, B, A, ls_min, ls_max, eps
 def tanh_gaussian_sample_fwd(feat, ld_feat, seed, step_counter, draw_id, eps_out, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action,
                              neg_logp, saved=None, action2_ptr=None, ld_action2=0):
     """tanh_gaussian_fwd with in-kernel Philox draws (written to eps_out); step_counter: device int32 tensor."""
+    _check_f32_vec(scale, A, "scale"), _check_f32_vec(bias, A, "bias")
     check(lib().pcrl_tanh_gaussian_sample_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(step_counter),
                                                   int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
                                                   _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
@@ -332,6 +340,7 @@ def tanh_gaussian_sample_fwd(feat, ld_feat, seed, step_counter, draw_id, eps_out
 
 
 def tanh_gaussian_bwd(feat, ld_feat, eps, saved, scale, B, A, ls_min, ls_max, epsilon, da0_ptr, da1_ptr, ld_da, d_neglogp, d_feat, ld_d_feat):
+    _check_f32_vec(scale, A, "scale")
     check(lib().pcrl_tanh_gaussian_bwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(saved), _ptr(scale), B, A, _f(ls_min), _f(ls_max),
                                            _f(epsilon), ctypes.c_void_p(da0_ptr), ctypes.c_void_p(da1_ptr) if da1_ptr else None,
                                            ctypes.c_int64(ld_da), _ptr(d_neglogp), _ptr(d_feat), ctypes.c_int64(ld_d_feat), _stream()))

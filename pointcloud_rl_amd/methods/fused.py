@@ -154,6 +154,17 @@ class FusedStep:
         # policy noise stream: torch's seed (torch.manual_seed controls it), decorrelated across data-parallel ranks
         from ..utils.dist import rank as _rank
         self.seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (_rank() + 1)) & (2 ** 64 - 1)
+        # action scale / bias as the kernels read them: float32 [A] on the device.  The head keeps them as the reference
+        # does -- Python ints 1 / 0 for an unbounded action space, a float64 Parameter for scalar bounds
+        # (regression_base.py:24-34) -- neither of which may be handed to a kernel as a raw float32 pointer.
+        head = agent.actor.head
+
+        def _as_f32(v):
+            if torch.is_tensor(v):
+                return v.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous().clone()
+            return torch.full((self.A,), float(v), dtype=torch.float32, device=dev)
+        self.head_scale, self.head_bias = _as_f32(head.scale), _as_f32(head.bias)
+        assert self.head_scale.numel() == self.A and self.head_bias.numel() == self.A
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -198,11 +209,11 @@ class FusedStep:
         saved = self._buf(f"pi_saved_{tag}", M, 2 * A) if save else None
         if head.noise_override:          # parity tests inject the draws
             eps = head._standard_normal(eps)
-            hip.tanh_gaussian_fwd(feat, 2 * A, eps, head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+            hip.tanh_gaussian_fwd(feat, 2 * A, eps, self.head_scale, self.head_bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
                                   act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
         else:                            # drawn in the kernel; the critic optimizer's device step count advances the stream
             hip.tanh_gaussian_sample_fwd(feat, 2 * A, self.seed, a.critic_optim.step_counter, 0 if tag == "n" else 1, eps,
-                                         head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                         self.head_scale, self.head_bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
                                          act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
         return feat, eps, saved, nlp, h1, h2
 
@@ -276,8 +287,7 @@ class FusedStep:
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
         scale = yield [fc.grad]
         pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
-        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)
-        enc.invalidate_packed()
+        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
 
         # ---- actor + temperature (sac.py:161-205) --------------------------------------------------------
@@ -301,7 +311,7 @@ class FusedStep:
                          dx_cols=(F + S, A), ld_dx=ceil4(A))
             head = a.actor.head
             dfeat = self._buf("pi_dfeat", Ma, 2 * A)
-            hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, head.scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
+            hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, self.head_scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
                                   d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)

@@ -88,9 +88,23 @@ class HipAdam:
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
-    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False):
-        """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...)."""
+    def hyper(self):
+        """(lr, beta1, beta2, eps) of the one fused pass.  The reference's build_optimizer gives every tensor its own group
+        with the same values (optimizer_utils.py:43-57); groups that differ cannot be served by one flat launch."""
         g = self.param_groups[0]
+        sig = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        for other in self.param_groups[1:]:
+            if (float(other["lr"]), float(other["betas"][0]), float(other["betas"][1]), float(other["eps"])) != sig:
+                raise NotImplementedError("HipAdam: per-tensor lr / betas / eps differ between param_groups; the fused optimizer "
+                                          "applies one set of hyper-parameters to its whole flat buffer")
+        return sig
+
+    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False):
+        """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...).
+        lr / betas / eps are kernel arguments: a launch captured in a hipGraph keeps the values it was captured with, which
+        is why SAC._run_step drops its graphs when an optimizer's hyper() changes (scheduler, load_state_dict)."""
+        g = self.param_groups[0]
+        self.hyper()
         return hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                              g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
                              target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer)
@@ -212,6 +226,19 @@ class SAC(BaseAgent):
                     self._target_flat, self._target_range, self._target_tau = target_flat, (begin, fc.total), taus.pop()
         self._alpha_t = self.log_alpha.detach().exp()
         self._dedup = self._encoder_is_shared()
+        # Encoders whose weights an optimizer writes: the fused Adam kernel updates parameters through raw pointers
+        # (no autograd version bump), so each of them must re-pack its MFMA weight image after that optimizer's step --
+        # with separate backbones (shared_backbone=False) these are the Q heads' own PointNets, not self.encoder.
+        from ..networks.pointnet import PointNet
+        self._packed_owners = {}
+        for name, module in (("critic", self.critic), ("actor", self.actor)):
+            ids = {id(p) for p in self._flat[name].params}
+            seen, owners = set(), []
+            for m in module.modules():
+                if isinstance(m, PointNet) and id(m) not in seen and any(id(p) in ids for p in m.parameters()):
+                    seen.add(id(m))
+                    owners.append(m)
+            self._packed_owners[name] = owners
         from .fused import FusedStep
         self._fused = FusedStep(self) if (self.use_fused_step and FusedStep.supported(self)) else None
         self._world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
@@ -241,10 +268,14 @@ class SAC(BaseAgent):
                 pend = opt.step(scale, defer=defer)
             if defer:
                 pending.append(pend)
+            for enc in self._packed_owners.get(name, ()):
+                enc.invalidate_packed()
             return opt.grad_norm.reshape(())
         if scale != 1.0:
             fb.grad.mul_(scale)
         opt.step()
+        for enc in self._packed_owners.get(name, ()):
+            enc.invalidate_packed()
         return fb.grad_norm_sq().sqrt()
 
     def _encode(self, module_for_fallback, obs):
@@ -277,9 +308,7 @@ class SAC(BaseAgent):
         fb.zero_grad()
         critic_loss.backward()
         scale = self._allreduce(fb.grad)
-        grad_norm = self._optim_step("critic", scale, polyak=polyak)
-        if self.encoder is not None:
-            self.encoder.invalidate_packed()
+        grad_norm = self._optim_step("critic", scale, polyak=polyak)      # re-pack of the encoders it owns: _optim_step
         with torch.no_grad():
             stats["critic_loss"] = critic_loss.detach()
             stats["max_critic_abs_err"] = torch.abs(q - q_target).max()
@@ -414,14 +443,19 @@ class SAC(BaseAgent):
             self._soft_update(updates)
             return self._finish({k: v for k, v in stats.items()}, updates)
         batch = self._to_static(batch)
+        # launches bake lr / betas / eps in as kernel arguments: a changed hyper-parameter invalidates the captured graphs
+        hyper = tuple(opt.hyper() for opt in (self.critic_optim, self.actor_optim, self.alpha_optim) if isinstance(opt, HipAdam))
+        if hyper != getattr(self, "_graph_hyper", hyper):
+            self._graphs, self._graph_seen = {}, {k: self._graph_warmup for k in self._graph_seen}
+        self._graph_hyper = hyper
         key = (do_actor, polyak)
         if key not in self._graphs:
             seen = self._graph_seen.get(key, 0)
             self._graph_seen[key] = seen + 1
             if seen < self._graph_warmup:          # eager warm-up: lazy initialisation must not be captured
                 return self._finish(self._step_body(batch, do_actor, polyak), updates)
-            if self.encoder is not None:
-                self.encoder.invalidate_packed()   # every replay starts by re-packing the (updated) weights
+            for enc in {id(e): e for owners in self._packed_owners.values() for e in owners}.values():
+                enc.invalidate_packed()            # every replay starts by re-packing the (updated) weights
             torch.cuda.synchronize()
             self._graphs[key] = self._capture_segments(batch, do_actor, polyak) if exchanging else self._capture_whole(batch, do_actor, polyak)
             if exchanging:                          # capturing a segmented step also executed it

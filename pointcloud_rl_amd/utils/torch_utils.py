@@ -218,7 +218,17 @@ class BaseAgent(ExtendedModule):
     # inside update_parameters, so these switches only record the state the drivers toggle
     # (run_rl.py:329, train_rl.py:396-405).
     def to_ddp(self, device_ids=None):
+        """The reference wraps actor / critic / target critic in DistributedDataParallel here, whose constructor
+        broadcasts rank 0's parameters and buffers (module_utils.py:322-343) -- drivers seed torch with seed + rank
+        before building the agent (run_rl.py:263), so without that broadcast the replicas would start from different
+        weights and, with only gradients averaged, never meet.  Same effect here: every parameter of the agent
+        (actor, critic, target critic, log_alpha; in place, so flat-buffer views stay valid) is broadcast from rank 0."""
+        from .dist import broadcast_parameters_, world_size
         self._device_ids = device_ids
+        if world_size() > 1:
+            broadcast_parameters_(self)
+            for enc in (m for m in self.modules() if hasattr(m, "invalidate_packed")):
+                enc.invalidate_packed()
         self.recover_ddp()
 
     def to_normal(self):

@@ -57,3 +57,38 @@ def test_shard_slices_partition_the_batch():
     idx = list(range(256))
     parts = [idx[shard_slice(256, r, 8)] for r in range(8)]
     assert sum(parts, []) == idx and all(len(p) == 32 for p in parts)
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    cfg = configs.sac_dmc(6, 4, 8, head_hidden=32)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 16], "rgb": [3, 16]}, 4)
+    torch.manual_seed(100 + rank)             # the reference's driver seeds torch with seed + rank (run_rl.py:263)
+    agent = build_agent(cfg)
+    with torch.no_grad():
+        agent.log_alpha.fill_(float(rank))    # differs across ranks until to_ddp
+    before = torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).clone()
+    agent.to_ddp(device_ids=["cuda"])         # reference: DDP's constructor broadcasts rank 0's weights (module_utils.py:322-343)
+    after = torch.cat([p.detach().reshape(-1) for p in agent.parameters()]).clone()
+    tgt = torch.cat([p.detach().reshape(-1) for p in agent.target_critic.parameters()]).clone()
+    out[rank] = (before, after, tgt, agent.is_data_parallel())
+    agent.to_normal()
+    assert not agent.is_data_parallel()
+    agent.recover_ddp()
+    assert agent.is_data_parallel()
+    dist.destroy_process_group()
+
+
+def test_to_ddp_broadcasts_rank0_weights_like_ddp_does():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ddp_worker, args=(world, port, out), nprocs=world, join=True)
+    (b0, a0, t0, dp0), (b1, a1, t1, dp1) = out[0], out[1]
+    assert dp0 and dp1
+    assert not torch.equal(b0, b1)                            # different seeds: different replicas before
+    assert torch.equal(a0, b0)                                # rank 0 keeps its weights
+    assert torch.equal(a1, a0) and torch.equal(t1, t0)        # every parameter (incl. target critic, log_alpha) now rank 0's

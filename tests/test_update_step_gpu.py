@@ -223,3 +223,62 @@ def test_checkpoint_resume_continues_bit_for_bit(cuda, tmp_path):
     # the target network's own (non-shared) parameters travel too
     for (n, p), (_, q) in zip(whole.target_critic.named_parameters(), resumed.target_critic.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def test_graph_replay_honours_a_changed_learning_rate(cuda):
+    """lr / betas / eps are kernel arguments of the fused Adam launch; graphs captured with the old values must be
+    dropped when a scheduler (or load_state_dict) changes param_groups.  With lr = 0 nothing an optimizer owns may move."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    cfg = configs.sac_dmc(6, 6, 16, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 96], "rgb": [3, 96]}, 6)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    agent.enable_graphs(warmup=1)
+    mem = SyntheticReplay(16, 96, 6, seed=5, device=cuda)
+    for u in range(1, 7):
+        agent.update_parameters(mem, u)
+    assert len(agent._graphs) == 2
+    for opt in (agent.critic_optim, agent.actor_optim, agent.alpha_optim):
+        for g in opt.param_groups:
+            g["lr"] = 0.0
+    owned = {n: p.detach().clone() for n, p in list(agent.critic.named_parameters()) + list(agent.actor.named_parameters())}
+    log_alpha = agent.log_alpha.detach().clone()
+    for u in range(7, 13):
+        agent.update_parameters(mem, u)
+    assert len(agent._graphs) == 2          # re-captured with the new values
+    now = dict(list(agent.critic.named_parameters()) + list(agent.actor.named_parameters()))
+    for n, p in owned.items():
+        assert torch.equal(p, now[n].detach()), n
+    assert torch.equal(log_alpha, agent.log_alpha.detach())
+
+
+def test_separate_backbones_repack_their_own_encoders(cuda):
+    """shared_backbone=False (the SAC constructor's default): each Q head owns a PointNet that the critic optimizer
+    updates through raw pointers.  After every optimizer step those encoders must run on the updated weights: a
+    freshly built PointNet loaded with the current state_dict gives bit-identical features."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.networks import build_all
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A = 8, 96, 4
+    cfg = configs.sac_dmc(6, A, B, head_hidden=32)
+    cfg["shared_backbone"] = False
+    cfg["critic_cfg"]["nn_cfg"]["visual_nn_cfg"] = dict(cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"])
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    encs = [v.backbone.visual_nn for v in agent.critic.values]
+    assert encs[0] is not encs[1] and encs[0] is not agent.actor.backbone.visual_nn
+    mem = SyntheticReplay(B, N, A, seed=3, device=cuda)
+    w_before = [e.conv.mlp.conv1.weight.detach().clone() for e in encs]
+    for u in range(1, 4):
+        agent.update_parameters(mem, u)
+    obs = {k: v for k, v in mem.batch["obs"].items() if k in ("xyz", "rgb")}
+    for e, w0 in zip(encs, w_before):
+        assert not torch.equal(e.conv.mlp.conv1.weight.detach(), w0), "the critic optimizer did not train this encoder"
+        fresh = build_all(dict(cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"])).to(cuda)
+        fresh.load_state_dict(e.state_dict())
+        with torch.no_grad():
+            assert torch.equal(e(obs), fresh(obs))

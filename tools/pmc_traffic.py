@@ -5,7 +5,11 @@ read, same guide, HBM section); WRITE_SIZE is taken as reported (uncalibrated).
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha  # noqa: E402
 
 
 def mean_counter(d, kernel, counter):
@@ -21,6 +25,7 @@ fetch_kb, n_f = mean_counter(sys.argv[1], sys.argv[3], "FETCH_SIZE")
 write_kb, n_w = mean_counter(sys.argv[2], sys.argv[3], "WRITE_SIZE")
 out = {"kernel": sys.argv[3], "launches_sampled": [n_f, n_w], "FETCH_SIZE_KB_reported": fetch_kb, "WRITE_SIZE_KB_reported": write_kb,
        "fetch_bytes_corrected_x2": None if fetch_kb is None else 2 * 1024 * fetch_kb, "write_bytes": None if write_kb is None else 1024 * write_kb}
+out["kernel_source_sha"] = kernel_source_sha()      # bench.py reports the figure only while the kernel's sources still hash to this
 if fetch_kb is not None and write_kb is not None:
     out["hbm_bytes_per_launch"] = out["fetch_bytes_corrected_x2"] + out["write_bytes"]
 json.dump(out, open(sys.argv[4], "w"), indent=1)
