@@ -64,18 +64,32 @@ def pointnet_forward(P, obs, prefix=ENC, ln_eps=1e-6):
     return F.layer_norm(feat, (feat.shape[-1],), P[f + "1.weight"], P[f + "1.bias"], 1e-5)
 
 
-def linear_mlp(P, prefix, x):
-    """LinearMLP with norm_cfg=None, ReLU between layers, linear output (mlp.py:97-100, 48-49)."""
+def linear_mlp(P, prefix, x, masks=None, flips=None):
+    """LinearMLP with norm_cfg=None, ReLU between layers, linear output (mlp.py:97-100, 48-49).
+
+    masks (tests only): per hidden layer a 0/1 tensor that REPLACES the ReLU's own branch decision (x * mask instead of
+    relu(x)) -- the decisions of another implementation of the same network.  A ReLU input within rounding of zero is
+    decided by the summation order, and which way it falls changes the layer's weight gradient by a whole sample's
+    contribution; with the decisions injected, two implementations can be compared at tight tolerance, and the decisions
+    themselves are compared separately: every disagreement is recorded in `flips` as (count, largest |pre-activation|
+    among them), which must be rounding-sized."""
     i = 0
     while f"{prefix}linear{i}.weight" in P:
         x = F.linear(x, P[f"{prefix}linear{i}.weight"], P[f"{prefix}linear{i}.bias"])
         if f"{prefix}linear{i + 1}.weight" in P:
-            x = F.relu(x)
+            if masks is None:
+                x = F.relu(x)
+            else:
+                m = masks[i].to(x.dtype)
+                if flips is not None:
+                    bad = (x.detach() > 0) != (m > 0)
+                    flips.append((int(bad.sum()), float(x.detach().abs()[bad].max()) if bad.any() else 0.0))
+                x = x * m
         i += 1
     return x
 
 
-def visuomotor(P, mlp_prefix, obs, actions=None, visual_feature=None, detach_visual=False, count=None):
+def visuomotor(P, mlp_prefix, obs, actions=None, visual_feature=None, detach_visual=False, count=None, masks=None, flips=None):
     """Visuomotor.forward (pyrl/networks/backbones/visuomotor.py:56-146), non-recurrent path.
     Returns (output of final_mlp, visual feature before the robot state is appended)."""
     obs = dict(obs)
@@ -100,7 +114,7 @@ def visuomotor(P, mlp_prefix, obs, actions=None, visual_feature=None, detach_vis
         feat = torch.cat([feat, robot_state], dim=-1)
     if actions is not None:
         feat = torch.cat([feat, actions], dim=-1)
-    return linear_mlp(P, mlp_prefix, feat), saved
+    return linear_mlp(P, mlp_prefix, feat, masks, flips), saved
 
 
 def tanh_gaussian(feature, eps, scale, bias, log_std_bound=(-10.0, 2.0), epsilon=1e-6):
@@ -151,15 +165,18 @@ class RefAgent:
         self.alpha = float(self.P["log_alpha"].exp().item())
         self.encoder_passes = [0]
         self.last_grads = {}
+        self.flips = []          # (count, max |pre-activation|) per masked hidden layer, see linear_mlp
 
     # -- modules ---------------------------------------------------------------------------
-    def actor(self, obs, eps, detach_visual=False):
-        feat, saved = visuomotor(self.P, "actor.backbone.final_mlp.mlp.", obs, detach_visual=detach_visual, count=self.encoder_passes)
+    def actor(self, obs, eps, detach_visual=False, masks=None):
+        feat, saved = visuomotor(self.P, "actor.backbone.final_mlp.mlp.", obs, detach_visual=detach_visual, count=self.encoder_passes,
+                                 masks=masks, flips=self.flips)
         a, neg_logp = tanh_gaussian(feat, eps, self.P["actor.head.scale"], self.P["actor.head.bias"])
         return a, neg_logp, saved
 
-    def critic(self, obs, actions, which="critic", visual_feature=None):
-        """ContinuousCritic.forward (applications/actor_critic.py:122-133): one Visuomotor pass per head."""
+    def critic(self, obs, actions, which="critic", visual_feature=None, masks=None):
+        """ContinuousCritic.forward (applications/actor_critic.py:122-133): one Visuomotor pass per head.
+        masks: [head][hidden layer] injected ReLU decisions (see linear_mlp)."""
         outs = []
         shared = None
         for h in (0, 1):
@@ -169,7 +186,8 @@ class RefAgent:
                     shared = pointnet_forward(self.P, {k: v for k, v in obs.items() if k not in ("state", "agent")})
                     self.encoder_passes[0] += 1
                 vf = shared
-            q, _ = visuomotor(self.P, f"{which}.values.{h}.backbone.final_mlp.mlp.", obs, actions=actions, visual_feature=vf, count=self.encoder_passes)
+            q, _ = visuomotor(self.P, f"{which}.values.{h}.backbone.final_mlp.mlp.", obs, actions=actions, visual_feature=vf, count=self.encoder_passes,
+                              masks=None if masks is None else masks[h], flips=self.flips)
             outs.append(q)
         return torch.cat(outs, dim=-1)
 
@@ -198,8 +216,12 @@ class RefAgent:
         return rep
 
     # -- the update step ---------------------------------------------------------------------
-    def update_parameters(self, batch, updates, eps_list, jitter_list=None):
+    def update_parameters(self, batch, updates, eps_list, jitter_list=None, relu_masks=None):
+        """relu_masks (tests only): {"q": [head][layer], "pi": [layer], "q_pi": [head][layer]} ReLU decisions of the
+        gradient-carrying head passes taken from the implementation under test (see linear_mlp)."""
         P = self.P
+        relu_masks = relu_masks or {}
+        self.flips = []
         pre = self.kind
         eps_list = list(eps_list)
         obs, next_obs = batch["obs"], batch["next_obs"]
@@ -224,7 +246,7 @@ class RefAgent:
             else:                      # sac.py:131-134
                 q_target = rewards * self.reward_scale + (1 - dones.float()) * self.gamma * min_q_next
                 q_target = q_target.repeat_interleave(q_next.shape[-1], dim=-1)
-        q = self.critic(obs, actions)
+        q = self.critic(obs, actions, masks=relu_masks.get("q"))
         critic_loss = F.mse_loss(q, q_target) * q_target.shape[-1]
         with torch.no_grad():
             abs_err = torch.abs(q - q_target).max().item()
@@ -244,9 +266,9 @@ class RefAgent:
                 a_obs = {k: v.reshape(B, self.num_aug, *v.shape[1:])[:, 0] for k, v in obs.items()}
             else:
                 a_obs = obs
-            pi, neg_logp, saved = self.actor(a_obs, eps_list.pop(0), detach_visual=True)
+            pi, neg_logp, saved = self.actor(a_obs, eps_list.pop(0), detach_visual=True, masks=relu_masks.get("pi"))
             entropy = neg_logp.mean()
-            q_pi = self.critic(a_obs, pi, visual_feature=saved.detach())
+            q_pi = self.critic(a_obs, pi, visual_feature=saved.detach(), masks=relu_masks.get("q_pi"))
             q_pi = torch.min(q_pi, dim=-1, keepdim=True).values
             actor_loss = -(q_pi.mean() + self.alpha * entropy)
             self.actor_optim.zero_grad()

@@ -172,6 +172,16 @@ class FusedStep:
             self.bufs[key] = torch.zeros(*shape, dtype=dtype, device=self.a._flat["critic"].data.device)
         return self.bufs[key]
 
+    def relu_decisions(self, M, Ma=None):
+        """ReLU branch decisions (hidden activation > 0) of the gradient-carrying head passes of the last eager step, for
+        the parity tests: {"q": [head][layer], "pi": [layer], "q_pi": [head][layer]} of bool [rows, H] tensors."""
+        H = self.H
+        out = {"q": [[self.bufs[(n, 2, M, H)][h] > 0 for n in ("q_h1", "q_h2")] for h in range(2)]}
+        if Ma is not None and ("pi_h1_a", 1, Ma, H) in self.bufs:
+            out["pi"] = [self.bufs[(n, 1, Ma, H)][0] > 0 for n in ("pi_h1_a", "pi_h2_a")]
+            out["q_pi"] = [[self.bufs[(n, 2, Ma, H)][h] > 0 for n in ("qa_h1", "qa_h2")] for h in range(2)]
+        return out
+
     # -- pieces -------------------------------------------------------------------------------------
     def _features(self, jobs):
         """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
@@ -252,6 +262,7 @@ class FusedStep:
         pooled_n, _, _ = enc.encode_raw(vis_n)
         vis_o, state_o = split(obs)
         pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
+        self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
         XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
         (_, _), (xhat, rstd) = self._features([
             (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F), (state_n, XQ_n, F)]),
