@@ -221,6 +221,12 @@ int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
 /* Up to 4 INDEPENDENT problems in one launch (no problem may read what another writes): dW and dx of
  * one layer, or the online and target Q heads of one layer.  Same per-problem semantics as above. */
 int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
+/* Tuning knob (tests, benchmarks): a launch runs its long-K forward-shaped problems (M, N >= 48, K >= 512, both operands
+ * k-contiguous and 16-byte readable) as LDS-staged 64x64 tiles when together they make at least `min_tiles` workgroups,
+ * otherwise as 32x32 split-K tiles; min_tiles <= 1 forces the staged tiles for every problem they can compute (K >= 64,
+ * any operand orientation).  The results of the two paths agree to fp32 summation order.  Returns the previous value
+ * (default 192, or the environment variable PCRL_GEMM_TILE64_MIN); a negative argument only queries. */
+int pcrl_gemm_set_tile64_min(int32_t min_tiles);
 
 /* Row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1] = nn.LayerNorm(out), pointnet.py:110).
  * The result is written to n_dst <= 4 destinations (dst[i] with leading dimension ld_dst[i]): the

@@ -8,8 +8,10 @@ namespace pcrl {
 
 // Records a thread-local error message and returns `code` (see pcrl_last_error()).
 int fail(int code, const char* fmt, ...);
-// Number of compute units of the current device (cached).
+// Number of compute units of the current device (cached per device).
 int num_cus();
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for `kernel` on the current device (done once per device and kernel).
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 #define PCRL_CHECK_HIP(expr)                                                                  \
     do {                                                                                      \

@@ -24,6 +24,8 @@
 //   * the epilogue issues its bias / mask loads before the split-K barrier and stores through the
 //     buffer path with out-of-range rows / columns dropped by the bounds check.
 #include "common.h"
+#include <atomic>
+#include <cstdlib>
 
 namespace pcrl {
 
@@ -39,9 +41,12 @@ struct GemmParams {
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
     int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
+    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS
+    int a_rc, b_rc;          // cfg 1: operand is contiguous along its row index (m resp. n) instead of along k
     int wg_n, wg_nm;         // n tiles, n tiles * m tiles
-    float inv_wg_n, inv_wg_nm;
+    float inv_wg_n, inv_wg_nm, inv_wg_m;
     int wg_begin;            // first workgroup of this problem inside the launch
+    int tiles;               // workgroups of this problem (all batch elements)
 };
 
 constexpr int kGemmWaves = 8;
@@ -90,15 +95,10 @@ __device__ __forceinline__ void gemm_mfma16(const f32x4 (&a)[4], const f32x4 (&b
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[t][j], acc, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmGroup g) {
-    __shared__ __attribute__((aligned(16))) float s_red[kGemmWaves][16][64];
+// cfg 0: one 32x32 output tile per workgroup, K split over the 8 waves, operands straight from L2.
+__device__ __forceinline__ void gemm_tile32_splitk(const GemmParams& p, const int wg, float* smem) {
+    float (*s_red)[16][64] = reinterpret_cast<float (*)[16][64]>(smem);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
-    const int wg = blockIdx.x;
-    int gi = 0;
-#pragma unroll
-    for (int j = 1; j < kGemmGroup; ++j)
-        if (j < g.n && wg >= g.wg_begin[j]) gi = j;
-    const GemmParams p = g.p[gi];
     // every field is needed within the next microsecond: one clause of scalar loads instead of dependent waits
     asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.C), "s"(p.bias), "s"(p.mask), "s"(p.C_ones), "s"(p.a_bs), "s"(p.b_bs), "s"(p.c_bs),
                  "s"(p.bias_bs), "s"(p.mask_bs), "s"(p.c_ones_bs));
@@ -203,6 +203,272 @@ __global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmGro
             buf_store_f1(rs_c, c_off[e], 0, v);
         }
     }
+}
+
+
+// cfg 1: one 64x64 output tile per workgroup, for the layers where all three dimensions are large (the 1024 x 1024 layers
+// of the heads and their gradients).  Both operands are staged through LDS in 64-k chunks (two stages: the global loads of
+// chunk c + 1 are in flight while chunk c is multiplied), so every operand element is fetched from L2 once per workgroup
+// and used by two waves -- 16 FLOP per byte of L2 traffic instead of 8 -- with coalesced 16-byte loads whatever the
+// operand's orientation.  Waves: (k half, 2 x 2 blocks of 32 x 32); the two k halves are added in LDS in a fixed order.
+// An operand is "k-contiguous" (LDS image [row][k], 16-byte operand reads) or "row-contiguous" ([k][row], 4-byte reads).
+constexpr int kT64Kc = 64;                       // k per stage: one barrier per 32 MFMAs of a wave
+constexpr int kT64LdK = kT64Kc + 4;              // LDS pitch (floats) of a k-contiguous image [64 rows][k]: + 4 keeps 16-byte accesses conflict-free
+constexpr int kT64LdR = 68;                      // ... of a row-contiguous image [k][64 rows]
+constexpr int kT64Stage = kT64Kc * kT64LdR > 64 * kT64LdK ? kT64Kc * kT64LdR : 64 * kT64LdK;   // floats per operand per stage
+constexpr int kT64Pieces = kT64Kc / 32;          // 16-byte pieces per thread, operand and chunk
+constexpr size_t kGemmLdsBytes32 = sizeof(float) * kGemmWaves * 16 * 64;       // cfg 0: the split-K partial sums
+constexpr size_t kGemmLdsBytes = sizeof(float) * 4 * kT64Stage;   // 2 operands x 2 stages = 139 264 B (>= the 32 KB of cfg 0)
+
+struct T64Operand {
+    __amdgpu_buffer_rsrc_t rs;    // batch element (buffer addressing: loads do not touch the LDS counter, out-of-range offsets read 0)
+    unsigned voff[kT64Pieces];    // this thread's byte offsets of its 16-byte pieces inside chunk 0
+    int lofs[kT64Pieces];         // where they go in the LDS image (floats)
+    unsigned step;                // bytes from one chunk to the next
+    int r0, rows_mem, rc, ones_row;
+    bool edge;                    // the tile hangs over the operand's last row: row-contiguous pieces are read element-wise
+    bool plain;                   // every piece of a chunk inside K is one unconditional 16-byte load
+};
+
+// Piece idx = tid + 512 u of a 64 x kT64Kc operand chunk: k-contiguous operand -> row idx / (Kc/4), k = 4 (idx % (Kc/4)) .. + 3;
+// row-contiguous operand -> k = idx >> 4, rows 4 (idx & 15) .. + 3.
+__device__ __forceinline__ void t64_piece(int rc, int idx, int& hi, int& lo4) {
+    if (rc) { hi = idx >> 4; lo4 = 4 * (idx & 15); }
+    else { hi = idx / (kT64Kc / 4); lo4 = 4 * (idx % (kT64Kc / 4)); }
+}
+
+__device__ __forceinline__ T64Operand t64_operand_setup(const float* base, unsigned s_row4, unsigned s_k4, int r0, int rows_mem, int rc,
+                                                        int ones_row, int tid) {
+    T64Operand o;
+    o.rs = make_rsrc(base, kGemmRecords);
+    o.r0 = r0; o.rows_mem = rows_mem; o.rc = rc; o.ones_row = ones_row;
+    o.edge = r0 + 64 > rows_mem;
+    o.plain = !(rc && o.edge) && !(ones_row >= r0 && ones_row < r0 + 64);
+    o.step = rc ? (unsigned)kT64Kc * s_k4 : 4u * kT64Kc;
+#pragma unroll
+    for (int u = 0; u < kT64Pieces; ++u) {
+        int hi, lo4;
+        t64_piece(rc, tid + 512 * u, hi, lo4);
+        // k-contiguous: rows past the end are clamped (they compute garbage that is never stored)
+        o.voff[u] = rc ? (unsigned)hi * s_k4 + 4u * (unsigned)(r0 + lo4) : (unsigned)min(r0 + hi, rows_mem - 1) * s_row4 + 4u * (unsigned)lo4;
+        o.lofs[u] = hi * (rc ? kT64LdR : kT64LdK) + lo4;
+    }
+    return o;
+}
+
+// Branches are workgroup-uniform; per-lane conditions only select offsets (kGemmOob reads 0).
+// o.plain (no virtual ones row in this tile, no element-wise edge reads) and a chunk inside K: straight-line 16-byte loads.
+__device__ __forceinline__ void t64_gload(const T64Operand& o, int c, int K, int tid, f32x4 (&v)[kT64Pieces]) {
+    const int k0 = kT64Kc * c;
+    const bool full = k0 + kT64Kc <= K;                                      // the chunk lies inside K: no k predicate
+    const unsigned soff = (unsigned)c * o.step;
+    if (full && o.plain) {
+#pragma unroll
+        for (int u = 0; u < kT64Pieces; ++u) v[u] = buf_load_f4(o.rs, o.voff[u], soff);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < kT64Pieces; ++u) {
+        int hi, lo4;
+        t64_piece(o.rc, tid + 512 * u, hi, lo4);
+        f32x4 x;
+        if (!o.rc) {
+            const int k = k0 + lo4;
+            x = buf_load_f4(o.rs, (full || k < K) ? o.voff[u] : kGemmOob, soff);
+            if (!full) {                                                    // ragged K: both operands read zero beyond it
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = k + e < K ? x[e] : 0.0f;
+            }
+            if (o.ones_row >= 0 && o.r0 + hi == o.ones_row) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = k + e < K ? 1.0f : 0.0f;
+            }
+        } else {
+            const bool k_ok = full || k0 + hi < K;
+            if (!o.edge) {
+                x = buf_load_f4(o.rs, k_ok ? o.voff[u] : kGemmOob, soff);
+            } else {
+                const int row = o.r0 + lo4;
+                const unsigned kbase = o.voff[u] - 4u * (unsigned)row;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    x[e] = buf_load_f1(o.rs, k_ok ? kbase + 4u * (unsigned)min(row + e, o.rows_mem - 1) : kGemmOob, soff);
+                if (o.ones_row >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (row + e == o.ones_row) x[e] = k_ok ? 1.0f : 0.0f;
+                }
+            }
+        }
+        v[u] = x;
+    }
+}
+
+__device__ __forceinline__ void t64_lds_store(float* s, const T64Operand& o, const f32x4 (&v)[kT64Pieces]) {
+#pragma unroll
+    for (int u = 0; u < kT64Pieces; ++u) *reinterpret_cast<f32x4*>(s + o.lofs[u]) = v[u];
+}
+
+// Operand values of the 4 MFMAs of a group for lane (i, h): k = kq + j, j = 0..3, of row `row` (kq already holds + 4 h).
+template <bool RC>
+__device__ __forceinline__ f32x4 t64_operand(const float* s, int row, int kq) {
+    if (!RC) return *reinterpret_cast<const f32x4*>(s + row * kT64LdK + kq);
+    f32x4 x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = s[(kq + j) * kT64LdR + row];
+    return x;
+}
+
+// Main loop of a 64x64 tile, one instantiation per pair of operand orientations (straight-line LDS reads and MFMAs).
+template <bool ARC, bool BRC>
+__device__ __forceinline__ void t64_mainloop(const T64Operand& oa, const T64Operand& ob, int K, float* smem, int tid, int arow, int i, int kb,
+                                             f32x16& acc0, f32x16& acc1) {
+    float* sA = smem;
+    float* sB = smem + 2 * kT64Stage;
+    const int n_chunks = (K + kT64Kc - 1) / kT64Kc;
+    // Register ring two chunks deep: chunk c + 2 is requested before chunk c is multiplied and lands in LDS one iteration
+    // later, so a load has two chunk times to come back from L2 / MALL.
+    f32x4 ra[2][kT64Pieces], rb[2][kT64Pieces];
+    auto compute = [&](int st) {
+        const float* a_s = sA + st * kT64Stage;
+        const float* b_s = sB + st * kT64Stage;
+        constexpr int NQ = kT64Kc / 32;                            // groups of 8 k for this wave's quarter of the chunk
+        f32x4 a[NQ], b0[NQ], b1[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            a[q] = t64_operand<ARC>(a_s, arow, kb + 8 * q);
+            b0[q] = t64_operand<BRC>(b_s, i, kb + 8 * q);
+            b1[q] = t64_operand<BRC>(b_s, 32 + i, kb + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b0[q][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][j], b1[q][j], acc1, 0, 0, 0);
+            }
+    };
+    t64_gload(oa, 0, K, tid, ra[0]);
+    t64_gload(ob, 0, K, tid, rb[0]);
+    if (n_chunks > 1) {
+        t64_gload(oa, 1, K, tid, ra[1]);
+        t64_gload(ob, 1, K, tid, rb[1]);
+    }
+    t64_lds_store(sA, oa, ra[0]);
+    t64_lds_store(sB, ob, rb[0]);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; c += 2) {
+        // even chunk c in stage 0; ring slot 1 holds chunk c + 1, slot 0 is free for chunk c + 2
+        if (c + 2 < n_chunks) {
+            t64_gload(oa, c + 2, K, tid, ra[0]);
+            t64_gload(ob, c + 2, K, tid, rb[0]);
+        }
+        compute(0);
+        if (c + 1 < n_chunks) {
+            t64_lds_store(sA + kT64Stage, oa, ra[1]);
+            t64_lds_store(sB + kT64Stage, ob, rb[1]);
+        }
+        __syncthreads();
+        if (c + 1 >= n_chunks) break;
+        // odd chunk c + 1 in stage 1; slot 0 holds chunk c + 2, slot 1 is free for chunk c + 3
+        if (c + 3 < n_chunks) {
+            t64_gload(oa, c + 3, K, tid, ra[1]);
+            t64_gload(ob, c + 3, K, tid, rb[1]);
+        }
+        compute(1);
+        if (c + 2 < n_chunks) {
+            t64_lds_store(sA, oa, ra[0]);
+            t64_lds_store(sB, ob, rb[0]);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void gemm_tile64(const GemmParams& p, const int wg, float* smem) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    // wave = (k quarter kg, row half bm): a 32 x 64 strip = two accumulators that share the A operand.  Two independent
+    // accumulators matter: an instruction slipped between two MFMAs on the SAME accumulator costs ~43 idle matrix cycles,
+    // between MFMAs on different ones ~6 (MI355X_MICROARCH.md), and the A operand is read from LDS once for both.
+    const int kg = wave >> 1, bm = wave & 1;
+    int local = wg - p.wg_begin;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2: XCD x takes a contiguous eighth of the tile
+    // list (batch, N tile, M tile with M fastest), i.e. a few N tiles with all their M tiles, so a slice of the large B
+    // operand is fetched into one L2 only and shared there by the M tiles that use it.
+    if ((p.tiles & 7) == 0) local = (local & 7) * (p.tiles >> 3) + (local >> 3);
+    const int bz = __builtin_amdgcn_readfirstlane((int)(((float)local + 0.5f) * p.inv_wg_nm));
+    const int rem = local - bz * p.wg_nm;
+    const int wg_m = p.wg_nm / p.wg_n;
+    const int nx = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * p.inv_wg_m));
+    const int my = rem - nx * wg_m;
+    const int m0 = my * 64, n0 = nx * 64;
+    const T64Operand oa = t64_operand_setup(uniform_ptr(p.A + bz * p.a_bs), p.a_sm4, p.a_sk4, m0, p.M, p.a_rc, -1, tid);
+    const T64Operand ob = t64_operand_setup(uniform_ptr(p.B + bz * p.b_bs), p.b_sn4, p.b_sk4, n0, p.ones_col >= 0 ? p.ones_col : p.N, p.b_rc,
+                                            p.ones_col, tid);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+    const int arow = 32 * bm + i, kb = (kT64Kc / 4) * kg + 4 * h;
+    if (!p.a_rc && !p.b_rc) t64_mainloop<false, false>(oa, ob, p.K, smem, tid, arow, i, kb, acc0, acc1);        // forward
+    else if (!p.a_rc && p.b_rc) t64_mainloop<false, true>(oa, ob, p.K, smem, tid, arow, i, kb, acc0, acc1);     // data gradient
+    else if (p.a_rc && p.b_rc) t64_mainloop<true, true>(oa, ob, p.K, smem, tid, arow, i, kb, acc0, acc1);       // weight gradient
+    else t64_mainloop<true, false>(oa, ob, p.K, smem, tid, arow, i, kb, acc0, acc1);
+    // ---- the four k quarters meet in LDS (the stages are free: every wave is past the last barrier) -----------------
+    float (*s_red)[32][64] = reinterpret_cast<float (*)[32][64]>(smem);         // [wave][accumulator register][lane], 64 KB
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s_red[wave][r][lane] = acc0[r]; s_red[wave][16 + r][lane] = acc1[r]; }
+    // wave (kg, bm) finishes accumulator registers 8 kg .. 8 kg + 7 (of 32) of row half bm: block column kg >> 1
+    const int bn = kg >> 1;
+    const int col = n0 + 32 * bn + i;
+    const bool col_ok = col < p.N;
+    float bv = 0.0f, mv[8], old[8];
+    unsigned c_off[8];
+    int row[8];
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(uniform_ptr(p.C + bz * p.c_bs), kGemmRecords);
+    if (p.bias) bv = (p.bias + bz * p.bias_bs)[min(col, p.N - 1)];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = (8 * kg + e) & 15;
+        row[e] = m0 + 32 * bm + (r & 3) + 8 * (r >> 2) + 4 * h;
+        c_off[e] = (row[e] < p.M && col_ok) ? (unsigned)row[e] * p.ldc4 + 4u * col : kGemmOob;
+        mv[e] = 1.0f; old[e] = 0.0f;
+    }
+    if (p.mask) {
+        const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(uniform_ptr(p.mask + bz * p.mask_bs), kGemmRecords);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            mv[e] = buf_load_f1(rs_m, c_off[e] == kGemmOob ? kGemmOob : (unsigned)row[e] * p.ld_mask4 + 4u * col, 0);
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) old[e] = buf_load_f1(rs_c, c_off[e], 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int R = 8 * kg + e;
+        float v = (s_red[bm][R][lane] + s_red[2 + bm][R][lane]) + (s_red[4 + bm][R][lane] + s_red[6 + bm][R][lane]);
+        v = v + bv;
+        if (p.relu) v = v > 0.0f ? v : 0.0f;
+        v = mv[e] > 0.0f ? v : 0.0f;
+        v = old[e] + v;
+        if (p.C_ones && col == p.ones_col) {
+            if (c_off[e] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row[e]] = v;
+        } else {
+            buf_store_f1(rs_c, c_off[e], 0, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    const int wg = blockIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int j = 1; j < kGemmGroup; ++j)
+        if (j < g.n && wg >= g.wg_begin[j]) gi = j;
+    const GemmParams p = g.p[gi];
+    if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
+    else gemm_tile32_splitk(p, wg, gemm_smem);
 }
 
 // Row-wise LayerNorm over a short feature vector (PointNet.final_mlp[1]: nn.LayerNorm(out), eps 1e-5,
@@ -329,7 +595,7 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
 
 using namespace pcrl;
 
-static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total) {
+static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool want_tile64, bool force_tile64) {
     if (!d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 1) return fail(PCRL_E_ARG, "bad GEMM shape");
     p = GemmParams{};
@@ -355,28 +621,73 @@ static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total) {
     };
     p.a_k4 = d->a_stride_k == 1 && aligned(p.A, d->a_stride_m, p.a_bs);
     p.b_k4 = d->b_stride_k == 1 && aligned(p.B, d->b_stride_n, p.b_bs);
-    p.wg_n = (p.N + 31) / 32;
-    p.wg_nm = p.wg_n * ((p.M + 31) / 32);
+    // 64x64 LDS-staged tiles: all three dimensions large, both operands readable in 16-byte pieces in one of the two orientations
+    const bool a_kc = p.a_k4 && d->a_stride_m >= d->K, a_rc = d->a_stride_m == 1 && aligned(p.A, d->a_stride_k, p.a_bs);
+    const bool b_kc = p.b_k4 && d->b_stride_n >= d->K, b_rc = d->b_stride_n == 1 && aligned(p.B, d->b_stride_k, p.b_bs);
+    // Measured (tools/bench_gemm.py, MI355X): the staged tiles win where K is long and both operands are k-contiguous (the
+    // forward layers: 4 heads x 256x1024x1024 in 24.7 us against 32.7 us); the gradient GEMMs -- short K (dW: K = batch) or
+    // a row-contiguous operand read from LDS four bytes at a time (dX) -- are faster as 32x32 split-K tiles at four
+    // workgroups per CU -- unless the caller forces the path (force_tile64: tests exercise every orientation).
+    const bool big = d->M >= 48 && d->N >= 48 && d->K >= 64;
+    const bool pays = force_tile64 || (a_kc && b_kc && d->K >= 512);
+    p.cfg = (want_tile64 && big && pays && (a_kc || a_rc) && (b_kc || b_rc)) ? 1 : 0;
+    p.a_rc = !a_kc; p.b_rc = !b_kc;
+    const int t = p.cfg ? 64 : 32;
+    p.wg_n = (p.N + t - 1) / t;
+    const int wg_m = (p.M + t - 1) / t;
+    p.wg_nm = p.wg_n * wg_m;
     p.inv_wg_n = 1.0f / (float)(p.wg_n > 0 ? p.wg_n : 1);
     p.inv_wg_nm = 1.0f / (float)(p.wg_nm > 0 ? p.wg_nm : 1);
+    p.inv_wg_m = 1.0f / (float)(wg_m > 0 ? wg_m : 1);
     p.wg_begin = wg_total;
-    wg_total += p.wg_nm * d->batch;
+    p.tiles = p.wg_nm * d->batch;
+    wg_total += p.tiles;
     return PCRL_OK;
+}
+
+// Problems of a launch that could run as 64x64 tiles do so when together they give the chip enough workgroups: a 64x64
+// tile moves half the L2 bytes per FLOP of four 32x32 split-K tiles but is a quarter of the parallelism.
+static std::atomic<int> g_tile64_min{-1};
+static int tile64_min_tiles() {
+    int v = g_tile64_min.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("PCRL_GEMM_TILE64_MIN");
+        v = e ? atoi(e) : 192;
+        g_tile64_min.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+extern "C" int pcrl_gemm_set_tile64_min(int32_t min_tiles) {
+    const int prev = tile64_min_tiles();
+    if (min_tiles >= 0) g_tile64_min.store(min_tiles, std::memory_order_relaxed);
+    return prev;
 }
 
 extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream) {
     if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
     GemmGroup g{};
     int wg_total = 0;
-    for (int i = 0; i < n; ++i) {
-        const int rc = gemm_fill(&descs[i], g.p[g.n], wg_total);
-        if (rc != PCRL_OK) return rc;
-        g.wg_begin[g.n] = g.p[g.n].wg_begin;
-        if (descs[i].M > 0 && descs[i].N > 0) ++g.n;        // empty problems contribute no workgroups
+    for (int pass = 0; pass < 2; ++pass) {          // pass 0: everything eligible as 64x64 tiles; pass 1 (too few of them): 32x32
+        g = GemmGroup{};
+        wg_total = 0;
+        int tiles64 = 0;
+        for (int i = 0; i < n; ++i) {
+            const int rc = gemm_fill(&descs[i], g.p[g.n], wg_total, pass == 0, tile64_min_tiles() <= 1);
+            if (rc != PCRL_OK) return rc;
+            g.wg_begin[g.n] = g.p[g.n].wg_begin;
+            if (g.p[g.n].cfg == 1) tiles64 += g.p[g.n].wg_nm * descs[i].batch;
+            if (descs[i].M > 0 && descs[i].N > 0) ++g.n;        // empty problems contribute no workgroups
+        }
+        if (pass == 1 || tiles64 == 0 || tiles64 >= tile64_min_tiles()) break;
     }
     if (g.n == 0 || wg_total == 0) return PCRL_OK;
     if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), 0, (hipStream_t)stream, g);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), kGemmLdsBytes)) return rc;
+    bool any64 = false;
+    for (int i = 0; i < g.n; ++i) any64 = any64 || g.p[i].cfg == 1;
+    const size_t lds = any64 ? kGemmLdsBytes : kGemmLdsBytes32;      // a launch of 32x32 tiles only keeps several workgroups per CU
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
     PCRL_CHECK_LAUNCH("gemm_f32_kernel");
     return PCRL_OK;
 }

@@ -600,22 +600,13 @@ static size_t bwd_lds_bytes(int T0, int C1) {
 
 template <int T0, int C1, bool BF16>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
-    static bool attr_set = false;
     const size_t lds = bwd_lds_bytes(T0, C1);
     auto kern = encoder_bwd_points_kernel<T0, C1, BF16>;
-    if (!attr_set) {
-        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
     constexpr size_t wgrad_lds = 4 * 32 * 64 * sizeof(f32x4);        // h1 operand of one cloud: 128 KB at 256 active points
-    static bool wgrad_attr_set = false;
-    if (!wgrad_attr_set) {
-        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_bwd_wgrad_kernel<C1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)wgrad_lds));
-        wgrad_attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(encoder_bwd_wgrad_kernel<C1>), wgrad_lds)) return rc;
     hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid), dim3(512), wgrad_lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_wgrad_kernel");
     return PCRL_OK;

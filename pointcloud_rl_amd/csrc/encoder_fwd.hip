@@ -341,13 +341,9 @@ static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16) {
 
 template <int T0, int C1, int C2, int C3, bool BF16>
 static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
-    static bool attr_set = false;
     const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16);
     auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16>;
-    if (!attr_set) {
-        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_fwd_kernel");
     return PCRL_OK;

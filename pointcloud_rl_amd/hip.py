@@ -277,6 +277,12 @@ def gemm_group(descs):
         check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
 
 
+def gemm_set_tile64_min(min_tiles):
+    """Tuning knob of pcrl_gemm_group_f32 (include/pcrl.h): minimum number of 64x64 tiles in a launch for the LDS-staged
+    path; returns the previous value (negative argument: query only)."""
+    return lib().pcrl_gemm_set_tile64_min(int(min_tiles))
+
+
 def gemm(*args, **kwargs):
     """One GEMM launch; arguments as gemm_desc."""
     gemm_group([gemm_desc(*args, **kwargs)])

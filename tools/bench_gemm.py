@@ -32,16 +32,26 @@ def shapes():
     yield "K=1 dh2 x2", [hip.gemm_desc(t(M, 2), W2, t(2, M, H), M, H, 1, (2, 1), (H, 1), H, mask=h, ld_mask=H, batch=2, batch_strides=(1, H, M * H, 0, M * H))]
 
 
-for name, descs in shapes():
+def time_group(descs, n=200):
     for _ in range(5):
         hip.gemm_group(descs)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 200
     e0.record()
     for _ in range(n):
         hip.gemm_group(descs)
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / n * 1e3
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+print(f"{'shape':32s} {'32x32 split-K':>22s} {'64x64 LDS tiles':>22s} {'default':>22s}")
+for name, descs in shapes():
     flops = sum(2.0 * d.M * d.N * d.K * d.batch for d in descs)
-    print(f"{name:32s} {us:7.1f} us  {flops / us / 1e6:6.1f} TFLOP/s")
+    cols = []
+    for min_tiles in (1 << 30, 1, None):
+        prev = hip.gemm_set_tile64_min(-1 if min_tiles is None else min_tiles)
+        us = time_group(descs)
+        if min_tiles is not None:
+            hip.gemm_set_tile64_min(prev)
+        cols.append(f"{us:7.1f} us {flops / us / 1e6:6.1f} TF/s")
+    print(f"{name:32s} " + " ".join(f"{c:>22s}" for c in cols))
