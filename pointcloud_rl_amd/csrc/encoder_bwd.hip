@@ -8,8 +8,13 @@
 // c3 = 256 points per cloud.  This implementation is exact, not approximate: it visits only those
 // points.
 //
-//   kernel A (one workgroup per cloud, one wave per 32 active points)
-//     sort/unique the cloud's argmax -> active point list; recompute the forward chain for the
+//   prep (one 256-thread workgroup per cloud)
+//     the cloud's active point list = the distinct argmax points in ascending order (a bitmap in LDS and a prefix
+//     popcount: no sort), each channel's slot in it, and -- when the forward's pooled values are given -- the per-channel
+//     and per-point quantities of the LayerNorm-2 / max-pool backward; norm2's own gradients.
+//   kernel A (one wave per tile of 32 active points; the tiles of all clouds are dealt over the chip's waves, so a small
+//   batch still uses every CU and a SIMD holds at most ceil(tiles / SIMDs) of them)
+//     recompute the forward chain for the
 //     active points with the same MFMA chains as the forward kernel; LayerNorm/ReLU backward in
 //     the accumulator layout; input-gradient GEMMs chained in registers against transposed
 //     weight images; every weight-gradient operand (dz2, h1, dz1, h0, dz0, x|1) is written to a
@@ -66,6 +71,15 @@ struct BwdParams {
     float* pw;               // [B][GradLayout.total()]
     int* n_act;              // [B]
     float* grads;            // [GradLayout.total()]
+    // written by the prep kernel, read by kernel A
+    int* flag;               // [B] 1: per-channel shortcut valid for this cloud (pooled given, no lossy channel)
+    int* act;                // [B][kSlots] active point indices, ascending
+    unsigned char* slot;     // [B][kC3] slot of the channel's argmax point
+    float* dx;               // [B][kC3] dL/d(xhat2) of the channel at its argmax point
+    float2* pt;              // [B][kSlots] per active point: (sum dx, sum dx * xhat) over the channels it owns
+    float* n1part;           // [B][8][kC2][2] norm1 (dgamma, dbeta) partial sums per tile
+    int tile_mode;           // 1: B < #CUs, work items are single tiles found through a prefix sum of the clouds' tile counts
+    int parts;               // kernel B: workgroups per cloud (1, 2, 4 or 8; > 1 only for small batches)
 };
 
 template <int CTRL>
@@ -117,12 +131,158 @@ __host__ __device__ constexpr unsigned op_off(int arr_floats, int mb, int r) {
     return 4u * (unsigned)(arr_floats + mb * 32 * kPiece + ((r & 3) + 8 * (r >> 2)) * 4);
 }
 
-// BF16: the forward recompute contracts bf16 operands exactly as encoder_fwd_kernel<.., true> does (so that the LayerNorm
-// inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`) and so do the two data-gradient
-// GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
-// through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
+// ---- prep: active list, slots, per-channel / per-point sums of the pool + LayerNorm-2 backward --------------------------
+constexpr int kBitmapMaxWords = 8192;      // N <= 262 144 points per cloud
+// Called by EVERY thread of the block (256 threads in the stand-alone kernel, 512 in kernel A's prologue: threads >= 256 only
+// take part in the barriers).  s_words: [2 * nW] bitmap + prefix, s_scan: [256] ints (s_scan[255] = n_act on return),
+// s_slot: [kC3] bytes, s_dx / s_xh: [kC3] floats, s_flag: 1 int (on return 1 when the per-channel shortcut must not be used).
+template <int T0, int C1>
+__device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int tid_all, unsigned* s_words, int* s_scan, unsigned char* s_slot,
+                                               float* s_dx, float* s_xh, int* s_flag_p) {
+    constexpr PackedLayout L{T0, C1, kC2, kC3};
+    const GradLayout GL{p.cl.C, C1};
+    const int nW = (p.cl.N + 31) >> 5;
+    unsigned* s_pre = s_words + nW;
+    const bool on = tid_all < 256;
+    const int tid = on ? tid_all : 255;
+    int& s_flag = *s_flag_p;
+    // every global load of the cloud is issued up front (they are independent of the bitmap phase)
+    int pc = 0;
+    float y_in = 0.0f, g_in = 0.0f, gam = 1.0f, bet = 0.0f;
+    const bool have_pooled = p.pooled != nullptr;
+    if (on) {
+        pc = p.argmax[(long long)b * kC3 + tid];
+        if (have_pooled) {
+            y_in = p.pooled[(long long)b * kC3 + tid];
+            g_in = p.gpool[(long long)b * kC3 + tid];
+            gam = p.packed[L.ln2() + 2 * tid]; bet = p.packed[L.ln2() + 2 * tid + 1];
+        }
+    }
+    __syncthreads();
+    if (on) {
+        for (int w = tid; w < nW; w += 256) s_words[w] = 0u;
+        if (tid == 0) s_flag = 0;
+    }
+    __syncthreads();
+    pc = pc < 0 ? 0 : (pc >= p.cl.N ? p.cl.N - 1 : pc);
+    if (on) atomicOr(&s_words[pc >> 5], 1u << (pc & 31));
+    __syncthreads();
+    // exclusive prefix popcount over the words: each thread owns `per` consecutive words; the 256 per-thread counts are
+    // scanned inside each wave with DPP-free shuffles and the four wave totals are added through LDS (one barrier)
+    const int per = (nW + 255) >> 8, w0 = tid * per;
+    int local = 0;
+    for (int k = 0; k < per; ++k)
+        if (w0 + k < nW) local += __popc(s_words[w0 + k]);
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += v;
+    }
+    if (on && (tid & 63) == 63) s_scan[tid >> 6] = incl;
+    __syncthreads();
+    int wave_base = 0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+        if (w < (tid >> 6)) wave_base += s_scan[w];
+    if (tid_all == 255) s_scan[255] = wave_base + incl;
+    int run = wave_base + incl - local;
+    if (on)
+        for (int k = 0; k < per; ++k)
+            if (w0 + k < nW) { s_pre[w0 + k] = (unsigned)run; run += __popc(s_words[w0 + k]); }
+    __syncthreads();
+    const int n_act = s_scan[255];
+    const int slot = (int)s_pre[pc >> 5] + __popc(s_words[pc >> 5] & ((1u << (pc & 31)) - 1u));
+    if (on) {
+        s_slot[tid] = (unsigned char)slot;
+        p.slot[(long long)b * kC3 + tid] = (unsigned char)slot;
+        p.act[(long long)b * kSlots + slot] = pc;                   // every channel of the point writes the same value
+    }
+    // With the forward's pooled values the LayerNorm-2 / max-pool backward needs no search for "which of my 128 registers
+    // hold a channel I own": channel c contributes only at its argmax point, where y = pooled[c] (the recompute is
+    // bit-identical to the forward), so dL/dxhat_c = [y > 0] g_c gamma_c and xhat_c = (y - beta_c) / gamma_c are per-CHANNEL
+    // quantities, and a point's two sums are sums over the channels that name it.
+    float dyl = 0.0f, xh = 0.0f, dxc = 0.0f;
+    if (have_pooled && on) {
+        const float y = y_in, g = g_in;
+        const bool live = y > 0.0f;
+        dyl = live ? g : 0.0f;
+        // xhat = (y - beta) / gamma loses |beta| / |gamma| ulps by cancellation and is not recoverable at all through a
+        // zero gamma; a non-finite y carries no xhat either.  In those cases the whole cloud takes the dense path, which
+        // recomputes xhat at the point itself (the default affine, gamma ~ 1 / beta ~ 0, never gets here).
+        const bool lossy = __builtin_fabsf(gam) < 1e-3f || __builtin_fabsf(bet) > 8.0f * __builtin_fabsf(gam);
+        if ((live && lossy) || !(__builtin_fabsf(y) <= 3.0e38f)) s_flag = 1;
+        xh = (live && gam != 0.0f) ? (y - bet) / gam : 0.0f;
+        dxc = dyl * gam;
+    }
+    if (on) {
+        s_dx[tid] = dxc;
+        s_xh[tid] = xh;
+        p.dx[(long long)b * kC3 + tid] = dxc;
+    }
+    __syncthreads();
+    const bool use_pooled = have_pooled && s_flag == 0;
+    if (tid_all == 0) { p.n_act[b] = n_act; p.flag[b] = use_pooled ? 1 : 0; }
+    if (use_pooled && on) {
+        float* pw = p.pw + (long long)b * GL.total();
+        pw[GL.g2() + tid] = dyl * xh;                               // norm2.weight / norm2.bias gradients of this cloud
+        pw[GL.be2() + tid] = dyl;
+        if (tid < n_act) {
+            // The channels that name this point, in ascending order.  First a branch-free sweep over the slot table (four
+            // channels per word, sixteen words in flight) that only collects a 256-bit membership mask; then the few set
+            // bits (a point owns ~1.5 channels) are walked in order.  (Adding inside the sweep put ~250 divergent, dependent
+            // LDS round trips on every wave: 12 us.)
+            float t1 = 0.0f, t2 = 0.0f;
+            const unsigned* slot_w = reinterpret_cast<const unsigned*>(s_slot);
+            const unsigned me = (unsigned)tid * 0x01010101u;
+            unsigned mine[kC3 / 32];
+#pragma unroll
+            for (int j0 = 0; j0 < kC3 / 4; j0 += 16) {
+                unsigned w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = slot_w[j0 + j] ^ me;        // a zero byte marks a channel of this point
+                unsigned lo = 0u, hi = 0u;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    unsigned m4 = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m4 |= (((w[j] >> (8 * e)) & 0xFFu) == 0u ? 1u : 0u) << e;
+                    if (j < 8) lo |= m4 << (4 * j); else hi |= m4 << (4 * (j - 8));
+                }
+                mine[j0 / 8] = lo; mine[j0 / 8 + 1] = hi;
+            }
+#pragma unroll
+            for (int k = 0; k < kC3 / 32; ++k) {
+                unsigned m = mine[k];
+                while (m) {
+                    const int c = 32 * k + __builtin_ctz(m);
+                    m &= m - 1u;
+                    t1 = t1 + s_dx[c];
+                    t2 = __builtin_fmaf(s_dx[c], s_xh[c], t2);
+                }
+            }
+            p.pt[(long long)b * kSlots + tid] = float2{t1, t2};
+        }
+    }
+}
+
+template <int T0, int C1>
+__global__ __launch_bounds__(256) void encoder_bwd_prep_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned s_words[];   // [nW] bitmap, then [nW] exclusive prefix popcounts
+    __shared__ int s_scan[256];
+    __shared__ __attribute__((aligned(4))) unsigned char s_slot[kC3];
+    __shared__ float s_dx[kC3], s_xh[kC3];
+    __shared__ int s_flag;
+    for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x)
+        bwd_prep_cloud<T0, C1>(p, b, threadIdx.x, s_words, s_scan, s_slot, s_dx, s_xh, &s_flag);
+}
+
+// ---- kernel A, cloud mode (B >= #CUs): one workgroup per cloud, wave w takes the cloud's tile w --------------------------------
+// The cloud's tables (active list by a bitonic sort of the argmax keys, slots, per-channel / per-point sums) live in LDS and
+// are built by the workgroup itself.  Same per-tile chain as the tile-mode kernel below; kept as its own kernel because
+// every value the tile-mode kernel carries per wave (cloud index, table pointers, resources) is a spilled register here.
 template <int T0, int C1, bool BF16>
-__global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
+__global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
     constexpr OpsLayout OL{MB1};
@@ -458,6 +618,285 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     }
 }
 
+// ---- kernel A, tile mode (B < #CUs) ----------------------------------------------------------------------------------
+// BF16: the forward recompute contracts bf16 operands exactly as encoder_fwd_kernel<.., true> does (so that the LayerNorm
+// inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`) and so do the two data-gradient
+// GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
+// through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
+constexpr int kTileTabBytes = kC3 + 4 * kC3;       // per wave: slot bytes + dx floats of the tile's cloud
+constexpr int kMaxTileModeClouds = 256;           // tile mode needs the clouds' tile prefix in LDS
+template <int T0, int C1, bool BF16>
+__global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
+    constexpr PackedLayout L{T0, C1, kC2, kC3};
+    constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
+    constexpr OpsLayout OL{MB1};
+    const GradLayout GL{p.cl.C, C1};
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
+    char* s_tab = reinterpret_cast<char*>(s_desc + PCRL_MAX_CHANNELS);             // [8 waves][kTileTabBytes]
+    int* s_tstart = reinterpret_cast<int*>(s_tab + 8 * kTileTabBytes);            // [kMaxTileModeClouds + 8] tile prefix (tile mode)
+    float* s_ln1 = reinterpret_cast<float*>(s_tstart + kMaxTileModeClouds + 8);
+    float* s_ln2 = s_ln1 + 2 * kC2;
+    float* s_b0 = s_ln2 + 2 * kC3;
+    float* s_w0 = s_b0 + C1;
+    float* s_w2 = s_w0 + MB1 * T0 * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    {
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
+        f32x4* s = reinterpret_cast<f32x4*>(s_w2);
+        stage_to_lds<512, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
+        for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
+        for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
+        for (int i = tid; i < 2 * kC2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
+        for (int i = tid; i < 2 * kC3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
+        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
+        if (tid == 0) {           // exclusive prefix of the clouds' tile counts (B <= 256: a serial walk is ~1 us)
+            int run = 0;
+            for (int b = 0; b < p.cl.B; ++b) { s_tstart[b] = run; run += (p.n_act[b] + 31) >> 5; }
+            s_tstart[p.cl.B] = run;
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
+    unsigned char* s_slot = reinterpret_cast<unsigned char*>(s_tab + wave * kTileTabBytes);
+    float* s_dx = reinterpret_cast<float*>(s_slot + kC3);
+
+    // Work items: the tiles of all clouds form one list and wave w of workgroup g takes item w * grid + g, so the first
+    // `grid` items go to wave 0 of every workgroup (one tile per SIMD before any SIMD gets a second one).  With B < #CUs
+    // there are at most 8 * B <= 8 * grid items: one per wave at most.
+    {
+        int b, tile, n_act;
+        const int item = wave * (int)gridDim.x + (int)blockIdx.x;
+        if (item >= s_tstart[p.cl.B]) return;
+        {
+            int lo = 0, hi = p.cl.B;             // largest b with s_tstart[b] <= item
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tstart[mid] <= item) lo = mid; else hi = mid; }
+            b = lo; tile = item - s_tstart[lo];
+        }
+        n_act = p.n_act[b];
+        const bool use_pooled = p.flag[b] != 0;
+        // this wave's copy of the cloud's tables
+        reinterpret_cast<unsigned*>(s_slot)[lane] = reinterpret_cast<const unsigned*>(p.slot + (long long)b * kC3)[lane];
+        reinterpret_cast<f32x4*>(s_dx)[lane] = reinterpret_cast<const f32x4*>(p.dx + (long long)b * kC3)[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        b = __builtin_amdgcn_readfirstlane(b);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        n_act = __builtin_amdgcn_readfirstlane(n_act);
+        const float* g_row = p.gpool + (long long)b * kC3;
+
+        float* pw = p.pw + (long long)b * GL.total();
+        const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(p.ops + (long long)b * OL.total(), 4u * (unsigned)OL.total());
+        const __amdgpu_buffer_rsrc_t r_xs = make_rsrc(p.xs + (long long)b * kXsFloats, 4u * (unsigned)kXsFloats);
+        {
+            const int s = 32 * tile + l31;
+            const bool valid = s < n_act;
+            const int pidx = p.act[(long long)b * kSlots + (valid ? s : n_act - 1)];
+            const unsigned s_match = valid ? (unsigned)s : 0xFFFFu;   // never equals a slot byte when invalid
+            // lane-dependent byte offset of an operand element: octet q = s >> 3, k-lane (s >> 2) & 1, k-slot s & 3
+            const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
+            const unsigned xs_off = 4u * (unsigned)(tile * 64 * 64 + lane);
+
+            const f32x16 x = load_point<T0>(p.cl, s_desc, b, pidx);
+            if (half == 0) {   // B operand of the conv0 weight gradient: rows = input channels, row C = 1 (bias)
+#pragma unroll
+                for (int c = 0; c < 2 * T0; ++c)
+                    if (c < p.cl.C) buf_store_f1(r_ops, lane_off, 4u * (unsigned)(OL.xb() + c * 4), x[c]);
+                buf_store_f1(r_ops, lane_off + 16u * (unsigned)p.cl.C, 4u * (unsigned)OL.xb(), 1.0f);
+            }
+            const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
+            // ---- forward recompute: conv0 + ReLU -------------------------------------------------
+            f32x16 a0[MB1];
+            unsigned mask0[MB1];
+#pragma unroll
+            for (int mb = 0; mb < MB1; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const float bop = half_select(x[2 * t], x[2 * t + 1], half_mask);
+                    a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
+                }
+                mask0[mb] = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    a0[mb][r] = relu_nan(a0[mb][r]);
+                    mask0[mb] |= (a0[mb][r] > 0.0f ? 1u : 0u) << r;
+                    buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
+                }
+            }
+            // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
+            f32x16 a1[MB2];
+            if (BF16)
+                dense_layer_bf16<MB2, C1 / 16>(
+                    a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, C1 / 8, 3>(
+                    a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            const float rstd1 = ln_to_xhat<kC2>(a1, p.eps);
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb) {
+                float2 gbv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gbv[r] = reinterpret_cast<const float2*>(s_ln1)[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    buf_store_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64), a1[mb][r]);
+                    a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
+                    buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
+                }
+            }
+            // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
+            f32x16 a2[MB3];
+            if (BF16)
+                dense_layer_bf16<MB3, kC2 / 16>(
+                    a2, [&](int mb, int g) { return s_w2v[(mb * (kC2 / 16) + g) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB3, kC2 / 8, 2>(
+                    a2, [&](int mb, int tq) { return s_w2v[(mb * (kC2 / 8) + tq) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            const float rstd2 = ln_to_xhat<kC3>(a2, p.eps);
+
+            // ---- max-pool + ReLU + LN2 backward ----------------------------------------------------
+            // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
+            // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
+            // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
+            unsigned long long own[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)tile);
+            float m1, m2;
+            if (use_pooled) {                       // the point's sums were formed per channel before the tiles
+                const float2 t = p.pt[(long long)b * kSlots + (valid ? s : 0)];
+                m1 = valid ? t.x / (float)kC3 : 0.0f;      // padding lanes of the last tile own nothing: their dz must stay 0
+                m2 = valid ? t.y / (float)kC3 : 0.0f;
+            } else {
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch0 = acc_chan(mb * 16 + r, 0);
+                        if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {      // channel ch0 or ch0 + 4 owned in this tile
+                            const int ch = ch0 + 4 * half;
+                            const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
+                            const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
+                            const bool mine = (unsigned)s_slot[ch] == s_match;
+                            const float dyl = (mine && y > 0.0f) ? g_row[ch] : 0.0f;
+                            // exactly one point per channel contributes: norm2's gradients of this cloud (dense path only: with the
+                            // per-channel shortcut the prep kernel has written them)
+                            if (mine) { pw[GL.g2() + ch] = dyl * a2[mb][r]; pw[GL.be2() + ch] = dyl; }
+                            const float dx = dyl * gb.x;
+                            s1 = s1 + dx;
+                            s2 = __builtin_fmaf(dx, a2[mb][r], s2);
+                        }
+                    }
+                float lo, hi;
+                both_halves(s1, lo, hi);
+                m1 = (lo + hi) / (float)kC3;
+                both_halves(s2, lo, hi);
+                m2 = (lo + hi) / (float)kC3;
+            }
+            const float cA = -(rstd2 * m2), cB = -(rstd2 * m1);     // dz = rstd*dx - rstd*m1 - xhat*rstd*m2
+#pragma unroll
+            for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch0 = acc_chan(mb * 16 + r, 0);
+                    float dz = __builtin_fmaf(a2[mb][r], cA, cB);
+                    if ((own[ch0 >> 6] >> (ch0 & 63)) & 0x11ull) {
+                        const int ch = ch0 + 4 * half;
+                        const bool mine = (unsigned)s_slot[ch] == s_match;
+                        float dx;
+                        if (use_pooled) {                       // the channel's dL/dxhat is already in the table
+                            dx = mine ? s_dx[ch] : 0.0f;
+                        } else {
+                            const float2 gb = reinterpret_cast<const float2*>(s_ln2)[ch];
+                            const float y = __builtin_fmaf(a2[mb][r], gb.x, gb.y);
+                            dx = ((mine && y > 0.0f) ? g_row[ch] : 0.0f) * gb.x;
+                        }
+                        dz = __builtin_fmaf(rstd2, dx, dz);
+                    }
+                    a2[mb][r] = dz;
+                    buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
+                }
+            // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
+            f32x16 d1[MB2];
+            if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
+                dense_layer_bf16<MB2, kC3 / 16>(
+                    d1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2tb() + (mb * (kC3 / 16) + g) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, kC3 / 8, 3>(
+                    d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
+            f32x16 xh1[MB2];
+            float s1 = 0.0f, s2 = 0.0f, lo, hi;
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb)           // all 64 reloads of xhat1 in flight at once
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xh1[mb][r] = buf_load_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64));
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb) {
+                float2 gbv[16]; float tg[16], tb[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gbv[r] = reinterpret_cast<const float2*>(s_ln1)[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float y = __builtin_fmaf(xh1[mb][r], gbv[r].x, gbv[r].y);
+                    const float dyl = y > 0.0f ? d1[mb][r] : 0.0f;
+                    tg[r] = dyl * xh1[mb][r];          // norm1.weight / norm1.bias gradients: summed over this tile's 32 points below
+                    tb[r] = dyl;
+                    const float dx = dyl * gbv[r].x;
+                    d1[mb][r] = dx;
+                    s1 = s1 + dx;
+                    s2 = __builtin_fmaf(dx, xh1[mb][r], s2);
+                }
+                allreduce_add32_x16(tg);
+                allreduce_add32_x16(tb);
+                if (l31 == 0) {        // this tile's partial sums; kernel B adds a cloud's tiles in tile order
+                    float2* n1 = reinterpret_cast<float2*>(p.n1part) + ((long long)b * 8 + tile) * kC2;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) n1[acc_chan(mb * 16 + r, 0) + 4 * half] = float2{tg[r], tb[r]};
+                }
+            }
+            both_halves(s1, lo, hi);
+            const float n1 = (lo + hi) / (float)kC2;
+            both_halves(s2, lo, hi);
+            const float n2 = (lo + hi) / (float)kC2;
+#pragma unroll
+            for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    d1[mb][r] = rstd1 * ((d1[mb][r] - n1) - xh1[mb][r] * n2);
+                    buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
+                }
+            // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
+            f32x16 d0[MB1];
+            if (BF16)
+                dense_layer_bf16<MB1, kC2 / 16>(
+                    d0, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1tb() + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB1, kC2 / 8, 3>(
+                    d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
+#pragma unroll
+            for (int mb = 0; mb < MB1; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
+        }
+    }
+}
+
 // ---- kernel B: per-cloud weight-gradient GEMMs ------------------------------------------------
 // out[32 x 32 block (mb, nb)] = sum over slots of A[32mb + i][slot] * Bm[32nb + j][slot]
 // b_block_stride: distance between two column blocks of the B operand in 16-byte units (32 * 64 in the global workspace,
@@ -471,27 +910,37 @@ __device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, BPtr b
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     const f32x4* a4 = reinterpret_cast<const f32x4*>(A) + (long long)mb * 32 * 64 + lane;
     const auto b4 = b4_base + lane;
-    // the operands of octet q + 1 are in flight while the 4 * NB MFMAs of octet q issue
-    f32x4 a_nxt = {0.f, 0.f, 0.f, 0.f}, b_nxt[NB];
-    if (n_oct > 0) {
-        a_nxt = a4[0];
+    // the operands of octets q + 1 .. q + D are in flight while the 4 * NB MFMAs of octet q issue: an L2 round trip is longer
+    // than one octet's MFMAs (16 x 64 cycles), so a single octet of look-ahead left the matrix pipe waiting every iteration
+    constexpr int D = 3;
+    f32x4 ar[D], br[D][NB];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) b_nxt[n] = b4[(nb0 + n) * b_block_stride];
-    }
-    for (int q = 0; q < n_oct; ++q) {
-        const f32x4 a = a_nxt;
-        f32x4 bv[NB];
+    for (int d = 0; d < D; ++d)
+        if (d < n_oct) {
+            ar[d] = a4[d * 64];
 #pragma unroll
-        for (int n = 0; n < NB; ++n) bv[n] = b_nxt[n];
-        if (q + 1 < n_oct) {
-            a_nxt = a4[(q + 1) * 64];
-#pragma unroll
-            for (int n = 0; n < NB; ++n) b_nxt[n] = b4[(nb0 + n) * b_block_stride + (q + 1) * 64];
+            for (int n = 0; n < NB; ++n) br[d][n] = b4[(nb0 + n) * b_block_stride + d * 64];
         }
+    for (int q0 = 0; q0 < n_oct; q0 += D) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int d = 0; d < D; ++d) {
+            const int q = q0 + d;
+            if (q < n_oct) {
+                const f32x4 a = ar[d];
+                f32x4 bv[NB];
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[n][j], acc[n], 0, 0, 0);
+                for (int n = 0; n < NB; ++n) bv[n] = br[d][n];
+                if (q + D < n_oct) {
+                    ar[d] = a4[(q + D) * 64];
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) br[d][n] = b4[(nb0 + n) * b_block_stride + (q + D) * 64];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[n][j], acc[n], 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -506,6 +955,32 @@ __device__ __forceinline__ void store_tile(float* out, int ld, int mb, int nb, i
     }
 }
 
+// conv0.weight [C1][C] and conv0.bias (column C of the x|1 operand), row block mb.
+__device__ __forceinline__ void wgrad_conv0(const BwdParams& p, const float* ops, float* pw, const GradLayout& GL, int dz0_off, int xb_off,
+                                            int mb, int n_oct, int lane) {
+    f32x16 acc;
+    // rows of the x|1 block beyond C are never written by kernel A: mask them out of the B operand
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(ops + dz0_off) + (long long)mb * 32 * 64 + lane;
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(ops + xb_off) + lane;
+    const bool live = (lane & 31) <= p.cl.C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int q = 0; q < n_oct; ++q) {
+        const f32x4 a = a4[q * 64];
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (live) bv = b4[q * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (col < p.cl.C) pw[GL.w0() + row * p.cl.C + col] = acc[r];
+        else if (col == p.cl.C) pw[GL.b0() + row] = acc[r];
+    }
+}
+
 template <int C1>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdParams p) {
     constexpr int MB1 = C1 / 32;
@@ -513,10 +988,37 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
     const GradLayout GL{p.cl.C, C1};
     extern __shared__ __attribute__((aligned(16))) f32x4 s_h1[];      // [4][n_oct][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x) {
+    const int P = p.parts;
+    for (int item = blockIdx.x; item < p.cl.B * P; item += gridDim.x) {
+        const int b = item / P, part = item - b * P;
         const float* ops = p.ops + (long long)b * OL.total();
         float* pw = p.pw + (long long)b * GL.total();
-        const int n_oct = ((p.n_act[b] + 31) / 32) * 4;
+        const int n_tiles = (p.n_act[b] + 31) / 32, n_oct = n_tiles * 4;
+        if (p.tile_mode && part == 0 && tid < 2 * kC2) {   // norm1 gradients: fixed-order sum over the cloud's tiles (one partial per tile)
+            const float* n1 = p.n1part + (long long)b * 8 * kC2 * 2;
+            float acc = 0.0f;
+            for (int t = 0; t < n_tiles; ++t) acc = acc + n1[t * kC2 * 2 + tid];
+            pw[((tid & 1) ? GL.be1() : GL.g1()) + (tid >> 1)] = acc;
+        }
+        if (P > 1) {
+            // Small batch: the cloud's 32 + 4 MB1 + MB1 output blocks are dealt one at a time over the 8 P waves of its P
+            // workgroups (operands straight from L2; every block is one chain of n_oct * 4 MFMAs).
+            const int n_tasks = 32 + 4 * MB1 + MB1;
+            for (int t = part * 8 + wave; t < n_tasks; t += 8 * P) {
+                f32x16 acc[1];
+                if (t < 32) {
+                    wgrad_blocks<1>(ops + OL.dz2(), reinterpret_cast<const f32x4*>(ops + OL.h1()), 32 * 64, t >> 2, t & 3, n_oct, lane, acc);
+                    store_tile(pw + GL.w2(), kC2, t >> 2, t & 3, kC2, acc[0], lane);
+                } else if (t < 32 + 4 * MB1) {
+                    const int u = t - 32;
+                    wgrad_blocks<1>(ops + OL.dz1(), reinterpret_cast<const f32x4*>(ops + OL.h0()), 32 * 64, u / MB1, u % MB1, n_oct, lane, acc);
+                    store_tile(pw + GL.w1(), C1, u / MB1, u % MB1, C1, acc[0], lane);
+                } else {
+                    wgrad_conv0(p, ops, pw, GL, OL.dz0(), OL.xb(), t - 32 - 4 * MB1, n_oct, lane);
+                }
+            }
+            continue;
+        }
         {   // conv2.weight [256][128]: wave w owns row block w, all 4 column blocks.  Every wave contracts against the whole
             // of h1, so the cloud's h1 operand (4 blocks x n_oct KB) is staged in LDS once instead of being fetched from L2
             // by each of the 8 waves.
@@ -540,30 +1042,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
 #pragma unroll
             for (int n = 0; n < NB; ++n) store_tile(pw + GL.w1(), C1, mb, nb0 + n, C1, acc[n], lane);
         }
-        if (wave < MB1) {   // conv0.weight [C1][C] and conv0.bias (column C of the x|1 operand)
-            f32x16 acc[1];
-            // rows of the x|1 block beyond C are never written by kernel A: mask them out of the B operand
-            const float* xb = ops + OL.xb();
-            const f32x4* a4 = reinterpret_cast<const f32x4*>(ops + OL.dz0()) + (long long)wave * 32 * 64 + lane;
-            const f32x4* b4 = reinterpret_cast<const f32x4*>(xb) + lane;
-            const bool live = (lane & 31) <= p.cl.C;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
-            for (int q = 0; q < n_oct; ++q) {
-                const f32x4 a = a4[q * 64];
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (live) bv = b4[q * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc[0], 0, 0, 0);
-            }
-            const int col = lane & 31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (col < p.cl.C) pw[GL.w0() + row * p.cl.C + col] = acc[0][r];
-                else if (col == p.cl.C) pw[GL.b0() + row] = acc[0][r];
-            }
-        }
+        if (wave < MB1) wgrad_conv0(p, ops, pw, GL, OL.dz0(), OL.xb(), wave, n_oct, lane);
     }
 }
 
@@ -593,27 +1072,46 @@ __global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* _
     }
 }
 
-static size_t bwd_lds_bytes(int T0, int C1) {
+static size_t bwd_lds_bytes_cloud(int T0, int C1) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kSlots + 32 + kC3 + 4 * (size_t)kC3 +
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + 2 * (size_t)kC3 + 3 * (size_t)kSlots + (size_t)kC3 * kC2);
 }
 
+static size_t bwd_lds_bytes_tile(int T0, int C1) {
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)kTileTabBytes + 4 * (size_t)(kMaxTileModeClouds + 8) +
+           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + (size_t)kC3 * kC2);
+}
+
 template <int T0, int C1, bool BF16>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
-    const size_t lds = bwd_lds_bytes(T0, C1);
-    auto kern = encoder_bwd_points_kernel<T0, C1, BF16>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
-    PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
+    if (p.tile_mode) {
+        // small batch: prep (tables) -> one wave per tile, dealt over every CU
+        const int nW = (p.cl.N + 31) / 32;
+        auto prep = encoder_bwd_prep_kernel<T0, C1>;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
+        hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(256), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
+        PCRL_CHECK_LAUNCH("encoder_bwd_prep_kernel");
+        const size_t lds = bwd_lds_bytes_tile(T0, C1);
+        auto kern = encoder_bwd_points_kernel<T0, C1, BF16>;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, stream, p);
+        PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
+    } else {
+        const size_t lds = bwd_lds_bytes_cloud(T0, C1);
+        auto kern = encoder_bwd_points_cloud_kernel<T0, C1, BF16>;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+        PCRL_CHECK_LAUNCH("encoder_bwd_points_cloud_kernel");
+    }
     constexpr size_t wgrad_lds = 4 * 32 * 64 * sizeof(f32x4);        // h1 operand of one cloud: 128 KB at 256 active points
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(encoder_bwd_wgrad_kernel<C1>), wgrad_lds)) return rc;
-    hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid), dim3(512), wgrad_lds, stream, p);
+    hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid * p.parts), dim3(512), wgrad_lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_wgrad_kernel");
     return PCRL_OK;
 }
 
 struct BwdWorkspace {
-    size_t ops, xs, pw, nact, total;
+    size_t ops, xs, pw, nact, flag, act, slot, dx, pt, n1part, total;
 };
 static BwdWorkspace bwd_workspace(int B, int C, int C1) {
     const OpsLayout OL{C1 / 32};
@@ -624,7 +1122,13 @@ static BwdWorkspace bwd_workspace(int B, int C, int C1) {
     w.xs = al(w.ops + sizeof(float) * (size_t)B * OL.total());
     w.pw = al(w.xs + sizeof(float) * (size_t)B * kXsFloats);
     w.nact = al(w.pw + sizeof(float) * (size_t)B * GL.total());
-    w.total = al(w.nact + sizeof(int) * (size_t)B);
+    w.flag = al(w.nact + sizeof(int) * (size_t)B);
+    w.act = al(w.flag + sizeof(int) * (size_t)B);
+    w.slot = al(w.act + sizeof(int) * (size_t)B * kSlots);
+    w.dx = al(w.slot + (size_t)B * kC3);
+    w.pt = al(w.dx + sizeof(float) * (size_t)B * kC3);
+    w.n1part = al(w.pt + sizeof(float2) * (size_t)B * kSlots);
+    w.total = al(w.n1part + sizeof(float) * (size_t)B * 8 * kC2 * 2);
     return w;
 }
 
@@ -670,7 +1174,14 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.argmax = argmax; p.gpool = grad_pooled; p.pooled = pooled;
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);
+    p.flag = reinterpret_cast<int*>(base + ws.flag); p.act = reinterpret_cast<int*>(base + ws.act);
+    p.slot = reinterpret_cast<unsigned char*>(base + ws.slot); p.dx = reinterpret_cast<float*>(base + ws.dx);
+    p.pt = reinterpret_cast<float2*>(base + ws.pt); p.n1part = reinterpret_cast<float*>(base + ws.n1part);
     p.grads = grads;
+    if (p.cl.N > 32 * kBitmapMaxWords) return fail(PCRL_E_ARG, "encoder backward: N = %d > %d points per cloud", p.cl.N, 32 * kBitmapMaxWords);
+    p.tile_mode = (p.cl.B < num_cus() && p.cl.B <= kMaxTileModeClouds) ? 1 : 0;
+    p.parts = 1;
+    while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;
 
     const int grid = min(p.cl.B, num_cus());
     const int T0 = (p.cl.C + 1) / 2;
