@@ -53,8 +53,11 @@ typedef struct pcrl_feat_seg {
 /* A batch of B clouds of N points; channels are the concatenation of the
  * segments in order (torch.cat(feature, dim=-2), pointnet.py:63).  Segment 0
  * must be xyz (3 channels, f32) when an augmentation is requested. */
+/* row_div > 1: cloud b reads the stored cloud b / row_div of every segment, i.e. the batch is the stored batch with each cloud
+ * repeated row_div times in place (DrQ: GDict(obs).repeat(num_aug, 0), drq.py:52-60 -- the copies differ only by their
+ * augmentation, which is indexed by b itself).  B counts the clouds the encoder sees (stored clouds * row_div). */
 typedef struct pcrl_cloud_desc {
-    int32_t B, N, nseg, _pad;
+    int32_t B, N, nseg, row_div;
     pcrl_feat_seg seg[PCRL_MAX_SEG];
 } pcrl_cloud_desc;
 
@@ -244,6 +247,7 @@ typedef struct pcrl_ln_job {
     float* dst[4]; int64_t ld_dst[4];
     float* xhat; float* rstd;
     const float* cat_src[2]; float* cat_dst[2]; int64_t cat_ld_src[2], cat_ld_dst[2]; int32_t cat_n[2];
+    int32_t cat_row_div[2];        /* > 1: destination row m takes source row m / cat_row_div (a source stored once per sample, used by each of its augmentations) */
 } pcrl_ln_job;
 int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_t n_jobs, const float* gamma, const float* beta, int32_t F,
                                       float eps, void* stream);
@@ -283,8 +287,10 @@ int pcrl_tanh_gaussian_bwd_f32(const float* feat, int64_t ld_feat, const float* 
  *   y = r*reward_scale + (1-done)*gamma*(min_h q_next + exp(log_alpha)*neg_logp_next)  [mean over each
  *   group of `group` consecutive rows], loss = mse_loss(q, y)*H, dq = d loss / d q,
  *   stats = {loss, max|q-y|, mean_b min_h q, mean y}. */
+/* rd_row_div > 1: rewards / dones hold one row per SAMPLE and row b reads entry b / rd_row_div (DrQ without materialising
+ * the repeat_interleave of drq.py:61-63); 0 or 1: one entry per row. */
 int pcrl_sac_critic_loss_f32(const float* q_next, int64_t ld_q_next, const float* neg_logp_next, const float* rewards,
-                             const uint8_t* dones, const float* log_alpha, float gamma, float reward_scale,
+                             const uint8_t* dones, int32_t rd_row_div, const float* log_alpha, float gamma, float reward_scale,
                              int32_t ignore_dones, int32_t group, const float* q, int64_t ld_q, int32_t B, int32_t H,
                              float* q_target, float* dq, int64_t ld_dq, float* stats, void* stream);
 /* Actor and temperature losses (sac.py:177-195): actor_loss = -(mean_b min_h q_pi + alpha*mean neg_logp),

@@ -22,7 +22,7 @@ class FeatSeg(ctypes.Structure):
 
 
 class CloudDesc(ctypes.Structure):
-    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("nseg", ctypes.c_int32), ("_pad", ctypes.c_int32),
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("nseg", ctypes.c_int32), ("row_div", ctypes.c_int32),
                 ("seg", FeatSeg * PCRL_MAX_SEG)]
 
 
@@ -50,7 +50,7 @@ class LnJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
                 ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
                 ("cat_src", ctypes.c_void_p * 2), ("cat_dst", ctypes.c_void_p * 2), ("cat_ld_src", ctypes.c_int64 * 2),
-                ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2)]
+                ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2), ("cat_row_div", ctypes.c_int32 * 2)]
 
 
 class GatherSeg(ctypes.Structure):

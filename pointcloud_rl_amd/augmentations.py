@@ -11,7 +11,7 @@ from collections.abc import Sequence
 import numpy as np
 import torch
 
-from .networks.pointnet import AugmentedObs
+from .networks.pointnet import AugmentedObs, batch_rows
 from .utils.registry import Registry, build_from_cfg
 
 AUGMENTATIONS = Registry("data augmentation")
@@ -55,7 +55,13 @@ def build_data_augmentations(cfg, default_args=None):
 def _as_augmented(data):
     out = AugmentedObs(data)
     out.aug = dict(getattr(data, "aug", None) or {})
+    out.repeat = int(getattr(data, "repeat", 1) or 1)
     return out
+
+
+def _batch_shape(data):
+    """Shape of the xyz tensor the augmentation acts on: [rows of the (virtually repeated) batch, 3, N]."""
+    return (batch_rows(data),) + tuple(data["xyz"].shape[1:])
 
 
 class _PointAug:
@@ -91,7 +97,7 @@ class RandomJitterPoints(_PointAug):
         out = _as_augmented(data)
         if self.noise_override:
             noise = self.noise_override.pop(0)
-            assert noise.shape == data["xyz"].shape, f"{noise.shape} vs {data['xyz'].shape}"
+            assert tuple(noise.shape) == _batch_shape(data), f"{tuple(noise.shape)} vs {_batch_shape(data)}"
             out.aug["jitter_noise"] = noise.to(device=data["xyz"].device, dtype=torch.float32).contiguous()
         else:
             dev = data["xyz"].device
@@ -213,7 +219,7 @@ class GlobalRotScaleTrans(_PointAug):
         if self.matrix_override:
             mat = self.matrix_override.pop(0)
         else:
-            mat = self.sample_matrix(data["xyz"].shape[0], data["xyz"].device)
+            mat = self.sample_matrix(batch_rows(data), data["xyz"].device)
         if self.translation_range is None:
             mat = mat.clone()
             mat[..., :3, 3] = 0

@@ -481,7 +481,7 @@ struct LnJob {
     float* xhat; float* rstd;            // saved for backward (may be NULL)
     // optional pass-through columns (robot state / replay actions of Visuomotor's torch.cat, visuomotor.py:130-141):
     // cat_dst[m][0..cat_n) = cat_src[m][0..cat_n)
-    const float* cat_src[2]; float* cat_dst[2]; long long cat_lds[2], cat_ldd[2]; int cat_n[2];
+    const float* cat_src[2]; float* cat_dst[2]; long long cat_lds[2], cat_ldd[2]; int cat_n[2], cat_div[2];
 };
 constexpr int kLnJobs = 3;
 struct LnParams {
@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_fwd_kernel(const LnParams 
 #pragma unroll
     for (int c = 0; c < 2; ++c)
         if (jb.cat_src[c])
-            for (int f = lane; f < jb.cat_n[c]; f += 64) jb.cat_dst[c][(long long)row * jb.cat_ldd[c] + f] = jb.cat_src[c][(long long)row * jb.cat_lds[c] + f];
+            for (int f = lane; f < jb.cat_n[c]; f += 64)
+                jb.cat_dst[c][(long long)row * jb.cat_ldd[c] + f] = jb.cat_src[c][(long long)(row / jb.cat_div[c]) * jb.cat_lds[c] + f];
 }
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma, where dy is the
@@ -715,6 +716,7 @@ extern "C" int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_
             if (s.cat_n[c] > 0 && (!s.cat_src[c] || !s.cat_dst[c])) return fail(PCRL_E_ARG, "NULL pass-through columns");
             d.cat_src[c] = s.cat_n[c] > 0 ? s.cat_src[c] : nullptr; d.cat_dst[c] = s.cat_dst[c];
             d.cat_lds[c] = s.cat_ld_src[c]; d.cat_ldd[c] = s.cat_ld_dst[c]; d.cat_n[c] = s.cat_n[c];
+            d.cat_div[c] = s.cat_row_div[c] > 1 ? s.cat_row_div[c] : 1;
         }
         blocks += (s.M + 3) / 4;
     }

@@ -20,6 +20,7 @@ struct CloudParams {
     int B, N, C;
     int aug_flags;
     int row_mul, row_add;     // augmentation row of cloud b = b * row_mul + row_add
+    int row_div;              // cloud b reads the stored cloud b / row_div (>= 1)
     float jitter_lo, jitter_hi;
     const float* jitter_noise;
     const float* affine;
@@ -53,8 +54,9 @@ template <int T0>
 __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc* s_desc, int b, int n) {
     f32x16 x;
     const int n_src = p.point_index ? p.point_index[n] : n;
+    const int b_src = p.row_div > 1 ? b / p.row_div : b;      // b is wave-uniform: one scalar division per tile
 #pragma unroll
-    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n_src) : 0.0f;
+    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b_src, n_src) : 0.0f;
     const long long row = (long long)b * p.row_mul + p.row_add;
     if (p.aug_flags & PCRL_AUG_AFFINE) {
         const float* M = p.affine + row * 12;

@@ -301,6 +301,8 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
     CloudParams& p = *out;
     p = CloudParams{};
     p.B = clouds->B; p.N = clouds->N;
+    p.row_div = clouds->row_div > 1 ? clouds->row_div : 1;
+    if (p.B % p.row_div) return fail(PCRL_E_ARG, "B=%d is not a multiple of row_div=%d", p.B, p.row_div);
     int c = 0;
     for (int s = 0; s < clouds->nseg; ++s) {
         const pcrl_feat_seg& sg = clouds->seg[s];

@@ -113,6 +113,7 @@ struct CriticLossParams {
     const float* q_next; long long ld_qn;   // [B][H]
     const float* neg_logp_next;             // [B]
     const float* rewards; const unsigned char* dones;
+    int rd_div;                             // row b reads rewards / dones entry b / rd_div
     const float* log_alpha;                 // device scalar
     float gamma, reward_scale; int ignore_dones, group;   // group = num_aug (DrQ target mean), 1 for SAC
     const float* q; long long ld_q;         // [B][H]
@@ -133,8 +134,9 @@ __global__ __launch_bounds__(1024) void critic_loss_kernel(const CriticLossParam
             float mn = p.q_next[(long long)b * p.ld_qn];
             for (int hh = 1; hh < p.H; ++hh) mn = fminf(mn, p.q_next[(long long)b * p.ld_qn + hh]);
             mn = mn + alpha * p.neg_logp_next[b];
-            const float r = p.rewards[b] * p.reward_scale;
-            const float y = p.ignore_dones ? r + p.gamma * mn : r + (1.0f - (p.dones[b] ? 1.0f : 0.0f)) * p.gamma * mn;
+            const int e = b / p.rd_div;
+            const float r = p.rewards[e] * p.reward_scale;
+            const float y = p.ignore_dones ? r + p.gamma * mn : r + (1.0f - (p.dones[e] ? 1.0f : 0.0f)) * p.gamma * mn;
             ymean += y;
         }
         ymean = p.group > 1 ? ymean / (float)p.group : ymean;
@@ -303,13 +305,13 @@ extern "C" int pcrl_tanh_gaussian_bwd_f32(const float* feat, int64_t ld_feat, co
 }
 
 extern "C" int pcrl_sac_critic_loss_f32(const float* q_next, int64_t ld_q_next, const float* neg_logp_next, const float* rewards,
-                                        const uint8_t* dones, const float* log_alpha, float gamma, float reward_scale,
+                                        const uint8_t* dones, int32_t rd_row_div, const float* log_alpha, float gamma, float reward_scale,
                                         int32_t ignore_dones, int32_t group, const float* q, int64_t ld_q, int32_t B, int32_t H,
                                         float* q_target, float* dq, int64_t ld_dq, float* stats, void* stream) {
     if (!q_next || !neg_logp_next || !rewards || !log_alpha || !q || !q_target || !dq || !stats) return fail(PCRL_E_ARG, "NULL argument");
     if (!ignore_dones && !dones) return fail(PCRL_E_ARG, "dones is NULL");
     if (B < 1 || H < 1 || group < 1 || B % group) return fail(PCRL_E_ARG, "bad shape B=%d H=%d group=%d", B, H, group);
-    CriticLossParams p{q_next, ld_q_next, neg_logp_next, rewards, dones, log_alpha, gamma, reward_scale, ignore_dones, group, q, ld_q, B, H, q_target, dq, ld_dq, stats};
+    CriticLossParams p{q_next, ld_q_next, neg_logp_next, rewards, dones, rd_row_div > 1 ? rd_row_div : 1, log_alpha, gamma, reward_scale, ignore_dones, group, q, ld_q, B, H, q_target, dq, ld_dq, stats};
     hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("critic_loss_kernel");
     return PCRL_OK;

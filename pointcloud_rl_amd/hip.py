@@ -75,6 +75,7 @@ def make_cloud_desc(obs):
     """Describe the observation dict PointCloudBase.preprocess consumes (reference
     pyrl/networks/backbones/pointnet.py:49-73): keys xyz [B,3,N] f32, rgb [B,3,N] u8|f32,
     pos_encoding [B,F,N], seg [B,K,N]; or a bare xyz tensor.  Returns (desc, tensors kept alive)."""
+    repeat = int(getattr(obs, "repeat", 1) or 1)      # VirtualRepeat: every stored cloud is seen `repeat` times (DrQ)
     if torch.is_tensor(obs):
         obs = {"xyz": obs}
     keep, segs = [], []
@@ -95,7 +96,7 @@ def make_cloud_desc(obs):
                     stride_b=t.stride(0), stride_c=t.stride(1), stride_n=t.stride(2))
         segs.append(s)
         keep.append(t)
-    desc = CloudDesc(B=B, N=N, nseg=len(segs))
+    desc = CloudDesc(B=B * repeat, N=N, nseg=len(segs), row_div=repeat)
     for i, s in enumerate(segs):
         desc.seg[i] = s
     return desc, keep
@@ -307,9 +308,11 @@ def layernorm_rows_fwd_multi(jobs, gamma, beta, F, eps):
             j.dst[i], j.ld_dst[i] = t.data_ptr() + 4 * off, ld
         j.xhat = job["xhat"].data_ptr() if job.get("xhat") is not None else None
         j.rstd = job["rstd"].data_ptr() if job.get("rstd") is not None else None
-        for c, (src, dst, off, ld) in enumerate(job.get("cats", [])):
+        for c, cat in enumerate(job.get("cats", [])):
+            src, dst, off, ld = cat[:4]
             assert src.dtype == torch.float32 and src.stride(-1) == 1
             j.cat_src[c], j.cat_dst[c], j.cat_ld_src[c], j.cat_ld_dst[c], j.cat_n[c] = src.data_ptr(), dst.data_ptr() + 4 * off, src.stride(0), ld, src.shape[1]
+            j.cat_row_div[c] = int(cat[4]) if len(cat) > 4 else 1        # source stored once per sample, read by each augmentation row
     check(lib().pcrl_layernorm_rows_fwd_multi_f32(arr, len(jobs), _ptr(gamma), _ptr(beta), F, _f(eps), _stream()))
 
 
@@ -353,8 +356,8 @@ def tanh_gaussian_bwd(feat, ld_feat, eps, saved, scale, B, A, ls_min, ls_max, ep
 
 
 def sac_critic_loss(q_next, ld_qn, neg_logp_next, rewards, dones_u8, log_alpha, gamma, reward_scale, ignore_dones, group, q, ld_q, B, H,
-                    q_target, dq, ld_dq, stats):
-    check(lib().pcrl_sac_critic_loss_f32(_ptr(q_next), ctypes.c_int64(ld_qn), _ptr(neg_logp_next), _ptr(rewards), _ptr(dones_u8), _ptr(log_alpha),
+                    q_target, dq, ld_dq, stats, rd_row_div=1):
+    check(lib().pcrl_sac_critic_loss_f32(_ptr(q_next), ctypes.c_int64(ld_qn), _ptr(neg_logp_next), _ptr(rewards), _ptr(dones_u8), int(rd_row_div), _ptr(log_alpha),
                                          _f(gamma), _f(reward_scale), int(ignore_dones), int(group), _ptr(q), ctypes.c_int64(ld_q), B, H,
                                          _ptr(q_target), _ptr(dq), ctypes.c_int64(ld_dq), _ptr(stats), _stream()))
 

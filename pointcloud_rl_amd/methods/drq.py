@@ -16,14 +16,31 @@ from .sac import SAC
 
 
 def repeat_obs(obs, n):
-    """GDict(obs).repeat(n, 0): repeat_interleave of every leaf (reference array_ops.py:106-121)."""
+    """GDict(obs).repeat(n, 0): repeat_interleave of every leaf (reference array_ops.py:106-121) -- materialised; only the
+    autograd fallback path uses it."""
     return {k: torch.repeat_interleave(v, n, dim=0) for k, v in obs.items()}
 
 
+def virtual_repeat(obs, n):
+    """The same batch without the copies: the stored observation plus the factor.  The encoder kernel reads stored cloud
+    b // n for cloud b (pcrl_cloud_desc.row_div) and the fused step reads robot state / actions / rewards / dones of sample
+    b // n, so DrQ's eleven repeat_interleave launches per step disappear."""
+    out = AugmentedObs(obs)
+    out.aug = dict(getattr(obs, "aug", None) or {})
+    out.repeat = n * int(getattr(obs, "repeat", 1) or 1)
+    return out
+
+
 def first_augmentation(obs, batch_size, num_aug):
-    """GDict(obs).split_axis(0, [B, -1]).slice(0, 1): augmentation #0 of every sample (drq.py:115),
-    as strided views; the augmentation rows are remapped so the noise is the one the critic saw."""
-    out = AugmentedObs({k: v.reshape(batch_size, num_aug, *v.shape[1:])[:, 0] for k, v in obs.items()})
+    """GDict(obs).split_axis(0, [B, -1]).slice(0, 1): augmentation #0 of every sample (drq.py:115); the augmentation rows
+    are remapped so the noise is the one the critic saw.  A virtually repeated batch simply drops the factor; a
+    materialised one is viewed with a stride."""
+    repeat = int(getattr(obs, "repeat", 1) or 1)
+    if repeat > 1:
+        assert repeat == num_aug
+        out = AugmentedObs(obs)
+    else:
+        out = AugmentedObs({k: v.reshape(batch_size, num_aug, *v.shape[1:])[:, 0] for k, v in obs.items()})
     aug = getattr(obs, "aug", None)
     if aug:
         out.aug = dict(aug, row_mul=num_aug * aug.get("row_mul", 1), row_add=aug.get("row_add", 0))
@@ -42,8 +59,8 @@ class DrQ(SAC):
         self.obs_aug = build_data_augmentations(obs_aug)
         self.inference_aug = self.obs_aug if inference_aug == "same" else build_data_augmentations(inference_aug)
 
-    def _augment(self, obs):
-        obs = repeat_obs(obs, self.num_aug)
+    def _augment(self, obs, virtual=False):
+        obs = virtual_repeat(obs, self.num_aug) if virtual else repeat_obs(obs, self.num_aug)
         return self.obs_aug(obs) if self.obs_aug is not None else obs
 
     @torch.no_grad()
@@ -54,15 +71,15 @@ class DrQ(SAC):
 
     def _step_body(self, batch, do_actor, polyak):
         B = batch["actions"].shape[0]
+        if self._fused is not None:
+            args, kwargs = self._fused_args(batch, do_actor, polyak)
+            return self._fused.run(*args, **kwargs)
         with torch.no_grad():
             obs = self._augment(batch["obs"])
             actions = torch.repeat_interleave(batch["actions"], self.num_aug, dim=0)
             next_obs = self._augment(batch["next_obs"])
             rewards = torch.repeat_interleave(batch["rewards"], self.num_aug, dim=0)
             dones = torch.repeat_interleave(batch["dones"], self.num_aug, dim=0)
-        if self._fused is not None:
-            return self._fused.run(obs, next_obs, actions, rewards, dones, do_actor, polyak, group=self.num_aug,
-                                   actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
         stats = {}
         q_target = self._q_target(next_obs, rewards, dones, n_groups=B)
         self._critic_step(obs, actions, q_target, stats, polyak=polyak)
@@ -71,15 +88,14 @@ class DrQ(SAC):
         return stats
 
     def _fused_args(self, batch, do_actor, polyak):
+        """Nothing is repeated: observations carry the factor (virtual_repeat), actions / rewards / dones stay one row per
+        sample and the kernels index them by row // num_aug (`repeat=`)."""
         B = batch["actions"].shape[0]
         with torch.no_grad():
-            obs = self._augment(batch["obs"])
-            actions = torch.repeat_interleave(batch["actions"], self.num_aug, dim=0)
-            next_obs = self._augment(batch["next_obs"])
-            rewards = torch.repeat_interleave(batch["rewards"], self.num_aug, dim=0)
-            dones = torch.repeat_interleave(batch["dones"], self.num_aug, dim=0)
-        return (obs, next_obs, actions, rewards, dones, do_actor, polyak), dict(
-            group=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
+            obs = self._augment(batch["obs"], virtual=True)
+            next_obs = self._augment(batch["next_obs"], virtual=True)
+        return (obs, next_obs, batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), dict(
+            group=self.num_aug, repeat=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
 
     def update_parameters(self, memory, updates):
         if self._flat is None:

@@ -186,7 +186,7 @@ class FusedStep:
     def _features(self, jobs):
         """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
         jobs = [(pooled, M, tag, dsts, save, cats)]; the Linear GEMMs share one launch and so do the LayerNorms, which
-        also drop the pass-through columns `cats` = [(src [M, n], dst buffer, dst column)] (robot state, replay actions:
+        also drop the pass-through columns `cats` = [(src [M / div, n], dst buffer, dst column[, div])] (robot state, replay actions:
         Visuomotor's torch.cat, visuomotor.py:130-141) into the head inputs.  Returns [(xhat, rstd)]."""
         fc, off, F, c3 = self.a._flat["critic"], self.off, self.F, self.c3
         pre = "values.0.backbone.visual_nn.final_mlp."
@@ -197,10 +197,11 @@ class FusedStep:
         for (_, M, tag, dsts, save, cats), y in zip(jobs, ys):
             xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
             rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
-            pending = [(src if src.dtype == torch.float32 else src.float(), dst, col, dst.shape[1]) for src, dst, col in cats if src is not None]
+            pending = [(c[0] if c[0].dtype == torch.float32 else c[0].float(), c[1], c[2], c[1].shape[1], c[3] if len(c) > 3 else 1)
+                       for c in cats if c[0] is not None]
             while len(pending) > 2:                      # the kernel takes two pass-through blocks per job
-                src, dst, col, _ = pending.pop()
-                dst[:, col:col + src.shape[1]].copy_(src)
+                src, dst, col, _, div = pending.pop()
+                dst[:, col:col + src.shape[1]].copy_(torch.repeat_interleave(src, div, dim=0) if div > 1 else src)
             ln_jobs.append(dict(x=y, ldx=F, M=M, dsts=dsts, xhat=xhat, rstd=rstd, cats=pending))
             out.append((xhat, rstd))
         hip.layernorm_rows_fwd_multi(ln_jobs, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps)
@@ -242,7 +243,7 @@ class FusedStep:
         except StopIteration as done:
             return done.value
 
-    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None):
+    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None, repeat=1):
         """Generator form of the step: yields the flat gradient buffers that have to be all-reduced at
         that point (empty list when single-process semantics suffice) and receives the factor 1/world
         to fold into the optimizer pass.  Between two yields no cross-rank communication happens, so
@@ -252,7 +253,9 @@ class FusedStep:
         ldq, lda = self.ldq, self.lda
         fc, fa = a._flat["critic"], a._flat["actor"]
         split = type(a.actor.backbone).split_obs
-        M = actions.shape[0]
+        # repeat > 1 (DrQ): obs / next_obs are virtually repeated (AugmentedObs.repeat) and actions / rewards / dones / robot
+        # state hold one row per SAMPLE: row m of the step's batch reads entry m // repeat
+        M = actions.shape[0] * repeat
         stats = {}
 
         # ---- target y = r + (1-d) gamma (min_h Q'(s', a') + alpha * (-log pi(a'|s')))  (sac.py:110-134) and q = Q(s, a)
@@ -265,8 +268,8 @@ class FusedStep:
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
         XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
         (_, _), (xhat, rstd) = self._features([
-            (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F), (state_n, XQ_n, F)]),
-            (pooled_o, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F), (actions, XQ_o, F + S)])])
+            (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F, repeat), (state_n, XQ_n, F, repeat)]),
+            (pooled_o, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F, repeat), (actions, XQ_o, F + S, repeat)])])
         _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
@@ -281,7 +284,7 @@ class FusedStep:
         dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
         hip.sac_critic_loss(q_next, 2, nlp_n, rewards, dones_u8, a.log_alpha, a.gamma,
                             a.reward_scale if a.metric_prefix == "sac" else 1.0, a.ignore_dones, group, q, 2, M, 2,
-                            q_target, dq, 2, self.stats_c)
+                            q_target, dq, 2, self.stats_c, rd_row_div=repeat)
         dh1, dh2 = self._buf("q_dh1", 2, M, H), self._buf("q_dh2", 2, M, H)
         dX0 = self._buf("q_dX0", 2, M, ceil4(F))
         mlp_backward(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F), ld_dx=ceil4(F))

@@ -10,6 +10,8 @@ is executed:
     backward when data-parallel);
   * all returned metrics come from one device->host copy at the end of the step.
 """
+import contextlib
+import gc
 from copy import deepcopy
 
 import numpy as np
@@ -23,6 +25,20 @@ from ..networks import build_actor_critic, build_target_network
 from ..utils.dist import allreduce_sum_, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
+
+
+@contextlib.contextmanager
+def _no_gc():
+    """Python's cyclic collector must not run inside a stream capture: collecting a cycle that holds a tensor allocated
+    outside the graph's pool frees it mid-capture and the caching allocator aborts the process (seen as a flaky
+    'Fatal Python error: Aborted ... Garbage-collecting' under torch.cuda.graph, which only collects once on entry)."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class FlatBuffer:
@@ -478,7 +494,7 @@ class SAC(BaseAgent):
         graph = torch.cuda.CUDAGraph()
         host = None
         pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
-        with torch.cuda.graph(graph):
+        with _no_gc(), torch.cuda.graph(graph):
             stats = self._step_body(batch, do_actor, polyak)
             names = list(stats.keys())
             packed = getattr(stats, "packed", None)
@@ -499,7 +515,7 @@ class SAC(BaseAgent):
             graph = torch.cuda.CUDAGraph()
             exchange = []
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+            with _no_gc(), torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                 try:
                     if gen is None:     # batch preparation (DrQ: repeat + augmentation draws) belongs to the first segment
                         args, kwargs = self._fused_args(batch, do_actor, polyak)

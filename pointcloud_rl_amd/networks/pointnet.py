@@ -20,8 +20,17 @@ class LayerNorm1D(nn.LayerNorm):
 
 class AugmentedObs(dict):
     """Observation dict that carries a not-yet-applied point-cloud augmentation.  The encoder
-    kernel applies `aug` while loading xyz, so the augmented cloud is never materialised."""
+    kernel applies `aug` while loading xyz, so the augmented cloud is never materialised.
+    repeat > 1: every stored sample stands for `repeat` consecutive rows of the batch (DrQ's
+    GDict(obs).repeat(num_aug, 0), drq.py:52-60, without the copies): the encoder reads stored cloud b // repeat for
+    cloud b, the augmentation parameters are per row of the repeated batch."""
     aug = None           # dict(jitter_noise=, jitter_range=, seed=, offset=, affine=)
+    repeat = 1
+
+
+def batch_rows(obs):
+    """Rows of the batch an observation dict stands for (stored rows x repeat)."""
+    return obs["xyz"].shape[0] * int(getattr(obs, "repeat", 1) or 1)
 
 
 def materialize(obs):
@@ -29,6 +38,9 @@ def materialize(obs):
     fused encoder, e.g. visualisation); returns a plain dict."""
     aug = dict(getattr(obs, "aug", None) or {})
     out = dict(obs)
+    repeat = int(getattr(obs, "repeat", 1) or 1)
+    if repeat > 1:
+        out = {k: (torch.repeat_interleave(v, repeat, dim=0) if torch.is_tensor(v) else v) for k, v in out.items()}
     index = aug.pop("point_index", None)
     if index is not None:          # RandomDownSample: the same points of every key
         out = {k: (v[..., index.long()] if torch.is_tensor(v) and v.ndim == 3 else v) for k, v in out.items()}

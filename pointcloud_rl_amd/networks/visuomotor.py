@@ -33,52 +33,57 @@ class Visuomotor(ExtendedModule):
         self.saved_feature = None
         self.saved_visual_feature = None
 
-    @staticmethod
-    def split_obs(obs):
-        """(visual part, robot state): drops *_box/*_seg/*_sem_label/visual_state keys and pops
-        "state"/"agent" (visuomotor.py:80-91)."""
-        assert isinstance(obs, dict), f"obs is not a dict! {type(obs)}"
-        obs = copy(obs)
-        for key in list(obs.keys()):
-            if "_box" in key or "_seg" in key or "_sem_label" in key or key == "visual_state":
-                obs.pop(key)
-        robot_state = None
-        for key in ("state", "agent"):
-            if key in obs:
-                assert robot_state is None, f"Please provide only one robot state! Obs Keys: {list(obs.keys())}"
-                robot_state = obs.pop(key)
-        if not ("xyz" in obs or "rgb" in obs or "rgbd" in obs):
-            assert len(obs) == 1, f"Observations need to contain only one visual element! Obs Keys: {obs.keys()}!"
-            obs = obs[list(obs.keys())[0]]
-        return obs, robot_state
+    _DROPPED_SUFFIXES = ("_box", "_seg", "_sem_label")
+    _STATE_KEYS = ("state", "agent")
+
+    @classmethod
+    def split_obs(cls, obs):
+        """(what the visual encoder sees, robot state or None).  Keys naming boxes / segment ids / semantic labels and
+        "visual_state" never reach the encoder, "state" / "agent" is the robot state, and an observation without any
+        point-cloud / image key must consist of exactly one entry, which is handed over bare (reference
+        visuomotor.py:80-96).  The result keeps the class and attributes of `obs` (pending augmentation, virtual repeat)."""
+        if not isinstance(obs, dict):
+            raise AssertionError(f"obs is not a dict! {type(obs)}")
+        state_keys = [k for k in cls._STATE_KEYS if k in obs]
+        if len(state_keys) > 1:
+            raise AssertionError(f"Please provide only one robot state! Obs Keys: {list(obs.keys())}")
+        visual = copy(obs)
+        for key in list(visual.keys()):
+            if key in state_keys or key == "visual_state" or any(tag in key for tag in cls._DROPPED_SUFFIXES):
+                del visual[key]
+        if not any(k in visual for k in ("xyz", "rgb", "rgbd")):
+            if len(visual) != 1:
+                raise AssertionError(f"Observations need to contain only one visual element! Obs Keys: {visual.keys()}!")
+            visual = next(iter(visual.values()))
+        return visual, (obs[state_keys[0]] if state_keys else None)
+
+    def _encode(self, visual, visual_feature, detach_visual):
+        if visual_feature is not None:
+            return visual_feature
+        encoded = self.visual_nn(visual)
+        return encoded.detach() if detach_visual else encoded
 
     def forward(self, obs, actions=None, feature=None, visual_feature=None, prev_actions=None, save_feature=False,
                 detach_visual=False, rnn_mode="base", rnn_states=None, episode_dones=None, is_valid=None,
                 with_robot_state=True, **kwargs):
-        assert not (feature is not None and visual_feature is not None), "You cannot provide visual_feature and feature at the same time!"
-        self.saved_feature = None
-        self.saved_visual_feature = None
-        save_feature = save_feature or (feature is not None or visual_feature is not None)
-        obs, robot_state = self.split_obs(obs)
-        if feature is None:
-            if visual_feature is None:
-                feat = self.visual_nn(obs)
-                if detach_visual:
-                    feat = feat.detach()
-            else:
-                feat = visual_feature
-            if save_feature:
-                self.saved_visual_feature = feat.clone()
-            if robot_state is not None and with_robot_state:
-                assert feat.ndim == robot_state.ndim, "Visual feature and state vector should have the same dimension!"
-                feat = torch.cat([feat, robot_state], dim=-1)
-            if save_feature:
-                self.saved_feature = feat.clone()
-        else:
-            feat = feature
+        """encoder -> [detach] -> ++ robot state -> ++ (embedded) action -> dense head; `feature=` skips everything up to the
+        action, `visual_feature=` only the encoder.  Whenever a feature is handed in, or save_feature is set, copies of the
+        visual feature and of the feature with the robot state are left in saved_visual_feature / saved_feature."""
+        if feature is not None and visual_feature is not None:
+            raise AssertionError("You cannot provide visual_feature and feature at the same time!")
+        self.saved_feature = self.saved_visual_feature = None
+        keep = save_feature or feature is not None or visual_feature is not None
+        visual, robot_state = self.split_obs(obs)
+        x = feature
+        if x is None:
+            x = self._encode(visual, visual_feature, detach_visual)
+            if keep:
+                self.saved_visual_feature = x.clone()
+            if with_robot_state and robot_state is not None:
+                assert x.ndim == robot_state.ndim, "Visual feature and state vector should have the same dimension!"
+                x = torch.cat((x, robot_state), dim=-1)
+            if keep:
+                self.saved_feature = x.clone()
         if actions is not None:
-            actions = self.ac_feat(actions) if self.ac_feat is not None else actions
-            feat = torch.cat([feat, actions], dim=-1)
-        if self.final_mlp is not None:
-            feat = self.final_mlp(feat)
-        return feat
+            x = torch.cat((x, actions if self.ac_feat is None else self.ac_feat(actions)), dim=-1)
+        return x if self.final_mlp is None else self.final_mlp(x)

@@ -144,6 +144,18 @@ def test_critic_and_actor_loss(cuda, group):
     np.testing.assert_allclose(dq.cpu().numpy(), qt.grad.numpy(), atol=1e-7, rtol=1e-5)
     want = [loss.item(), (qt - yy).abs().max().item(), qt.min(-1).values.mean().item(), yy.mean().item()]
     np.testing.assert_allclose(stats.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    if group > 1:
+        # rewards / dones stored once per sample, read by row // group (DrQ without the repeat_interleave): same bits when
+        # the per-row arrays are the per-sample arrays repeated
+        r_s, done_s = g.randn(B // group).astype(np.float32), g.rand(B // group) < 0.2
+        outs = []
+        for rr, dd, div in ((np.repeat(r_s, group), np.repeat(done_s, group), 1), (r_s, done_s, group)):
+            oy, odq, ost = torch.empty(B, device=cuda), torch.empty(B, H, device=cuda), torch.empty(4, device=cuda)
+            hip.sac_critic_loss(T(qn, cuda), H, T(nlp, cuda), T(rr, cuda), T(dd.astype(np.uint8), cuda), torch.tensor([log_alpha], device=cuda),
+                                gamma, rs, False, group, T(q, cuda), H, B, H, oy, odq, H, ost, rd_row_div=div)
+            outs.append((oy, odq, ost))
+        for x, y_ in zip(*outs):
+            assert torch.equal(x, y_)
     # actor / alpha loss
     qp = torch.from_numpy(q).requires_grad_(True)
     nl = torch.from_numpy(nlp).requires_grad_(True)
@@ -162,9 +174,9 @@ def test_critic_and_actor_loss(cuda, group):
 
 
 def test_gemm_group_matches_single_launches(cuda, gemm_path):
+    """dW|db, dx and two unrelated shapes in one launch give the same bits as separate launches."""
     if gemm_path == "auto":
         pytest.skip("a group and its single launches may pick different tile shapes (different summation order)")
-    """dW|db, dx and two unrelated shapes in one launch give the same bits as separate launches."""
     from pointcloud_rl_amd import hip
     g = np.random.RandomState(5)
     M, K, N = 256, 1024, 1024
@@ -205,6 +217,14 @@ def test_layernorm_rows_multi_job_with_pass_through_columns(cuda):
         jobs.append(dict(x=X, ldx=Fd, M=M, dsts=[(dst, 0, 64)], cats=[(ST, dst, Fd, 64), (AC, dst, Fd + 5, 64)], keep=(X, ST, AC, dst)))
         ref = F.layer_norm(torch.from_numpy(x), (Fd,), G.cpu(), Bt.cpu(), 1e-5)
         wants.append(np.concatenate([ref.numpy(), st, ac, np.zeros((M, 64 - Fd - 11), np.float32)], 1))
+    # a job whose pass-through sources hold one row per SAMPLE and are read by row // 2 (DrQ's virtual repeat)
+    M = 64
+    x, st, ac = g.randn(M, Fd).astype(np.float32), g.randn(M // 2, 5).astype(np.float32), g.randn(M // 2, 6).astype(np.float32)
+    X, ST, AC = T(x, cuda), T(st, cuda), T(ac, cuda)
+    dst = torch.zeros(M, 64, device=cuda)
+    jobs.append(dict(x=X, ldx=Fd, M=M, dsts=[(dst, 0, 64)], cats=[(ST, dst, Fd, 64, 2), (AC, dst, Fd + 5, 64, 2)], keep=(X, ST, AC, dst)))
+    ref = F.layer_norm(torch.from_numpy(x), (Fd,), G.cpu(), Bt.cpu(), 1e-5)
+    wants.append(np.concatenate([ref.numpy(), np.repeat(st, 2, 0), np.repeat(ac, 2, 0), np.zeros((M, 64 - Fd - 11), np.float32)], 1))
     hip.layernorm_rows_fwd_multi(jobs, G, Bt, Fd, 1e-5)
     for job, want in zip(jobs, wants):
         np.testing.assert_allclose(job["keep"][3].cpu().numpy(), want, atol=2e-6, rtol=1e-5)

@@ -191,3 +191,36 @@ def test_fwd_bf16_matches_rounding_emulation(cuda, B, N, extra, c1):
     # and it is a different function from the fp32 kernel only by rounding
     pooled32, _ = _run_hip(obs, w, cuda)
     assert 1e-5 < np.abs(pooled - pooled32).max() < 0.15
+
+
+def test_virtual_repeat_equals_materialised_repeat(cuda):
+    """pcrl_cloud_desc.row_div (DrQ's repeat without the copies): cloud b reads stored cloud b // 2 with its own jitter row --
+    pooled, argmax and the backward's gradients are bitwise those of the repeat_interleave'd batch."""
+    import torch
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.networks.pointnet import AugmentedObs
+    B, N, rep = 5, 300, 2
+    obs_np = make_obs(B, N, seed=21, seg=1)
+    w = {k: torch.from_numpy(v).to(cuda) for k, v in make_encoder_weights(7, 128, 128, 256, seed=4).items()}
+    ew, _ = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    noise = torch.empty(B * rep, 3, N, device=cuda).uniform_(-0.01, 0.01)
+    gp = torch.randn(B * rep, 256, device=cuda)
+
+    def run(o):
+        desc, keep = hip.make_cloud_desc(o)
+        aug = hip.make_aug_desc(jitter_noise=noise)
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug)
+        grads = hip.encoder_bwd(desc, ew, packed, argmax, gp, aug=aug, pooled=pooled)
+        return pooled, argmax, grads
+
+    virt = AugmentedObs(obs)
+    virt.repeat = rep
+    mat = {k: torch.repeat_interleave(v, rep, dim=0) for k, v in obs.items()}
+    a, b = run(virt), run(mat)
+    assert a[0].shape == (B * rep, 256)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert not torch.equal(a[0][0], a[0][1])          # the two augmentations of a sample differ (their jitter rows do)
