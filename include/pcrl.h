@@ -79,7 +79,12 @@ typedef struct pcrl_cloud_desc {
  *            pcd_aug.py:231-257 + array_ops.py:659-680); N becomes n_index and the returned argmax counts
  *            positions of the subsampled cloud, as it does in the reference where the tensors are sliced.
  *            Jitter noise / Philox counters are indexed by the subsampled position. */
-enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2, PCRL_AUG_SUBSAMPLE = 4 };
+/*  COLOR     : ColorJitterPoints (pcd_aug.py:269-303): torchvision's ColorJitter on the uint8 rgb key viewed as a
+ *            [B,3,1,N] image batch -- brightness / contrast / saturation / hue applied in the drawn order with ONE set of
+ *            factors for the whole batch, uint8 truncation after every step, the contrast step blending with the cloud's
+ *            own grayscale mean (color_mean, from pcrl_color_contrast_mean_u8).  Segment 1 must be rgb (3 x uint8). */
+enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2, PCRL_AUG_SUBSAMPLE = 4, PCRL_AUG_COLOR = 8 };
+enum { PCRL_COLOR_BRIGHTNESS = 0, PCRL_COLOR_CONTRAST = 1, PCRL_COLOR_SATURATION = 2, PCRL_COLOR_HUE = 3, PCRL_COLOR_SKIP = 15 };
 typedef struct pcrl_aug_desc {
     int32_t flags, row_mul, row_add, _pad;
     const float* jitter_noise;
@@ -89,7 +94,11 @@ typedef struct pcrl_aug_desc {
     const uint64_t* offset_ptr;   /* device; when non-NULL the Philox offset is read from here at run
                                      time (a launch replayed from a hipGraph then draws fresh noise) */
     const int32_t* point_index;   /* device [n_index], values in [0, N): PCRL_AUG_SUBSAMPLE */
-    int32_t n_index, _pad2;
+    int32_t n_index;
+    int32_t color_order;          /* PCRL_AUG_COLOR: four PCRL_COLOR_* step ids, 4 bits each, lowest nibble first */
+    float color_factor[4];        /* brightness, contrast, saturation factors (blend ratios) and the hue shift */
+    float color_one_minus[4];     /* (float)(1.0 - (double)factor) for the three blends, as torch forms it; [3] unused */
+    const float* color_mean;      /* device [stored clouds]: grayscale mean entering the contrast step (NULL when contrast is skipped) */
 } pcrl_aug_desc;
 
 /* Weights of the shared per-point MLP in the reference's own state_dict layout
@@ -200,6 +209,14 @@ int pcrl_segmax_bwd_f32(const float* grad_out, const int32_t* idx, int64_t rows,
 /* RandomJitterPoints / GlobalRotScaleTrans applied to a [B,3,N] f32 tensor (in place when xyz_out ==
  * xyz_in): pcd_aug.py:306-327, 84-123.  Same pcrl_aug_desc semantics as the fused encoder load. */
 int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t B, int32_t N, const pcrl_aug_desc* aug, void* stream);
+/* ColorJitterPoints on a [B,3,N] uint8 tensor (strides in elements).  pcrl_color_contrast_mean_u8 applies the steps that
+ * precede the contrast step and returns each cloud's mean grayscale value at that point (mean_out [B] f32; the
+ * reduction over the N points of a cloud is the one thing the fused encoder load cannot do on the fly);
+ * pcrl_color_jitter_u8 materialises the jittered tensor (rgb_out may alias rgb_in).  Only flags / color_* of `aug` are read. */
+int pcrl_color_contrast_mean_u8(const uint8_t* rgb, int64_t stride_b, int64_t stride_c, int64_t stride_n, int32_t B, int32_t N,
+                                const pcrl_aug_desc* aug, float* mean_out, void* stream);
+int pcrl_color_jitter_u8(const uint8_t* rgb_in, uint8_t* rgb_out, int64_t stride_b, int64_t stride_c, int64_t stride_n, int32_t B, int32_t N,
+                         const pcrl_aug_desc* aug, void* stream);
 
 /* ---- dense heads --------------------------------------------------------------------------------
  * Batched fp32 GEMM  C[z] = epilogue(A[z] . B[z])  with generic operand strides (elements):

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PCRL_HIP_LIB") or os.path.join(_HERE, "libpcrl_hip.so
 PCRL_MAX_SEG = 4
 PCRL_MAX_CHANNELS = 16
 DT_F32, DT_U8, DT_BOOL = 0, 1, 2
-AUG_JITTER, AUG_AFFINE, AUG_SUBSAMPLE = 1, 2, 4
+AUG_JITTER, AUG_AFFINE, AUG_SUBSAMPLE, AUG_COLOR = 1, 2, 4, 8
 
 
 class FeatSeg(ctypes.Structure):
@@ -31,7 +31,8 @@ class AugDesc(ctypes.Structure):
                 ("jitter_noise", ctypes.c_void_p),
                 ("jitter_lo", ctypes.c_float), ("jitter_hi", ctypes.c_float),
                 ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p),
-                ("offset_ptr", ctypes.c_void_p), ("point_index", ctypes.c_void_p), ("n_index", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
+                ("offset_ptr", ctypes.c_void_p), ("point_index", ctypes.c_void_p), ("n_index", ctypes.c_int32), ("color_order", ctypes.c_int32),
+                ("color_factor", ctypes.c_float * 4), ("color_one_minus", ctypes.c_float * 4), ("color_mean", ctypes.c_void_p)]
 
 
 class EncoderWeights(ctypes.Structure):

@@ -159,6 +159,63 @@ class RandomDownSample:
         return f"{type(self).__name__}(max_num_points={self.max_num_points})"
 
 
+@AUGMENTATIONS.register_module()
+class ColorJitterPoints:
+    """torchvision's ColorJitter on the rgb key (pcd_aug.py:269-303): the reference views rgb [B,3,N] (uint8, as the replay
+    stores it) as an image batch [B,3,1,N] and applies ONE draw -- a random order of brightness / contrast / saturation / hue
+    and one factor each -- to the whole batch, in torchvision's uint8 arithmetic.  Here the draw is made with the same torch
+    calls in the same order (`randperm(4)`, then a `uniform_` per enabled factor, from torch's global generator) and
+    travels with the observation; the encoder kernel jitters each point's colour while loading it.  The one quantity that
+    is not per point -- the contrast step blends with the cloud's own grayscale mean -- comes from a small pre-pass over
+    rgb (3 B/point).  Arithmetic restated from torchvision 0.14.1 (oracle/color_jitter_ref.py); torchvision itself is not
+    installable here, so parity against it is unpinned."""
+
+    def __init__(self, main_key="inputs/rgb", req_keys="inputs/rgb", brightness=0.5, contrast=0.5, saturation=0.5, hue=0.5):
+        self.main_key = main_key
+        self.req_keys = [req_keys] if isinstance(req_keys, str) else list(req_keys or [main_key])
+        if list(self.req_keys) != ["rgb"] or main_key != "rgb":
+            raise NotImplementedError("the fused colour jitter acts on the 'rgb' key of a point-cloud observation "
+                                      "(main_key='rgb', req_keys=['rgb'], as in configs/mfrl/drq/*/pn_colorjitter.py)")
+        for name, v, hi in (("brightness", brightness, 1), ("contrast", contrast, 1), ("saturation", saturation, 1), ("hue", hue, 0.5)):
+            if v < 0 or v > hi:
+                raise ValueError(f"{name} shoud be non-negative")
+        self.brightness, self.contrast, self.saturation, self.hue = brightness, contrast, saturation, hue
+
+        def rng(value, center, clip=True):          # torchvision ColorJitter._check_input
+            lo, hi = center - float(value), center + float(value)
+            lo = max(lo, 0.0) if clip else lo
+            return None if lo == hi == center else (lo, hi)
+        self.ranges = [rng(brightness, 1.0), rng(contrast, 1.0), rng(saturation, 1.0), rng(hue, 0.0, clip=False)]
+        self.params_override = []      # parity tests queue (order, factors) draws here
+        self.graph_safe = False        # the draw is made on the host (torchvision's stream) and reaches the kernels by value
+
+    def draw(self):
+        """torchvision ColorJitter.get_params: (order [4], factors [4], None where a range is empty)."""
+        if self.params_override:
+            return self.params_override.pop(0)
+        order = [int(i) for i in torch.randperm(4)]
+        return order, [None if r is None else float(torch.empty(1).uniform_(r[0], r[1])) for r in self.ranges]
+
+    def __call__(self, data):
+        from . import hip
+        assert "rgb" in data, f"rgb, {list(data.keys())}"
+        rgb = data["rgb"]
+        assert rgb.shape[-2] == 3
+        if rgb.dtype != torch.uint8:
+            raise NotImplementedError("ColorJitterPoints: the fused path implements the uint8 rgb the replay stores "
+                                      f"(torchvision's float path differs), got {rgb.dtype}")
+        order, factors = self.draw()
+        color = dict(order=order, factors=factors)
+        color["mean"] = hip.color_contrast_mean(rgb, color)      # [stored clouds]: a virtual repeat shares it
+        out = _as_augmented(data)
+        out.aug["color"] = color
+        return out
+
+    def __repr__(self):
+        return (f"{type(self).__name__}(brightness={self.brightness},contrast={self.contrast},"
+                f"saturation={self.saturation},hue={self.hue})")
+
+
 def batch_rot_with_axis(angle, rot_axis=2):
     """[.., 1] angles -> [.., 3, 3] rotations about `rot_axis` (reference pyrl/utils/torch/ops.py:171-183)."""
     assert angle.shape[-1] == 1

@@ -106,9 +106,90 @@ __global__ __launch_bounds__(256) void augment_xyz_kernel(const AugParams p) {
     dst[0] = x0; dst[p.N] = x1; dst[2 * (long long)p.N] = x2;
 }
 
+struct ColorParams {
+    const unsigned char* in; unsigned char* out; long long sb, sc, sn; int B, N;
+    int order; float fac[4], omf[4]; const float* mean; float* mean_out; int n_steps;
+};
+
+// One workgroup per cloud: the steps before the contrast step, then the mean of the grayscale values (integers: the fp32 sum
+// is exact in any order up to 65 793 points, as is torch's).
+__global__ __launch_bounds__(256) void color_contrast_mean_kernel(const ColorParams p) {
+    __shared__ float s_part[256];
+    const int b = blockIdx.x;
+    float acc = 0.0f;
+    for (int n = threadIdx.x; n < p.N; n += 256) {
+        const unsigned char* src = p.in + (long long)b * p.sb + (long long)n * p.sn;
+        float r = (float)src[0], g = (float)src[p.sc], bl = (float)src[2 * p.sc];
+        cj_apply(r, g, bl, p.order, p.fac, p.omf, 0.0f, p.n_steps);
+        acc = acc + cj_gray(r, g, bl);
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) s_part[threadIdx.x] = s_part[threadIdx.x] + s_part[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.mean_out[b] = s_part[0] / (float)p.N;
+}
+
+__global__ __launch_bounds__(256) void color_jitter_kernel(const ColorParams p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)p.B * p.N) return;
+    const int b = (int)(i / p.N), n = (int)(i - (long long)b * p.N);
+    const long long off = (long long)b * p.sb + (long long)n * p.sn;
+    float r = (float)p.in[off], g = (float)p.in[off + p.sc], bl = (float)p.in[off + 2 * p.sc];
+    cj_apply(r, g, bl, p.order, p.fac, p.omf, p.mean ? p.mean[b] : 0.0f, 4);
+    p.out[off] = (unsigned char)r; p.out[off + p.sc] = (unsigned char)g; p.out[off + 2 * p.sc] = (unsigned char)bl;
+}
+
 }  // namespace pcrl
 
 using namespace pcrl;
+
+static int color_fill(const pcrl_aug_desc* aug, ColorParams& p, int* contrast_pos) {
+    if (!aug || !(aug->flags & PCRL_AUG_COLOR)) return fail(PCRL_E_ARG, "aug without PCRL_AUG_COLOR");
+    p.order = aug->color_order; p.mean = aug->color_mean;
+    *contrast_pos = -1;
+    for (int k = 0; k < 4; ++k) {
+        p.fac[k] = aug->color_factor[k]; p.omf[k] = aug->color_one_minus[k];
+        const int op = (aug->color_order >> (4 * k)) & 15;
+        if (op == PCRL_COLOR_CONTRAST) *contrast_pos = k;
+        else if (op != PCRL_COLOR_BRIGHTNESS && op != PCRL_COLOR_SATURATION && op != PCRL_COLOR_HUE && op != PCRL_COLOR_SKIP)
+            return fail(PCRL_E_ARG, "bad colour step id %d", op);
+    }
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_color_contrast_mean_u8(const uint8_t* rgb, int64_t stride_b, int64_t stride_c, int64_t stride_n, int32_t B, int32_t N,
+                                           const pcrl_aug_desc* aug, float* mean_out, void* stream) {
+    if (!rgb || !mean_out) return fail(PCRL_E_ARG, "NULL argument");
+    if (B < 0 || N < 1) return fail(PCRL_E_ARG, "bad shape");
+    ColorParams p{};
+    int cpos;
+    if (int rc = color_fill(aug, p, &cpos)) return rc;
+    if (B == 0) return PCRL_OK;
+    p.in = rgb; p.sb = stride_b; p.sc = stride_c; p.sn = stride_n; p.B = B; p.N = N; p.mean_out = mean_out;
+    p.n_steps = cpos < 0 ? 0 : cpos;
+    hipLaunchKernelGGL(color_contrast_mean_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("color_contrast_mean_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_color_jitter_u8(const uint8_t* rgb_in, uint8_t* rgb_out, int64_t stride_b, int64_t stride_c, int64_t stride_n, int32_t B, int32_t N,
+                                    const pcrl_aug_desc* aug, void* stream) {
+    if (!rgb_in || !rgb_out) return fail(PCRL_E_ARG, "NULL argument");
+    if (B < 0 || N < 1) return fail(PCRL_E_ARG, "bad shape");
+    ColorParams p{};
+    int cpos;
+    if (int rc = color_fill(aug, p, &cpos)) return rc;
+    if (cpos >= 0 && !aug->color_mean) return fail(PCRL_E_ARG, "contrast step without color_mean");
+    if (B == 0) return PCRL_OK;
+    p.in = rgb_in; p.out = rgb_out; p.sb = stride_b; p.sc = stride_c; p.sn = stride_n; p.B = B; p.N = N;
+    const long long n = (long long)B * N;
+    hipLaunchKernelGGL(color_jitter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("color_jitter_kernel");
+    return PCRL_OK;
+}
 
 extern "C" int pcrl_segmax_fwd_f32(const float* x, int64_t rows, int32_t N, float* out, int32_t* idx, void* stream) {
     if (!x || !out || !idx) return fail(PCRL_E_ARG, "NULL argument");

@@ -27,13 +27,74 @@ struct CloudParams {
     unsigned long long seed, offset;
     const unsigned long long* offset_ptr;
     const int* point_index;   // SUBSAMPLE: stored point of position n (N is then the subsampled count)
+    int color_order;          // COLOR: four step ids, 4 bits each
+    float color_fac[4], color_omf[4];
+    const float* color_mean;  // [stored clouds]
     ChanSrc ch[PCRL_MAX_CHANNELS];
 };
+
+// ---- ColorJitterPoints = torchvision 0.14 ColorJitter on uint8 rgb (reference pyrl/utils/augmentations/pcd_aug.py:269-303;
+// algorithm restated in oracle/color_jitter_ref.py).  r, g, b hold uint8 VALUES (0..255) as floats; every step ends with
+// torch's `.to(uint8)` (truncation after the clamp).  Every fp32 operation below is the one torch performs, in its order.
+__device__ __forceinline__ float cj_u8(float x) { return __builtin_floorf(__builtin_fminf(__builtin_fmaxf(x, 0.0f), 255.0f)); }
+__device__ __forceinline__ float cj_gray(float r, float g, float b) { return __builtin_floorf((0.2989f * r + 0.587f * g) + 0.114f * b); }
+__device__ __forceinline__ float cj_clamp01(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+
+__device__ __forceinline__ void cj_hue(float& r8, float& g8, float& b8, float shift) {
+    const float r = r8 / 255.0f, g = g8 / 255.0f, b = b8 / 255.0f;
+    const float maxc = __builtin_fmaxf(__builtin_fmaxf(r, g), b), minc = __builtin_fminf(__builtin_fminf(r, g), b);
+    const bool eqc = maxc == minc;
+    const float cr = maxc - minc;
+    const float s = cr / (eqc ? 1.0f : maxc);
+    const float crd = eqc ? 1.0f : cr;
+    const float rc = (maxc - r) / crd, gc = (maxc - g) / crd, bc = (maxc - b) / crd;
+    const float hr = (maxc == r) ? (bc - gc) : 0.0f;
+    const float hg = (maxc == g && maxc != r) ? ((2.0f + rc) - bc) : 0.0f;
+    const float hb = (maxc != g && maxc != r) ? ((4.0f + gc) - rc) : 0.0f;
+    float h = __builtin_fmodf(((hr + hg) + hb) / 6.0f + 1.0f, 1.0f);
+    h = h + shift;                                  // torch: (h + f) % 1.0 == remainder(h + f, 1.0)
+    float m = __builtin_fmodf(h, 1.0f);
+    if (m != 0.0f && m < 0.0f) m = m + 1.0f;
+    h = m;
+    const float v = maxc;
+    const float h6 = h * 6.0f;
+    const float fi = __builtin_floorf(h6);
+    const float f = h6 - fi;
+    int i = (int)fi;
+    const float pp = cj_clamp01(v * (1.0f - s));
+    const float q = cj_clamp01(v * (1.0f - s * f));
+    const float t = cj_clamp01(v * (1.0f - (s * (1.0f - f))));
+    i = i % 6;
+    if (i < 0) i += 6;
+    const float ro = i == 0 ? v : i == 1 ? q : i == 2 ? pp : i == 3 ? pp : i == 4 ? t : v;
+    const float go = i == 0 ? t : i == 1 ? v : i == 2 ? v : i == 3 ? q : i == 4 ? pp : pp;
+    const float bo = i == 0 ? pp : i == 1 ? pp : i == 2 ? t : i == 3 ? v : i == 4 ? v : q;
+    r8 = (float)(unsigned char)(int)(ro * 255.0f); g8 = (float)(unsigned char)(int)(go * 255.0f); b8 = (float)(unsigned char)(int)(bo * 255.0f);
+}
+
+// Steps [0, n_steps) of the drawn order (n_steps = 4: everything; the contrast-mean pre-pass stops before the contrast step).
+__device__ __forceinline__ void cj_apply(float& r, float& g, float& b, int order, const float* fac, const float* omf, float mean, int n_steps) {
+    for (int k = 0; k < n_steps; ++k) {
+        const int op = (order >> (4 * k)) & 15;
+        if (op == PCRL_COLOR_BRIGHTNESS) {
+            r = cj_u8(fac[0] * r + omf[0] * 0.0f); g = cj_u8(fac[0] * g + omf[0] * 0.0f); b = cj_u8(fac[0] * b + omf[0] * 0.0f);
+        } else if (op == PCRL_COLOR_CONTRAST) {
+            const float m = omf[1] * mean;
+            r = cj_u8(fac[1] * r + m); g = cj_u8(fac[1] * g + m); b = cj_u8(fac[1] * b + m);
+        } else if (op == PCRL_COLOR_SATURATION) {
+            const float m = omf[2] * cj_gray(r, g, b);
+            r = cj_u8(fac[2] * r + m); g = cj_u8(fac[2] * g + m); b = cj_u8(fac[2] * b + m);
+        } else if (op == PCRL_COLOR_HUE) {
+            cj_hue(r, g, b, fac[3]);
+        }
+    }
+}
 
 // Channel descriptors are staged in LDS (not SGPRs: 16 x 32 B of kernel arguments would stay
 // live across the whole tile body).  All lanes read the same descriptor; the dtype flags are
 // made scalar again so the branches stay wave-uniform.
-__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n) {
+// raw: skip the /255 of a uint8 rgb channel (the colour jitter works on the uint8 values and divides afterwards)
+__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n, bool raw = false) {
     const ChanSrc d = s_desc[c];
     const long long off = (long long)b * d.stride_b + (long long)n * d.stride_n;
     const int dtype = __builtin_amdgcn_readfirstlane(d.dtype);
@@ -45,7 +106,7 @@ __device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, 
         v = (float)static_cast<const unsigned char*>(d.base)[off];
         if (dtype == PCRL_DT_BOOL) v = v != 0.0f ? 1.0f : 0.0f;
     }
-    if (div255) v = v / 255.0f;
+    if (div255 && !raw) v = v / 255.0f;
     return v;
 }
 
@@ -55,8 +116,16 @@ __device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc
     f32x16 x;
     const int n_src = p.point_index ? p.point_index[n] : n;
     const int b_src = p.row_div > 1 ? b / p.row_div : b;      // b is wave-uniform: one scalar division per tile
+    const bool color = (p.aug_flags & PCRL_AUG_COLOR) != 0;       // channels 3..5 are the uint8 rgb key (checked on the host)
 #pragma unroll
-    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b_src, n_src) : 0.0f;
+    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b_src, n_src, color && c >= 3 && c < 6) : 0.0f;
+    if (color) {
+        if (2 * T0 >= 6) {
+            float r = x[3], g = x[4], bl = x[5];
+            cj_apply(r, g, bl, p.color_order, p.color_fac, p.color_omf, p.color_mean ? p.color_mean[b_src] : 0.0f, 4);
+            x[3] = r / 255.0f; x[4] = g / 255.0f; x[5] = bl / 255.0f;
+        }
+    }
     const long long row = (long long)b * p.row_mul + p.row_add;
     if (p.aug_flags & PCRL_AUG_AFFINE) {
         const float* M = p.affine + row * 12;

@@ -328,6 +328,16 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
             p.N = aug->n_index;
         }
         if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
+        if (aug->flags & PCRL_AUG_COLOR) {
+            if (clouds->nseg < 2 || clouds->seg[0].channels != 3 || clouds->seg[1].channels != 3 || clouds->seg[1].dtype != PCRL_DT_U8 || !clouds->seg[1].div255)
+                return fail(PCRL_E_ARG, "COLOR needs segment 0 = xyz (3 channels) and segment 1 = rgb (3 x uint8)");
+            if (aug->flags & PCRL_AUG_SUBSAMPLE) return fail(PCRL_E_ARG, "COLOR + SUBSAMPLE: the contrast mean would have to be taken over the subsampled cloud");
+            bool contrast = false;
+            for (int k = 0; k < 4; ++k) contrast = contrast || ((aug->color_order >> (4 * k)) & 15) == PCRL_COLOR_CONTRAST;
+            if (contrast && !aug->color_mean) return fail(PCRL_E_ARG, "COLOR with a contrast step needs color_mean (pcrl_color_contrast_mean_u8)");
+            p.color_order = aug->color_order; p.color_mean = aug->color_mean;
+            for (int k = 0; k < 4; ++k) { p.color_fac[k] = aug->color_factor[k]; p.color_omf[k] = aug->color_one_minus[k]; }
+        }
         p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
         p.row_mul = aug->row_mul ? aug->row_mul : 1; p.row_add = aug->row_add;
         p.offset_ptr = reinterpret_cast<const unsigned long long*>(aug->offset_ptr);

@@ -135,7 +135,9 @@ def encoder_pack_weights(ew, packed):
 
 
 def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None,
-                  point_index=None):
+                  point_index=None, color=None):
+    """color: dict(order=[4 step ids in application order], factors=[brightness, contrast, saturation, hue] (None: skip),
+    mean=float32 device tensor [stored clouds] or None) -- ColorJitterPoints, see include/pcrl.h PCRL_AUG_COLOR."""
     flags = 0
     aug = AugDesc()
     aug.row_mul, aug.row_add = int(row_mul), int(row_add)
@@ -155,8 +157,46 @@ def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine
         assert point_index.dtype == torch.int32 and point_index.is_cuda and point_index.is_contiguous() and point_index.ndim == 1
         flags |= _lib.AUG_SUBSAMPLE
         aug.point_index, aug.n_index = point_index.data_ptr(), point_index.numel()
+    if color is not None:
+        flags |= _lib.AUG_COLOR
+        order = 0
+        for k, op in enumerate(color["order"]):
+            f = color["factors"][op]
+            order |= (15 if f is None else int(op)) << (4 * k)
+            if f is not None:
+                aug.color_factor[op] = float(f)
+                aug.color_one_minus[op] = 1.0 - float(f)       # formed in double, rounded to float by the struct: as torch does
+        aug.color_order = order
+        mean = color.get("mean")
+        if mean is not None:
+            assert mean.dtype == torch.float32 and mean.is_cuda and mean.is_contiguous()
+            aug.color_mean = mean.data_ptr()
     aug.flags = flags
     return aug
+
+
+def color_contrast_mean(rgb, color):
+    """Per-cloud grayscale mean entering the contrast step of a ColorJitterPoints draw (rgb [B,3,N] uint8); None when the
+    draw has no contrast step."""
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.ndim == 3 and rgb.shape[1] == 3
+    if color["factors"][1] is None:
+        return None
+    desc = make_aug_desc(color=dict(color, mean=None))
+    out = torch.empty(rgb.shape[0], dtype=torch.float32, device=rgb.device)
+    check(lib().pcrl_color_contrast_mean_u8(_ptr(rgb), ctypes.c_int64(rgb.stride(0)), ctypes.c_int64(rgb.stride(1)), ctypes.c_int64(rgb.stride(2)),
+                                            rgb.shape[0], rgb.shape[2], ctypes.byref(desc), _ptr(out), _stream()))
+    return out
+
+
+def color_jitter_u8(rgb, color):
+    """Materialised ColorJitterPoints (rgb [B,3,N] uint8 -> new tensor); color["mean"] as returned by color_contrast_mean."""
+    assert rgb.is_cuda and rgb.dtype == torch.uint8 and rgb.ndim == 3 and rgb.shape[1] == 3
+    out = torch.empty_like(rgb)
+    assert out.stride() == rgb.stride()
+    desc = make_aug_desc(color=color)
+    check(lib().pcrl_color_jitter_u8(_ptr(rgb), _ptr(out), ctypes.c_int64(rgb.stride(0)), ctypes.c_int64(rgb.stride(1)), ctypes.c_int64(rgb.stride(2)),
+                                     rgb.shape[0], rgb.shape[2], ctypes.byref(desc), _stream()))
+    return out
 
 
 def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False):

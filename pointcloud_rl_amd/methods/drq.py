@@ -63,6 +63,18 @@ class DrQ(SAC):
         obs = virtual_repeat(obs, self.num_aug) if virtual else repeat_obs(obs, self.num_aug)
         return self.obs_aug(obs) if self.obs_aug is not None else obs
 
+    def enable_graphs(self, enabled=True, warmup=2):
+        """An augmentation whose random draw is made on the host and handed to the kernels by value (ColorJitterPoints:
+        torchvision's parameter draw) would be frozen into a captured graph and replayed with the same draw forever; such
+        agents keep launching eagerly."""
+        host_drawn = [type(t).__name__ for t in (self.obs_aug.transforms if self.obs_aug is not None else [])
+                      if not getattr(t, "graph_safe", True)]
+        if enabled and host_drawn:
+            import warnings
+            warnings.warn(f"hipGraph replay is off: {host_drawn} draw their parameters on the host every step")
+            enabled = False
+        super().enable_graphs(enabled, warmup)
+
     @torch.no_grad()
     def forward(self, obs, **kwargs):
         if self.inference_aug is not None:

@@ -41,6 +41,11 @@ def materialize(obs):
     repeat = int(getattr(obs, "repeat", 1) or 1)
     if repeat > 1:
         out = {k: (torch.repeat_interleave(v, repeat, dim=0) if torch.is_tensor(v) else v) for k, v in out.items()}
+    color = aug.pop("color", None)
+    if color is not None:          # ColorJitterPoints: before any repeat-independent indexing, on the stored uint8 rgb
+        rgb = obs["rgb"].contiguous()
+        jit = hip.color_jitter_u8(rgb, color)
+        out["rgb"] = torch.repeat_interleave(jit, repeat, dim=0) if repeat > 1 else jit
     index = aug.pop("point_index", None)
     if index is not None:          # RandomDownSample: the same points of every key
         out = {k: (v[..., index.long()] if torch.is_tensor(v) and v.ndim == 3 else v) for k, v in out.items()}
