@@ -215,6 +215,7 @@ def main():
             updates += 1
             agent.update_parameters(memory, updates)
     graphed = bool(getattr(agent, "_graphs", None))
+    n_graph_variants = len(getattr(agent, "_graphs", {}) or {})
     if not graphed:
         hip.TIMER = hip.KernelTimer()          # eager: HIP events around every C-ABI launch inside the timed region
     sync()
@@ -224,6 +225,23 @@ def main():
         agent.update_parameters(memory, updates)
     sync()
     elapsed = time.perf_counter() - t0
+    nocomm_ms = None
+    if world > 1:
+        # the same step with the gradient exchange switched off (every rank trains on its shard alone): what is left of
+        # ms_per_step is compute, the difference is what the (overlapped) all-reduces still cost
+        agent.to_normal()
+        n2 = max(args.steps // 2, 2)
+        for _ in range(12):
+            updates += 1
+            agent.update_parameters(memory, updates)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            updates += 1
+            agent.update_parameters(memory, updates)
+        sync()
+        nocomm_ms = (time.perf_counter() - t1) / n2 * 1e3
+        agent.recover_ddp()
     if graphed:
         # Launches replayed from a hipGraph cannot be bracketed by host-recorded events, so the per-kernel
         # durations come from an eager pass over the same batch and weights right after the timed region
@@ -236,9 +254,9 @@ def main():
         sync()
     timer, hip.TIMER = hip.TIMER, None
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, nocomm_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, nocomm_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         spans = timer.summary()
@@ -280,6 +298,9 @@ def main():
                          "algorithmic_flops_per_launch": flops_per_launch},
             "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
         }
+        if nocomm_ms is not None:
+            out["ms_per_step_nocomm"] = nocomm_ms
+            out["comm_ms_per_step"] = elapsed / args.steps * 1e3 - nocomm_ms
         if world == 1 and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
             # bounded samples (about 10-30 s of CPU work each): every granted core on a slice of the batch that takes a few
             # seconds per step, and the reference's shipped single-thread setting (pyrl/utils/meta/__init__.py:38-49) on a

@@ -230,24 +230,27 @@ class FusedStep:
 
     # -- the step -------------------------------------------------------------------------------------
     def run(self, *args, **kwargs):
-        """Execute the step in one go; gradient exchanges (data-parallel) happen inline."""
-        a = self.a
+        """Execute the step in one go; gradient exchanges (data-parallel) happen inline: `steps` yields ("start", pieces) where
+        a range of a flat gradient buffer has become final (its all-reduce then overlaps the rest of the backward) and
+        ("finish", pieces) right before an optimizer pass."""
+        from ..utils.dist import Exchange
+        ex = Exchange(enabled=self.a._be_data_parallel)
         gen = self.steps(*args, **kwargs)
-        exchange = next(gen)
+        kind, pieces = next(gen)
         try:
             while True:
-                scale = 1.0
-                for t in exchange:
-                    scale = a._allreduce(t)
-                exchange = gen.send(scale)
+                for t in pieces:
+                    ex.start(t)
+                kind, pieces = gen.send(ex.finish() if kind == "finish" else None)
         except StopIteration as done:
             return done.value
 
-    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None, repeat=1):
-        """Generator form of the step: yields the flat gradient buffers that have to be all-reduced at
-        that point (empty list when single-process semantics suffice) and receives the factor 1/world
-        to fold into the optimizer pass.  Between two yields no cross-rank communication happens, so
-        every stretch can be captured as its own hipGraph while the collectives stay eager."""
+    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None, repeat=1, exchanging=True):
+        """Generator form of the step: yields ("start", [pieces]) when a range of a flat gradient buffer is final and its
+        all-reduce may begin, and ("finish", [pieces]) when the remaining pieces must be reduced and every started one
+        waited for -- it then receives the factor 1/world to fold into the optimizer pass.  Between two yields no
+        cross-rank communication is issued, so every stretch can be captured as its own hipGraph while the collectives stay
+        eager; a caller without peers skips the "start" yields (exchanging=False) and keeps the step in one graph."""
         a = self.a
         enc, F, S, A, H = a.encoder, self.F, self.S, self.A, self.H
         ldq, lda = self.ldq, self.lda
@@ -288,6 +291,10 @@ class FusedStep:
         dh1, dh2 = self._buf("q_dh1", 2, M, H), self._buf("q_dh2", 2, M, H)
         dX0 = self._buf("q_dX0", 2, M, ceil4(F))
         mlp_backward(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F), ld_dx=ceil4(F))
+        # The Q heads' gradients (the tail of the critic's flat buffer: 2 x 1.1 M floats at K1 of 2.27 M) are final: their
+        # all-reduce runs under the feature-head and encoder backward, only the small head of the buffer waits for those.
+        if exchanging:
+            yield ("start", [fc.grad[self.q_base:]])
         off, pre = self.off, "values.0.backbone.visual_nn.final_mlp."
         dy = self._buf("feat_dy", M, F)
         ws = self._buf("ln_ws", ((M + 3) // 4) * 2 * F)
@@ -299,7 +306,7 @@ class FusedStep:
                                       c_ones=fc.grad[off[pre + "0.bias"]:]),
                         hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
-        scale = yield [fc.grad]
+        scale = yield ("finish", [fc.grad[:self.q_base] if exchanging else fc.grad])
         pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
         stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
@@ -329,7 +336,7 @@ class FusedStep:
                                   d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
-            scale = yield ([fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
+            scale = yield ("finish", [fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
             stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
             a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.dist import allreduce_sum_, world_size
+from ..utils.dist import Exchange, allreduce_sum_, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -464,7 +464,7 @@ class SAC(BaseAgent):
         if hyper != getattr(self, "_graph_hyper", hyper):
             self._graphs, self._graph_seen = {}, {k: self._graph_warmup for k in self._graph_seen}
         self._graph_hyper = hyper
-        key = (do_actor, polyak)
+        key = (do_actor, polyak, exchanging)       # a step with exchanges is cut into segments, one without is one graph
         if key not in self._graphs:
             seen = self._graph_seen.get(key, 0)
             self._graph_seen[key] = seen + 1
@@ -478,10 +478,13 @@ class SAC(BaseAgent):
                 segments, names, out = self._graphs[key]
                 return self._finish(dict(zip(names, out.unbind(0))), updates)
         segments, names, out = self._graphs[key]
-        for graph, exchange in segments:
+        ex = Exchange()
+        for graph, (kind, pieces) in segments:
             graph.replay()
-            for t in exchange:
-                allreduce_sum_(t)
+            for t in pieces:
+                ex.start(t)
+            if kind == "finish":
+                ex.finish()
         if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
             stream = self.__dict__.get("_sync_stream")
             if stream is None or stream.cuda_stream != hip.raw_stream():
@@ -502,7 +505,7 @@ class SAC(BaseAgent):
             if packed is not None:          # the metrics land in pinned host memory as the graph's last node
                 host = pinned[:len(names)]
                 host.copy_(out, non_blocking=True)
-        return [(graph, [])], names, (host if host is not None else out)
+        return [(graph, ("finish", []))], names, (host if host is not None else out)
 
     def _capture_segments(self, batch, do_actor, polyak):
         """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay
@@ -511,26 +514,31 @@ class SAC(BaseAgent):
         pool = torch.cuda.graph_pool_handle()
         scale = 1.0 / world_size()
         segments, names, out, gen = [], None, None, None
+        ex = Exchange()
+        kind = None
         while names is None:
             graph = torch.cuda.CUDAGraph()
-            exchange = []
+            exchange = ("finish", [])
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
             with _no_gc(), torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                 try:
-                    if gen is None:     # batch preparation (DrQ: repeat + augmentation draws) belongs to the first segment
+                    if gen is None:     # batch preparation (DrQ: augmentation draws) belongs to the first segment
                         args, kwargs = self._fused_args(batch, do_actor, polyak)
                         gen = self._fused.steps(*args, **kwargs)
                         exchange = next(gen)
                     else:
-                        exchange = gen.send(scale)
+                        exchange = gen.send(scale if kind == "finish" else None)
                 except StopIteration as done:
                     stats = done.value
                     names = list(stats.keys())
                     out = torch.stack([stats[k].reshape(()).float() for k in names])
+            kind, pieces = exchange
             graph.replay()
-            for t in exchange:
-                allreduce_sum_(t)
-            segments.append((graph, list(exchange)))
+            for t in pieces:
+                ex.start(t)
+            if kind == "finish":
+                ex.finish()
+            segments.append((graph, (kind, list(pieces))))
         return segments, names, out
 
     def update_parameters(self, memory, updates):

@@ -27,6 +27,30 @@ def allreduce_sum_(flat_grad, enabled=True):
     return 1.0 / w
 
 
+class Exchange:
+    """Gradient exchanges of one update step.  `start(t)` launches a SUM all-reduce of a piece of a flat gradient buffer that
+    is already final while the rest of the backward is still running -- the collective runs on the process group's own
+    stream (RCCL) / thread (gloo) -- and `finish()` makes the current stream wait for every piece before the optimizer
+    reads the buffer.  The reference's DistributedDataParallel does the same with its gradient buckets
+    (pyrl/utils/torch/module_utils.py:322-343); here the pieces are two per backward: the dense heads' range, final before
+    the encoder backward starts, and the small encoder + feature-head range after it."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled and world_size() > 1
+        self.pending = []
+        self.scale = 1.0 / world_size() if self.enabled else 1.0
+
+    def start(self, flat_piece):
+        if self.enabled:
+            self.pending.append(dist.all_reduce(flat_piece, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for work in self.pending:
+            work.wait()
+        self.pending = []
+        return self.scale
+
+
 def broadcast_parameters_(module, src=0):
     """Make every rank start from rank `src`'s weights (what DDP's constructor does implicitly)."""
     if world_size() == 1:

@@ -117,3 +117,30 @@ def test_bench_two_ranks_prints_the_contract_line(cuda):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 128
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3 * 1e3
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_overlapped_exchange_pieces_cover_the_flat_buffer_once(cuda):
+    """The step yields the Q-head range of the critic's gradient buffer as soon as it is final ("start") and the rest right
+    before the optimizer ("finish"): together exactly the whole buffer, each float once; actor and alpha buffers whole."""
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    agent = _agent(B)
+    mem = SyntheticReplay(B, N, A, seed=9, device="cuda:0")
+    agent.update_parameters(mem, 1)                      # builds the flat buffers and the fused step
+    batch = mem.sample(B).to_torch(device="cuda:0")
+    fc, fa = agent._flat["critic"], agent._flat["actor"]
+    gen = agent._fused.steps(batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], True, True)
+    seen, kinds = [], []
+    msg = next(gen)
+    try:
+        while True:
+            kinds.append(msg[0])
+            seen.append([(t.data_ptr(), t.numel()) for t in msg[1]])
+            msg = gen.send(1.0 if msg[0] == "finish" else None)
+    except StopIteration:
+        pass
+    assert kinds == ["start", "finish", "finish"]
+    (a_ptr, a_n), = seen[0]
+    (b_ptr, b_n), = seen[1]
+    base = fc.grad.data_ptr()
+    assert b_ptr == base and a_ptr == base + 4 * b_n and a_n + b_n == fc.grad.numel() and a_n > 0 and b_n > 0
+    assert seen[2][0] == (fa.grad.data_ptr(), fa.grad.numel())
