@@ -62,9 +62,12 @@ MANISKILL_NETS = ([128, 128, 256], 128)    # configs/mfrl/drq/maniskill/base/pn_
 JITTER = dict(type="RandomJitterPoints", main_key="xyz", req_keys=["xyz"], jitter_range=[-0.01, 0.01])
 
 
-def sac_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024):
-    """configs/mfrl/sac/dm_control/pn.py"""
-    cfg = _agent_cfg("SAC", DMC_NETS, pcd_channels, action_dim, 0, batch_size, 0.99, head_hidden, {})
+MOTIVATING_NETS = ([32, 64, 128], 50)      # configs/mfrl/sac/dm_control/pn_motivating.py:25-31, drq/dm_control/pn_shift_motivating.py
+
+
+def sac_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, nets=DMC_NETS, **extra):
+    """configs/mfrl/sac/dm_control/pn.py (nets=MOTIVATING_NETS, use_episode_dones=True: pn_motivating.py)"""
+    cfg = _agent_cfg("SAC", nets, pcd_channels, action_dim, 0, batch_size, 0.99, head_hidden, dict(extra))
     cfg["critic_cfg"]["nn_cfg"]["mlp_cfg"]["bias"] = True
     return cfg
 

@@ -29,35 +29,36 @@
 
 namespace pcrl {
 
-constexpr int kC2 = 128, kC3 = 256, kSlots = 256, kPiece = 256;   // floats per piece (64 lanes x 4)
+constexpr int kPiece = 256;   // floats per piece (64 lanes x 4)
 
 // Flat gradient layout = the reference's parameter order inside visual_nn.conv.mlp:
 // conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias, conv2.weight, norm2.weight, norm2.bias
 struct GradLayout {
-    int C, C1;
+    int C, C1, C2, C3;
     __host__ __device__ int w0() const { return 0; }
     __host__ __device__ int b0() const { return C1 * C; }
     __host__ __device__ int w1() const { return b0() + C1; }
-    __host__ __device__ int g1() const { return w1() + kC2 * C1; }
-    __host__ __device__ int be1() const { return g1() + kC2; }
-    __host__ __device__ int w2() const { return be1() + kC2; }
-    __host__ __device__ int g2() const { return w2() + kC3 * kC2; }
-    __host__ __device__ int be2() const { return g2() + kC3; }
-    __host__ __device__ int total() const { return be2() + kC3; }
+    __host__ __device__ int g1() const { return w1() + C2 * C1; }
+    __host__ __device__ int be1() const { return g1() + C2; }
+    __host__ __device__ int w2() const { return be1() + C2; }
+    __host__ __device__ int g2() const { return w2() + C3 * C2; }
+    __host__ __device__ int be2() const { return g2() + C3; }
+    __host__ __device__ int total() const { return be2() + C3; }
 };
 
-// Per-cloud operand workspace (floats): block arrays [nblk][32 octets][piece]
+// Per-cloud operand workspace (floats): block arrays [nblk][32 octets][piece]; a cloud has at most C3 active points = C3 / 32 tiles
 struct OpsLayout {
-    int MB1;
-    __host__ __device__ int dz2() const { return 0; }
-    __host__ __device__ int h1() const { return dz2() + 8 * 32 * kPiece; }
-    __host__ __device__ int dz1() const { return h1() + 4 * 32 * kPiece; }
-    __host__ __device__ int h0() const { return dz1() + 4 * 32 * kPiece; }
-    __host__ __device__ int dz0() const { return h0() + MB1 * 32 * kPiece; }
-    __host__ __device__ int xb() const { return dz0() + MB1 * 32 * kPiece; }
-    __host__ __device__ int total() const { return xb() + 32 * kPiece; }
+    int MB1, MB2, MB3;
+    __host__ __device__ constexpr int blk() const { return 32 * kPiece; }      // floats per 32-channel block: room for 256 active points whatever c3
+    __host__ __device__ constexpr int dz2() const { return 0; }
+    __host__ __device__ constexpr int h1() const { return dz2() + MB3 * blk(); }
+    __host__ __device__ constexpr int dz1() const { return h1() + MB2 * blk(); }
+    __host__ __device__ constexpr int h0() const { return dz1() + MB2 * blk(); }
+    __host__ __device__ constexpr int dz0() const { return h0() + MB1 * blk(); }
+    __host__ __device__ constexpr int xb() const { return dz0() + MB1 * blk(); }
+    __host__ __device__ constexpr int total() const { return xb() + blk(); }
 };
-constexpr int kXsFloats = 8 * 64 * 64;   // xhat1 spill: [wave][R][lane]
+constexpr int kXsFloats = 8 * 64 * 64;   // xhat1 spill: [tile][R][lane], sized for c2 = 128, c3 = 256
 
 struct BwdParams {
     CloudParams cl;
@@ -73,10 +74,10 @@ struct BwdParams {
     float* grads;            // [GradLayout.total()]
     // written by the prep kernel, read by kernel A
     int* flag;               // [B] 1: per-channel shortcut valid for this cloud (pooled given, no lossy channel)
-    int* act;                // [B][kSlots] active point indices, ascending
+    int* act;                // [B][kC3] active point indices, ascending
     unsigned char* slot;     // [B][kC3] slot of the channel's argmax point
     float* dx;               // [B][kC3] dL/d(xhat2) of the channel at its argmax point
-    float2* pt;              // [B][kSlots] per active point: (sum dx, sum dx * xhat) over the channels it owns
+    float2* pt;              // [B][kC3] per active point: (sum dx, sum dx * xhat) over the channels it owns
     float* n1part;           // [B][8][kC2][2] norm1 (dgamma, dbeta) partial sums per tile
     int tile_mode;           // 1: B < #CUs, work items are single tiles found through a prefix sum of the clouds' tile counts
     int parts;               // kernel B: workgroups per cloud (1, 2, 4 or 8; > 1 only for small batches)
@@ -136,21 +137,22 @@ constexpr int kBitmapMaxWords = 8192;      // N <= 262 144 points per cloud
 // Called by EVERY thread of the block (256 threads in the stand-alone kernel, 512 in kernel A's prologue: threads >= 256 only
 // take part in the barriers).  s_words: [2 * nW] bitmap + prefix, s_scan: [256] ints (s_scan[255] = n_act on return),
 // s_slot: [kC3] bytes, s_dx / s_xh: [kC3] floats, s_flag: 1 int (on return 1 when the per-channel shortcut must not be used).
-template <int T0, int C1>
+template <int T0, int C1, int kC2, int kC3>
 __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int tid_all, unsigned* s_words, int* s_scan, unsigned char* s_slot,
                                                float* s_dx, float* s_xh, int* s_flag_p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
-    const GradLayout GL{p.cl.C, C1};
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
     const int nW = (p.cl.N + 31) >> 5;
     unsigned* s_pre = s_words + nW;
-    const bool on = tid_all < 256;
+    const bool on = tid_all < 256;                      // the 256 threads that scan the bitmap
     const int tid = on ? tid_all : 255;
+    const bool chan = on && tid < kC3;                  // thread = channel for the per-channel work (c3 <= 256)
     int& s_flag = *s_flag_p;
     // every global load of the cloud is issued up front (they are independent of the bitmap phase)
     int pc = 0;
     float y_in = 0.0f, g_in = 0.0f, gam = 1.0f, bet = 0.0f;
     const bool have_pooled = p.pooled != nullptr;
-    if (on) {
+    if (chan) {
         pc = p.argmax[(long long)b * kC3 + tid];
         if (have_pooled) {
             y_in = p.pooled[(long long)b * kC3 + tid];
@@ -165,7 +167,7 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
     }
     __syncthreads();
     pc = pc < 0 ? 0 : (pc >= p.cl.N ? p.cl.N - 1 : pc);
-    if (on) atomicOr(&s_words[pc >> 5], 1u << (pc & 31));
+    if (chan) atomicOr(&s_words[pc >> 5], 1u << (pc & 31));
     __syncthreads();
     // exclusive prefix popcount over the words: each thread owns `per` consecutive words; the 256 per-thread counts are
     // scanned inside each wave with DPP-free shuffles and the four wave totals are added through LDS (one barrier)
@@ -193,17 +195,17 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
     __syncthreads();
     const int n_act = s_scan[255];
     const int slot = (int)s_pre[pc >> 5] + __popc(s_words[pc >> 5] & ((1u << (pc & 31)) - 1u));
-    if (on) {
+    if (chan) {
         s_slot[tid] = (unsigned char)slot;
         p.slot[(long long)b * kC3 + tid] = (unsigned char)slot;
-        p.act[(long long)b * kSlots + slot] = pc;                   // every channel of the point writes the same value
+        p.act[(long long)b * kC3 + slot] = pc;                   // every channel of the point writes the same value
     }
     // With the forward's pooled values the LayerNorm-2 / max-pool backward needs no search for "which of my 128 registers
     // hold a channel I own": channel c contributes only at its argmax point, where y = pooled[c] (the recompute is
     // bit-identical to the forward), so dL/dxhat_c = [y > 0] g_c gamma_c and xhat_c = (y - beta_c) / gamma_c are per-CHANNEL
     // quantities, and a point's two sums are sums over the channels that name it.
     float dyl = 0.0f, xh = 0.0f, dxc = 0.0f;
-    if (have_pooled && on) {
+    if (have_pooled && chan) {
         const float y = y_in, g = g_in;
         const bool live = y > 0.0f;
         dyl = live ? g : 0.0f;
@@ -215,7 +217,7 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
         xh = (live && gam != 0.0f) ? (y - bet) / gam : 0.0f;
         dxc = dyl * gam;
     }
-    if (on) {
+    if (chan) {
         s_dx[tid] = dxc;
         s_xh[tid] = xh;
         p.dx[(long long)b * kC3 + tid] = dxc;
@@ -223,7 +225,7 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
     __syncthreads();
     const bool use_pooled = have_pooled && s_flag == 0;
     if (tid_all == 0) { p.n_act[b] = n_act; p.flag[b] = use_pooled ? 1 : 0; }
-    if (use_pooled && on) {
+    if (use_pooled && chan) {
         float* pw = p.pw + (long long)b * GL.total();
         pw[GL.g2() + tid] = dyl * xh;                               // norm2.weight / norm2.bias gradients of this cloud
         pw[GL.be2() + tid] = dyl;
@@ -261,12 +263,12 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
                     t2 = __builtin_fmaf(s_dx[c], s_xh[c], t2);
                 }
             }
-            p.pt[(long long)b * kSlots + tid] = float2{t1, t2};
+            p.pt[(long long)b * kC3 + tid] = float2{t1, t2};
         }
     }
 }
 
-template <int T0, int C1>
+template <int T0, int C1, int kC2, int kC3>
 __global__ __launch_bounds__(256) void encoder_bwd_prep_kernel(const BwdParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned s_words[];   // [nW] bitmap, then [nW] exclusive prefix popcounts
     __shared__ int s_scan[256];
@@ -274,26 +276,26 @@ __global__ __launch_bounds__(256) void encoder_bwd_prep_kernel(const BwdParams p
     __shared__ float s_dx[kC3], s_xh[kC3];
     __shared__ int s_flag;
     for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x)
-        bwd_prep_cloud<T0, C1>(p, b, threadIdx.x, s_words, s_scan, s_slot, s_dx, s_xh, &s_flag);
+        bwd_prep_cloud<T0, C1, kC2, kC3>(p, b, threadIdx.x, s_words, s_scan, s_slot, s_dx, s_xh, &s_flag);
 }
 
 // ---- kernel A, cloud mode (B >= #CUs): one workgroup per cloud, wave w takes the cloud's tile w --------------------------------
 // The cloud's tables (active list by a bitonic sort of the argmax keys, slots, per-channel / per-point sums) live in LDS and
 // are built by the workgroup itself.  Same per-tile chain as the tile-mode kernel below; kept as its own kernel because
 // every value the tile-mode kernel carries per wave (cloud index, table pointers, resources) is a spilled register here.
-template <int T0, int C1, bool BF16>
+template <int T0, int C1, int kC2, int kC3, bool BF16>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
-    constexpr OpsLayout OL{MB1};
-    const GradLayout GL{p.cl.C, C1};
+    constexpr OpsLayout OL{C1 / 32, kC2 / 32, kC3 / 32};
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
     unsigned* s_key = reinterpret_cast<unsigned*>(s_desc + PCRL_MAX_CHANNELS);   // [256] sort keys
     int* s_scan = reinterpret_cast<int*>(s_key + kC3);                            // [256]
     int* s_act = s_scan + kC3;                                                    // [256] active point indices
-    int* s_misc = s_act + kSlots;                                                 // [8]   n_act, flags (all LDS is dynamic: G17)
+    int* s_misc = s_act + kC3;                                                 // [8]   n_act, flags (all LDS is dynamic: G17)
     unsigned char* s_slot = reinterpret_cast<unsigned char*>(s_misc + 8);         // [256] slot of the channel's argmax point
     float* s_g = reinterpret_cast<float*>(s_slot + kC3);                          // [256] grad_pooled row
     float* s_ln1 = s_g + kC3;
@@ -305,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
     float* s_dx = reinterpret_cast<float*>(s_dgb + kC3);                          // [256] dL/d(xhat2) of the channel at its argmax point
     float* s_xh = s_dx + kC3;                                                     // [256] xhat2 of the channel at its argmax point
     float2* s_pt = reinterpret_cast<float2*>(s_xh + kC3);                         // [256] per active point: (sum dx, sum dx * xhat)
-    int* s_first = reinterpret_cast<int*>(s_pt + kSlots);                         // [256] sorted position where the point's run of keys starts
-    float* s_w2 = reinterpret_cast<float*>(s_first + kSlots);
+    int* s_first = reinterpret_cast<int*>(s_pt + kC3);                         // [256] sorted position where the point's run of keys starts
+    float* s_w2 = reinterpret_cast<float*>(s_first + kC3);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -476,9 +478,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
             // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
             // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
-            unsigned long long own[4];
+            unsigned long long own[kC3 / 64];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)wave);
+            for (int k = 0; k < kC3 / 64; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)wave);
             float m1, m2;
             if (use_pooled) {                       // the point's sums were formed per channel before the tiles
                 const float2 t = s_pt[valid ? s : 0];
@@ -623,14 +625,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
 // inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`) and so do the two data-gradient
 // GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
 // through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
-constexpr int kTileTabBytes = kC3 + 4 * kC3;       // per wave: slot bytes + dx floats of the tile's cloud
+constexpr int kTileTabBytes = 256 + 4 * 256;       // per wave: slot bytes + dx floats of the tile's cloud (c3 <= 256)
 constexpr int kMaxTileModeClouds = 256;           // tile mode needs the clouds' tile prefix in LDS
-template <int T0, int C1, bool BF16>
+template <int T0, int C1, int kC2, int kC3, bool BF16>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
-    constexpr OpsLayout OL{MB1};
-    const GradLayout GL{p.cl.C, C1};
+    constexpr OpsLayout OL{C1 / 32, kC2 / 32, kC3 / 32};
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
@@ -680,8 +682,10 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
         n_act = p.n_act[b];
         const bool use_pooled = p.flag[b] != 0;
         // this wave's copy of the cloud's tables
-        reinterpret_cast<unsigned*>(s_slot)[lane] = reinterpret_cast<const unsigned*>(p.slot + (long long)b * kC3)[lane];
-        reinterpret_cast<f32x4*>(s_dx)[lane] = reinterpret_cast<const f32x4*>(p.dx + (long long)b * kC3)[lane];
+        if (lane < kC3 / 4) {
+            reinterpret_cast<unsigned*>(s_slot)[lane] = reinterpret_cast<const unsigned*>(p.slot + (long long)b * kC3)[lane];
+            reinterpret_cast<f32x4*>(s_dx)[lane] = reinterpret_cast<const f32x4*>(p.dx + (long long)b * kC3)[lane];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
         {
             const int s = 32 * tile + l31;
             const bool valid = s < n_act;
-            const int pidx = p.act[(long long)b * kSlots + (valid ? s : n_act - 1)];
+            const int pidx = p.act[(long long)b * kC3 + (valid ? s : n_act - 1)];
             const unsigned s_match = valid ? (unsigned)s : 0xFFFFu;   // never equals a slot byte when invalid
             // lane-dependent byte offset of an operand element: octet q = s >> 3, k-lane (s >> 2) & 1, k-slot s & 3
             const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
@@ -769,12 +773,12 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
             // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
             // masks), so the ownership arithmetic (branch-free inside) runs for ~1/3 of the registers.
-            unsigned long long own[4];
+            unsigned long long own[kC3 / 64];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)tile);
+            for (int k = 0; k < kC3 / 64; ++k) own[k] = __ballot(((unsigned)s_slot[64 * k + lane] >> 5) == (unsigned)tile);
             float m1, m2;
             if (use_pooled) {                       // the point's sums were formed per channel before the tiles
-                const float2 t = p.pt[(long long)b * kSlots + (valid ? s : 0)];
+                const float2 t = p.pt[(long long)b * kC3 + (valid ? s : 0)];
                 m1 = valid ? t.x / (float)kC3 : 0.0f;      // padding lanes of the last tile own nothing: their dz must stay 0
                 m2 = valid ? t.y / (float)kC3 : 0.0f;
             } else {
@@ -981,11 +985,11 @@ __device__ __forceinline__ void wgrad_conv0(const BwdParams& p, const float* ops
     }
 }
 
-template <int C1>
+template <int C1, int kC2, int kC3>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdParams p) {
     constexpr int MB1 = C1 / 32;
-    constexpr OpsLayout OL{MB1};
-    const GradLayout GL{p.cl.C, C1};
+    constexpr OpsLayout OL{C1 / 32, kC2 / 32, kC3 / 32};
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
     extern __shared__ __attribute__((aligned(16))) f32x4 s_h1[];      // [4][n_oct][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = p.parts;
@@ -1000,25 +1004,29 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
             for (int t = 0; t < n_tiles; ++t) acc = acc + n1[t * kC2 * 2 + tid];
             pw[((tid & 1) ? GL.be1() : GL.g1()) + (tid >> 1)] = acc;
         }
-        if (P > 1) {
-            // Small batch: the cloud's 32 + 4 MB1 + MB1 output blocks are dealt one at a time over the 8 P waves of its P
-            // workgroups (operands straight from L2; every block is one chain of n_oct * 4 MFMAs).
-            const int n_tasks = 32 + 4 * MB1 + MB1;
+        constexpr bool kStandard = kC2 == 128 && kC3 == 256 && (C1 == 64 || C1 == 128);   // the 8-wave mapping below assumes these
+        if (P > 1 || !kStandard) {
+            // Small batch (or a shape without a hand-laid wave mapping): the cloud's MB3 MB2 + MB2 MB1 + MB1 output blocks are dealt
+            // one at a time over the 8 P waves of its P workgroups (operands straight from L2; every block is one chain of
+            // n_oct * 4 MFMAs).
+            constexpr int MB2 = kC2 / 32, MB3 = kC3 / 32;
+            const int n_tasks = MB3 * MB2 + MB2 * MB1 + MB1;
             for (int t = part * 8 + wave; t < n_tasks; t += 8 * P) {
                 f32x16 acc[1];
-                if (t < 32) {
-                    wgrad_blocks<1>(ops + OL.dz2(), reinterpret_cast<const f32x4*>(ops + OL.h1()), 32 * 64, t >> 2, t & 3, n_oct, lane, acc);
-                    store_tile(pw + GL.w2(), kC2, t >> 2, t & 3, kC2, acc[0], lane);
-                } else if (t < 32 + 4 * MB1) {
-                    const int u = t - 32;
+                if (t < MB3 * MB2) {
+                    wgrad_blocks<1>(ops + OL.dz2(), reinterpret_cast<const f32x4*>(ops + OL.h1()), 32 * 64, t / MB2, t % MB2, n_oct, lane, acc);
+                    store_tile(pw + GL.w2(), kC2, t / MB2, t % MB2, kC2, acc[0], lane);
+                } else if (t < MB3 * MB2 + MB2 * MB1) {
+                    const int u = t - MB3 * MB2;
                     wgrad_blocks<1>(ops + OL.dz1(), reinterpret_cast<const f32x4*>(ops + OL.h0()), 32 * 64, u / MB1, u % MB1, n_oct, lane, acc);
                     store_tile(pw + GL.w1(), C1, u / MB1, u % MB1, C1, acc[0], lane);
                 } else {
-                    wgrad_conv0(p, ops, pw, GL, OL.dz0(), OL.xb(), t - 32 - 4 * MB1, n_oct, lane);
+                    wgrad_conv0(p, ops, pw, GL, OL.dz0(), OL.xb(), t - MB3 * MB2 - MB2 * MB1, n_oct, lane);
                 }
             }
             continue;
         }
+        if constexpr (kStandard) {
         {   // conv2.weight [256][128]: wave w owns row block w, all 4 column blocks.  Every wave contracts against the whole
             // of h1, so the cloud's h1 operand (4 blocks x n_oct KB) is staged in LDS once instead of being fetched from L2
             // by each of the 8 waves.
@@ -1043,6 +1051,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
             for (int n = 0; n < NB; ++n) store_tile(pw + GL.w1(), C1, mb, nb0 + n, C1, acc[n], lane);
         }
         if (wave < MB1) wgrad_conv0(p, ops, pw, GL, OL.dz0(), OL.xb(), wave, n_oct, lane);
+        }
     }
 }
 
@@ -1072,40 +1081,41 @@ __global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* _
     }
 }
 
-static size_t bwd_lds_bytes_cloud(int T0, int C1) {
-    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kSlots + 32 + kC3 + 4 * (size_t)kC3 +
-           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + 2 * (size_t)kC3 + 3 * (size_t)kSlots + (size_t)kC3 * kC2);
+static size_t bwd_lds_bytes_cloud(int T0, int C1, int kC2, int kC3) {
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kC3 + 32 + kC3 + 4 * (size_t)kC3 +
+           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + 2 * (size_t)kC3 + 3 * (size_t)kC3 + (size_t)kC3 * kC2);
 }
 
-static size_t bwd_lds_bytes_tile(int T0, int C1) {
+static size_t bwd_lds_bytes_tile(int T0, int C1, int kC2, int kC3) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)kTileTabBytes + 4 * (size_t)(kMaxTileModeClouds + 8) +
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + (size_t)kC3 * kC2);
 }
 
-template <int T0, int C1, bool BF16>
+template <int T0, int C1, int C2, int C3, bool BF16>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
     if (p.tile_mode) {
         // small batch: prep (tables) -> one wave per tile, dealt over every CU
         const int nW = (p.cl.N + 31) / 32;
-        auto prep = encoder_bwd_prep_kernel<T0, C1>;
+        auto prep = encoder_bwd_prep_kernel<T0, C1, C2, C3>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
         hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(256), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_prep_kernel");
-        const size_t lds = bwd_lds_bytes_tile(T0, C1);
-        auto kern = encoder_bwd_points_kernel<T0, C1, BF16>;
+        const size_t lds = bwd_lds_bytes_tile(T0, C1, C2, C3);
+        auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
     } else {
-        const size_t lds = bwd_lds_bytes_cloud(T0, C1);
-        auto kern = encoder_bwd_points_cloud_kernel<T0, C1, BF16>;
+        const size_t lds = bwd_lds_bytes_cloud(T0, C1, C2, C3);
+        auto kern = encoder_bwd_points_cloud_kernel<T0, C1, C2, C3, BF16>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_points_cloud_kernel");
     }
     constexpr size_t wgrad_lds = 4 * 32 * 64 * sizeof(f32x4);        // h1 operand of one cloud: 128 KB at 256 active points
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(encoder_bwd_wgrad_kernel<C1>), wgrad_lds)) return rc;
-    hipLaunchKernelGGL(encoder_bwd_wgrad_kernel<C1>, dim3(grid * p.parts), dim3(512), wgrad_lds, stream, p);
+    auto wgrad = encoder_bwd_wgrad_kernel<C1, C2, C3>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad), wgrad_lds)) return rc;
+    hipLaunchKernelGGL(wgrad, dim3(grid * p.parts), dim3(512), wgrad_lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_bwd_wgrad_kernel");
     return PCRL_OK;
 }
@@ -1113,9 +1123,9 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
 struct BwdWorkspace {
     size_t ops, xs, pw, nact, flag, act, slot, dx, pt, n1part, total;
 };
-static BwdWorkspace bwd_workspace(int B, int C, int C1) {
-    const OpsLayout OL{C1 / 32};
-    const GradLayout GL{C, C1};
+static BwdWorkspace bwd_workspace(int B, int C, int C1, int kC2, int kC3) {
+    const OpsLayout OL{C1 / 32, kC2 / 32, kC3 / 32};
+    const GradLayout GL{C, C1, kC2, kC3};
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     BwdWorkspace w;
     w.ops = 0;
@@ -1124,10 +1134,10 @@ static BwdWorkspace bwd_workspace(int B, int C, int C1) {
     w.nact = al(w.pw + sizeof(float) * (size_t)B * GL.total());
     w.flag = al(w.nact + sizeof(int) * (size_t)B);
     w.act = al(w.flag + sizeof(int) * (size_t)B);
-    w.slot = al(w.act + sizeof(int) * (size_t)B * kSlots);
+    w.slot = al(w.act + sizeof(int) * (size_t)B * kC3);
     w.dx = al(w.slot + (size_t)B * kC3);
     w.pt = al(w.dx + sizeof(float) * (size_t)B * kC3);
-    w.n1part = al(w.pt + sizeof(float2) * (size_t)B * kSlots);
+    w.n1part = al(w.pt + sizeof(float2) * (size_t)B * kC3);
     w.total = al(w.n1part + sizeof(float) * (size_t)B * 8 * kC2 * 2);
     return w;
 }
@@ -1140,7 +1150,7 @@ extern "C" int pcrl_encoder_num_grads(int32_t c_in, int32_t c1, int32_t c2, int3
     size_t dummy;
     if (int rc = pcrl_encoder_packed_bytes(c_in, c1, c2, c3, &dummy)) return rc;
     if (!n) return fail(PCRL_E_ARG, "n is NULL");
-    *n = (size_t)GradLayout{c_in, c1}.total();
+    *n = (size_t)GradLayout{c_in, c1, c2, c3}.total();
     return PCRL_OK;
 }
 
@@ -1148,7 +1158,7 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     size_t dummy;
     if (int rc = pcrl_encoder_packed_bytes(c_in, c1, c2, c3, &dummy)) return rc;
     if (!bytes || B < 0) return fail(PCRL_E_ARG, "bad arguments");
-    *bytes = bwd_workspace(B, c_in, c1).total;
+    *bytes = bwd_workspace(B, c_in, c1, c2, c3).total;
     return PCRL_OK;
 }
 
@@ -1162,13 +1172,13 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
     BwdParams p{};
     if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
-    const GradLayout GL{w->c_in, w->c1};
+    const GradLayout GL{w->c_in, w->c1, w->c2, w->c3};
     hipStream_t st = (hipStream_t)stream;
     if (p.cl.B == 0) {
         PCRL_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * GL.total(), st));
         return PCRL_OK;
     }
-    const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1);
+    const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
     if (!workspace || workspace_bytes < ws.total) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.total);
     char* base = static_cast<char*>(workspace);
     p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.argmax = argmax; p.gpool = grad_pooled; p.pooled = pooled;
@@ -1186,10 +1196,12 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     const int grid = min(p.cl.B, num_cus());
     const int T0 = (p.cl.C + 1) / 2;
     int rc = PCRL_E_ARG;
-#define PCRL_BWD_CASE(T0_, C1_) \
-    if (T0 == T0_ && w->c1 == C1_) rc = bf16 ? launch_bwd<T0_, C1_, true>(p, grid, st) : launch_bwd<T0_, C1_, false>(p, grid, st);
-    PCRL_BWD_CASE(2, 64) PCRL_BWD_CASE(3, 64) PCRL_BWD_CASE(4, 64) PCRL_BWD_CASE(5, 64)
-    PCRL_BWD_CASE(2, 128) PCRL_BWD_CASE(3, 128) PCRL_BWD_CASE(4, 128) PCRL_BWD_CASE(5, 128)
+#define PCRL_BWD_CASE(T0_, C1_, C2_, C3_) \
+    if (T0 == T0_ && w->c1 == C1_ && w->c2 == C2_ && w->c3 == C3_) \
+        rc = bf16 ? launch_bwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : launch_bwd<T0_, C1_, C2_, C3_, false>(p, grid, st);
+    PCRL_BWD_CASE(2, 64, 128, 256) PCRL_BWD_CASE(3, 64, 128, 256) PCRL_BWD_CASE(4, 64, 128, 256) PCRL_BWD_CASE(5, 64, 128, 256)
+    PCRL_BWD_CASE(2, 128, 128, 256) PCRL_BWD_CASE(3, 128, 128, 256) PCRL_BWD_CASE(4, 128, 128, 256) PCRL_BWD_CASE(5, 128, 128, 256)
+    PCRL_BWD_CASE(2, 32, 64, 128) PCRL_BWD_CASE(3, 32, 64, 128) PCRL_BWD_CASE(4, 32, 64, 128) PCRL_BWD_CASE(5, 32, 64, 128)
 #undef PCRL_BWD_CASE
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;

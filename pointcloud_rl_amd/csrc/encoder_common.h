@@ -283,6 +283,25 @@ __device__ __forceinline__ void stream_operands(LoadFn load, BodyFn body) {
 // act(t) -> the B operand (activation register) of k-step t.
 template <int MB, int TQ, int DEPTH, bool ZERO_START = true, class LoadFn, class ActFn>
 __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    if constexpr (MB == 1) {
+        // a single 32-row block (c = 32 channels): one accumulator chain, operands DEPTH groups ahead
+        f32x4 ring[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < TQ) ring[d] = load(0, d);
+#pragma unroll
+        for (int g = 0; g < TQ; ++g) {
+            const f32x4 w = ring[g % DEPTH];
+            if (g + DEPTH < TQ) ring[g % DEPTH] = load(0, g + DEPTH);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool first = ZERO_START && g == 0 && j == 0;
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j], act(4 * g + j), first ? zero : acc[0], 0, 0, 0);
+            }
+        }
+        return;
+    } else {
     static_assert(MB % 2 == 0, "row blocks are processed in pairs");
     constexpr int NG = (MB / 2) * TQ;
     f32x4 ra[DEPTH], rb[DEPTH];
@@ -307,6 +326,7 @@ __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load,
             acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, first ? zero : acc[mb], 0, 0, 0);
             acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, first ? zero : acc[mb + 1], 0, 0, 0);
         }
+    }
     }
 }
 
@@ -339,6 +359,7 @@ __device__ __forceinline__ void dense_layer_bf16(f32x16 (&acc)[MB], LoadFn load,
     }
 }
 
+bool encoder_dims_supported(int c1, int c2, int c3);
 // Host side: validate the descriptors of the C ABI and flatten them into CloudParams.
 int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out);
 

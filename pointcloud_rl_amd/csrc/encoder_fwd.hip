@@ -361,8 +361,11 @@ static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
     return PCRL_OK;
 }
 
-static bool dims_supported(int c1, int c2, int c3) {
-    return (c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256;
+// mlp_spec of every shipped pn_* SAC / DrQ config: [64,128,256] (dm_control), [128,128,256] (maniskill), [32,64,128]
+// (dm_control pn_motivating / pn_shift_motivating).  The class default [64,128,1024] (pointnet.py:81) is used by none of
+// them and is not built: c3 = 1024 does not fit the one-point-per-lane register layout (1024 accumulators per point).
+bool encoder_dims_supported(int c1, int c2, int c3) {
+    return ((c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256) || (c1 == 32 && c2 == 64 && c3 == 128);
 }
 
 }  // namespace pcrl
@@ -371,8 +374,8 @@ using namespace pcrl;
 
 extern "C" int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes) {
     if (!bytes) return fail(PCRL_E_ARG, "bytes is NULL");
-    if (c_in < 1 || c_in > PCRL_MAX_CHANNELS || !dims_supported(c1, c2, c3))
-        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256])", c_in, c1, c2, c3);
+    if (c_in < 1 || c_in > PCRL_MAX_CHANNELS || !encoder_dims_supported(c1, c2, c3))
+        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256] or [32,64,128])", c_in, c1, c2, c3);
     const PackedLayout L{(c_in + 1) / 2, c1, c2, c3};
     *bytes = sizeof(float) * (size_t)L.total();
     return PCRL_OK;
@@ -434,10 +437,12 @@ static int encoder_fwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     const int T0 = (p.cl.C + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     int rc = PCRL_E_ARG;
-#define PCRL_FWD_CASE(T0_, C1_)                                                   \
-    if (T0 == T0_ && w->c1 == C1_) rc = bf16 ? launch_fwd<T0_, C1_, 128, 256, true>(p, grid, st) : launch_fwd<T0_, C1_, 128, 256, false>(p, grid, st);
-    PCRL_FWD_CASE(2, 64) PCRL_FWD_CASE(3, 64) PCRL_FWD_CASE(4, 64) PCRL_FWD_CASE(5, 64)
-    PCRL_FWD_CASE(2, 128) PCRL_FWD_CASE(3, 128) PCRL_FWD_CASE(4, 128) PCRL_FWD_CASE(5, 128)
+#define PCRL_FWD_CASE(T0_, C1_, C2_, C3_)                                         \
+    if (T0 == T0_ && w->c1 == C1_ && w->c2 == C2_ && w->c3 == C3_)                \
+        rc = bf16 ? launch_fwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : launch_fwd<T0_, C1_, C2_, C3_, false>(p, grid, st);
+    PCRL_FWD_CASE(2, 64, 128, 256) PCRL_FWD_CASE(3, 64, 128, 256) PCRL_FWD_CASE(4, 64, 128, 256) PCRL_FWD_CASE(5, 64, 128, 256)
+    PCRL_FWD_CASE(2, 128, 128, 256) PCRL_FWD_CASE(3, 128, 128, 256) PCRL_FWD_CASE(4, 128, 128, 256) PCRL_FWD_CASE(5, 128, 128, 256)
+    PCRL_FWD_CASE(2, 32, 64, 128) PCRL_FWD_CASE(3, 32, 64, 128) PCRL_FWD_CASE(4, 32, 64, 128) PCRL_FWD_CASE(5, 32, 64, 128)
 #undef PCRL_FWD_CASE
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;

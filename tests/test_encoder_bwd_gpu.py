@@ -11,7 +11,9 @@ NAMES = {"conv0.weight": "w0", "conv0.bias": "b0", "conv1.weight": "w1", "norm1.
          "conv2.weight": "w2", "norm2.weight": "g2", "norm2.bias": "be2"}
 
 
-def torch_reference_grads(obs_np, w_np, gpool_np, jitter=None):
+def torch_reference_grads(obs_np, w_np, gpool_np, jitter=None, route=None):
+    """route: int argmax [B, c3] to send the gradient through instead of torch's own max (a 1-ulp near-tie between two
+    points is decided by the summation order; see profiles/r02_parity_errors.md)."""
     from oracle import torch_ref
     P = {}
     for ref_name, k in NAMES.items():
@@ -24,7 +26,8 @@ def torch_reference_grads(obs_np, w_np, gpool_np, jitter=None):
         obs["xyz"] = obs["xyz"] + torch.from_numpy(jitter)
     pre = torch_ref.pointnet_prepool(P, obs)
     pooled, idx = pre.max(-1)
-    (pooled * torch.from_numpy(gpool_np)).sum().backward()
+    routed = pooled if route is None else pre.gather(-1, torch.from_numpy(route).long()[..., None])[..., 0]
+    (routed * torch.from_numpy(gpool_np)).sum().backward()
     return {n: P[torch_ref.ENC + "conv.mlp." + n].grad.numpy() for n in NAMES}, idx.numpy().astype(np.int32), pooled.detach().numpy()
 
 
@@ -63,17 +66,25 @@ def assert_grads_close(got, ref):
     (2, 300, dict(pos_encoding=3), 64),  # C = 9
     (3, 250, dict(seg=1), 128),          # ManiSkill nets: C = 7, c1 = 128
     (1, 1, dict(), 64),                  # a single point owns every channel
+    (3, 260, dict(), 32),                # mlp_spec [32, 64, 128] (pn_motivating configs): tile mode (B < #CUs)
+    (300, 140, dict(), 32),              # the same nets, one workgroup per cloud (B >= #CUs)
+    (260, 130, dict(seg=1), 128),        # cloud mode with the ManiSkill nets
 ])
 def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
     obs = make_obs(B, N, seed=17 * B + N, **extra)
     C = sum(v.shape[1] for v in obs.values())
-    w = make_encoder_weights(C, c1, 128, 256, seed=N + 1)
-    gpool = np.random.RandomState(N).randn(B, 256).astype(np.float32)
+    c2, c3 = (64, 128) if c1 == 32 else (128, 256)
+    w = make_encoder_weights(C, c1, c2, c3, seed=N + 1)
+    gpool = np.random.RandomState(N).randn(B, c3).astype(np.float32)
     ref, idx_ref, pooled_ref = torch_reference_grads(obs, w, gpool)
     got, idx, pooled, n_act = hip_grads(obs, w, gpool, cuda)
-    assert np.array_equal(idx, idx_ref)
     np.testing.assert_allclose(pooled, pooled_ref, atol=1e-5, rtol=0)
-    assert np.array_equal(n_act, [len(np.unique(r)) for r in idx_ref])
+    if not np.array_equal(idx, idx_ref):
+        # ATen's summation order decided a near-tie the other way (a few of B x c3 entries at the larger sizes): the two
+        # candidates must hold the same maximum to rounding; the gradient is then compared along this kernel's routing
+        assert (idx != idx_ref).mean() < 1e-3
+        ref, _, _ = torch_reference_grads(obs, w, gpool, route=idx)
+    assert np.array_equal(n_act, [len(np.unique(r)) for r in idx])
     assert_grads_close(got, ref)
     # the same without the forward's pooled values (dense search for the owned channels)
     got_dense, _, _, _ = hip_grads(obs, w, gpool, cuda, with_pooled=False)

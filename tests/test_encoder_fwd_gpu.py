@@ -41,11 +41,14 @@ def _check(obs, w, dev, **kw):
     (5, 257, dict(pos_encoding=3), 64),        # K0 layout: C = 9
     (4, 200, dict(seg=1), 128),                # ManiSkill nets: C = 7, c1 = 128
     (2, 96, dict(rgb=False), 64),              # xyz only (C = 3 -> one zero-padded k-step)
+    (3, 300, dict(), 32),                      # mlp_spec [32, 64, 128] (configs/mfrl/sac/dm_control/pn_motivating.py:29)
+    (2, 1100, dict(pos_encoding=3), 32),       # the same nets, C = 9, more than 8 tiles per wave
 ])
 def test_fwd_matches_oracle_small(cuda, B, N, C_extra, c1):
     obs = make_obs(B, N, seed=B * 1000 + N, **C_extra)
     C = sum(v.shape[1] for v in obs.values())
-    w = make_encoder_weights(C, c1, 128, 256, seed=N)
+    c2, c3 = (64, 128) if c1 == 32 else (128, 256)
+    w = make_encoder_weights(C, c1, c2, c3, seed=N)
     _check(obs, w, cuda)
 
 

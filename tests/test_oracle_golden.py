@@ -83,7 +83,10 @@ def test_torch_ref_update_matches_reference(path, mirror):
     n_updates = int(d["meta/dims"][4])
     for u in range(1, n_updates + 1):
         agent.encoder_passes[0] = 0
-        ret = agent.update_parameters(torch_ref.batch_from_fixture(d, u), u, fixture_draws(d, u, "eps"), fixture_draws(d, u, "jitter"))
+        batch = torch_ref.batch_from_fixture(d, u)
+        if "meta/use_episode_dones" in d.files and bool(d["meta/use_episode_dones"]):
+            batch["dones"] = batch["episode_dones"]              # sac.py:106-107
+        ret = agent.update_parameters(batch, u, fixture_draws(d, u, "eps"), fixture_draws(d, u, "jitter"))
         if mirror:
             assert agent.encoder_passes[0] == int(d[f"u{u}/n_encoder_passes"])
         for k, v in ret.items():

@@ -34,8 +34,11 @@ def build_from_fixture(d, dev, fused=True):
     kind = str(d["meta/agent_type"])
     hidden = d["init/actor.backbone.final_mlp.mlp.linear0.weight"].shape[0]
     C = d["init/actor.backbone.visual_nn.conv.mlp.conv0.weight"].shape[1]
+    conv = "init/actor.backbone.visual_nn.conv.mlp.conv%d.weight"
+    nets = ([int(d[conv % i].shape[0]) for i in range(3)], int(d["init/actor.backbone.visual_nn.final_mlp.0.weight"].shape[0]))
     if kind == "SAC":
-        cfg = configs.sac_dmc(C, A, B, hidden)
+        extra = dict(use_episode_dones=True) if ("meta/use_episode_dones" in d.files and bool(d["meta/use_episode_dones"])) else {}
+        cfg = configs.sac_dmc(C, A, B, hidden, nets=nets, **extra)
     elif S == 0:
         cfg = configs.drq_dmc(C, A, B, hidden)
     else:

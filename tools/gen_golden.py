@@ -110,6 +110,7 @@ def gen_step(name, cfg_file, overrides, obs_kw, B, N, A, n_updates, seed):
     out["meta/hyper"] = np.array([agent.gamma, agent.reward_scale, float(np.exp(float(agent.log_alpha.item()))),
                                   agent.target_entropy, agent.actor_update_interval, agent.target_update_interval,
                                   getattr(agent, "num_aug", 1)], dtype=np.float64)
+    out["meta/use_episode_dones"] = np.array(bool(getattr(agent, "use_episode_dones", False)))
     out["meta/update_coeff_default"] = np.array(agent.update_coeff["default"] if isinstance(agent.update_coeff, dict) else agent.update_coeff)
     for k, v in unique_named_params(agent).items():
         out[f"init/{k}"] = np_(v)
@@ -158,7 +159,7 @@ def gen_step(name, cfg_file, overrides, obs_kw, B, N, A, n_updates, seed):
         for side in ("obs", "next_obs"):
             for k, v in batch[side].items():
                 out[f"u{u}/batch/{side}/{k}"] = v
-        for k in ("actions", "rewards", "dones"):
+        for k in ("actions", "rewards", "dones") + (("episode_dones",) if getattr(agent, "use_episode_dones", False) else ()):
             out[f"u{u}/batch/{k}"] = batch[k]
 
         class Mem:
@@ -202,6 +203,13 @@ def gen_step(name, cfg_file, overrides, obs_kw, B, N, A, n_updates, seed):
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])          # fixture names to (re)generate; none: all
+
+    def _want(name):
+        return not only or name in only
+    _gen_encoder, _gen_step = gen_encoder, gen_step
+    gen_encoder = lambda name, *a, **k: _gen_encoder(name, *a, **k) if _want(name) else None
+    gen_step = lambda name, *a, **k: _gen_step(name, *a, **k) if _want(name) else None
     gen_encoder("encoder_dmc_c6", {}, [64, 128, 256], 50, B=4, N=100, seed=1)
     gen_encoder("encoder_dmc_c9_posenc", dict(pos_encoding=3), [64, 128, 256], 50, B=2, N=96, seed=2)
     gen_encoder("encoder_maniskill_c7", dict(seg=1), [128, 128, 256], 128, B=3, N=75, seed=3)
@@ -220,3 +228,7 @@ if __name__ == "__main__":
     }
     gen_step("drq_maniskill_jitter_small", f"{REF}/configs/mfrl/drq/maniskill/pn_jitter.py", ms_heads, dict(seg=1, agent=10),
              B=4, N=48, A=8, n_updates=2, seed=2)
+    # the small encoder of the "motivating" configs: mlp_spec [32, 64, 128], use_episode_dones=True
+    gen_encoder("encoder_dmc_motivating_c6", {}, [32, 64, 128], 50, B=3, N=90, seed=4)
+    gen_step("sac_dmc_motivating_small", f"{REF}/configs/mfrl/sac/dm_control/pn_motivating.py", small_heads, {}, B=8, N=80, A=4,
+             n_updates=4, seed=5)
