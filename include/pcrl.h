@@ -273,6 +273,47 @@ int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy
                                 float* dgamma, float* dbeta, int32_t accumulate,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* The backward kernel alone: the per-block partial sums of dgamma / dbeta stay in `workspace` as [ceil(M/4)][2][F] for a later
+ * pcrl_colsum_jobs_f32 launch (which can reduce several such leftovers at once). */
+int pcrl_layernorm_rows_bwd_partials_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                         const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                         void* workspace, size_t workspace_bytes, void* stream);
+/* Fixed-order column reductions of per-workgroup partial results, up to 12 jobs in one launch:
+ *   out[c] = scale * (op == 0 ? sum : max)_{b < nblk} part[b * blk_stride + c]   for c < ncols. */
+typedef struct pcrl_colsum_job { const float* part; int64_t blk_stride; int32_t nblk, ncols; float* out; float scale; int32_t op; } pcrl_colsum_job;
+int pcrl_colsum_jobs_f32(const pcrl_colsum_job* jobs, int32_t n, void* stream);
+
+/* ---- head tails: the last Linear of a head fused with what follows it (H = hidden width, multiple of 256) ------------------------
+ * pcrl_q_tail_critic_f32: for both Q heads h (second head at + *_head_stride floats):
+ *   q_next[m][h] = h2_target[h][m] . w2_target[h] + b2_target[h],  q[m][h] = h2[h][m] . w2[h] + b2[h]   (LinearMLP's last
+ *   Linear, pyrl/networks/backbones/mlp.py:97-100), then exactly pcrl_sac_critic_loss_f32's target / loss / dq (sac.py:125-157,
+ *   drq.py:76-103; group in {1, 2, 4}), dh2[h][m] = dq[m][h] w2[h] (.) [h2[h][m] > 0], and per-workgroup partials:
+ *   part [ceil(M/4)][2][H + 4] (columns < H: dW2[h] = sum_m dq[m][h] h2[h][m]; column H: db2[h]) and stat_part [ceil(M/4)][4]
+ *   = {sum (q-y)^2, max |q-y|, sum min_h q, sum y} -- reduce with pcrl_colsum_jobs_f32 (sizes: pcrl_q_tail_workspace_floats).
+ * pcrl_q_tail_actor_f32: q = Q(s, pi(s)) likewise, dq = d(-mean_m min_h q)/dq (sac.py:177-183), dh2, d_neglogp = -alpha / M,
+ *   stat_part [ceil(M/4)][4] = {sum min_h q, sum neg_logp, 0, 0}; pcrl_actor_finalize_f32 turns those into the actor / temperature
+ *   losses and d(alpha_loss)/d(log_alpha) (sac.py:183-195), i.e. the two together are pcrl_sac_actor_loss_f32 + the GEMMs around it.
+ * pcrl_policy_tail_fwd_f32: feat = h2 w2^T + b2 ([M][2A], the policy's last Linear) followed by pcrl_tanh_gaussian_fwd_f32 /
+ *   pcrl_tanh_gaussian_sample_fwd_f32 on it (eps == NULL: in-kernel Philox draws written to eps_out). */
+int pcrl_q_tail_workspace_floats(int32_t M, int32_t H, size_t* part_floats, size_t* stat_floats);
+int pcrl_q_tail_critic_f32(const float* h2, int64_t h2_head_stride, const float* w2, const float* b2, int64_t w_head_stride,
+                           const float* h2_target, int64_t h2_target_head_stride, const float* w2_target, const float* b2_target,
+                           int64_t w_target_head_stride, const float* neg_logp_next, const float* rewards, const uint8_t* dones,
+                           int32_t rd_row_div, const float* log_alpha, float gamma, float reward_scale, int32_t ignore_dones,
+                           int32_t group, int32_t M, int32_t H, float* q, int64_t ld_q, float* q_target, float* dq, int64_t ld_dq,
+                           float* dh2, int64_t dh2_head_stride, float* part, float* stat_part, void* stream);
+int pcrl_q_tail_actor_f32(const float* h2, int64_t h2_head_stride, const float* w2, const float* b2, int64_t w_head_stride,
+                          const float* neg_logp, const float* log_alpha, int32_t M, int32_t H, float* q, int64_t ld_q,
+                          float* dq, int64_t ld_dq, float* dh2, int64_t dh2_head_stride, float* d_neglogp, float* stat_part,
+                          void* stream);
+int pcrl_actor_finalize_f32(const float* stat_part, int32_t M, const float* log_alpha, float target_entropy, float* alpha_grad,
+                            float* stats, void* stream);
+int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
+                             uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
+                             const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
+                             float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
+                             void* stream);
+
 /* ---- update tail ---------------------------------------------------------------------------------
  * Squashed-Gaussian policy head, mode "max-entropy" (TanhGaussianHead + ScaledTanhNormal,
  * pyrl/networks/regression_heads/gaussian.py:23-50,83-87; pyrl/utils/torch/distributions.py:89,116-127):

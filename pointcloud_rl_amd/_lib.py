@@ -54,6 +54,11 @@ class LnJob(ctypes.Structure):
                 ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2), ("cat_row_div", ctypes.c_int32 * 2)]
 
 
+class ColsumJob(ctypes.Structure):
+    _fields_ = [("part", ctypes.c_void_p), ("blk_stride", ctypes.c_int64), ("nblk", ctypes.c_int32), ("ncols", ctypes.c_int32),
+                ("out", ctypes.c_void_p), ("scale", ctypes.c_float), ("op", ctypes.c_int32)]
+
+
 class GatherSeg(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
 

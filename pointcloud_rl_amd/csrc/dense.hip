@@ -737,6 +737,21 @@ extern "C" int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const fl
     return pcrl_layernorm_rows_fwd_multi_f32(&job, 1, gamma, beta, F, eps, stream);
 }
 
+extern "C" int pcrl_layernorm_rows_bwd_partials_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                                    const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy0 || !xhat || !rstd || !gamma || !dx) return fail(PCRL_E_ARG, "NULL argument");
+    if (F < 1 || F > 256) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256");
+    if (M == 0) return PCRL_OK;
+    const int nblk = (M + 3) / 4;
+    const size_t need = sizeof(float) * (size_t)nblk * 2 * F;
+    if (!workspace || workspace_bytes < need) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+    LnBwdParams p{dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, static_cast<float*>(workspace)};
+    hipLaunchKernelGGL(layernorm_rows_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("layernorm_rows_bwd_kernel");
+    return PCRL_OK;
+}
+
 extern "C" int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
                                            const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
                                            float* dgamma, float* dbeta, int32_t accumulate,

@@ -83,38 +83,6 @@ struct BwdParams {
     int parts;               // kernel B: workgroups per cloud (1, 2, 4 or 8; > 1 only for small batches)
 };
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return u2f((unsigned)__builtin_amdgcn_update_dpp(0, (int)f2u(v), CTRL, 0xF, 0xF, false));
-}
-// Sum over the 32 lanes of each wave half, same fixed butterfly order in every lane.
-__device__ __forceinline__ float allreduce_add32(float v) {
-    v = v + dpp_f<0xB1>(v);
-    v = v + dpp_f<0x4E>(v);
-    v = v + dpp_f<0x141>(v);
-    v = v + dpp_f<0x140>(v);
-    v = v + u2f((unsigned)__builtin_amdgcn_ds_swizzle((int)f2u(v), 0x401F));
-    return v;
-}
-
-// Sixteen independent 32-lane sums advanced together (the dependent DPP chains of one sum at a time cost ~100
-// cycles each); lane ^ 16 through v_permlane16_swap instead of ds_swizzle keeps the LDS pipe out of it.
-__device__ __forceinline__ void allreduce_add32_x16(float (&v)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0xB1>(v[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x4E>(v[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x141>(v[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = v[r] + dpp_f<0x140>(v[r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        auto sw = __builtin_amdgcn_permlane16_swap(f2u(v[r]), f2u(v[r]), false, false);
-        v[r] = u2f(sw[0]) + u2f(sw[1]);
-    }
-}
-
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
 template <int C>
 __device__ __forceinline__ float ln_to_xhat(f32x16 (&a)[C / 32], float eps) {

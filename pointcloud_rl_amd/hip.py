@@ -407,6 +407,61 @@ def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld
                                         _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
 
 
+def layernorm_rows_bwd_partials(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, workspace):
+    """layernorm_rows_bwd without the final column sums: the [ceil(M/4)][2][F] partials stay in `workspace` (float32 tensor)."""
+    check(lib().pcrl_layernorm_rows_bwd_partials_f32(ctypes.c_void_p(dy0), ctypes.c_void_p(dy1) if dy1 else None, ctypes.c_int64(lddy), _ptr(xhat),
+                                                     _ptr(rstd), _ptr(gamma), M, F, _ptr(dx), ctypes.c_int64(lddx), _ptr(workspace),
+                                                     ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
+
+
+def colsum_jobs(jobs):
+    """jobs: [(part ptr (int), blk_stride, nblk, ncols, out ptr (int), scale, op)] -> out[c] = scale * (sum | max)_b part[b * blk_stride + c]."""
+    arr = (_lib.ColsumJob * len(jobs))()
+    for j, (part, stride, nblk, ncols, out, scale, op) in zip(arr, jobs):
+        j.part, j.blk_stride, j.nblk, j.ncols, j.out, j.scale, j.op = part, stride, nblk, ncols, out, scale, op
+    check(lib().pcrl_colsum_jobs_f32(arr, len(jobs), _stream()))
+
+
+def q_tail_workspace_floats(M, H):
+    a, b = ctypes.c_size_t(), ctypes.c_size_t()
+    check(lib().pcrl_q_tail_workspace_floats(M, H, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+def q_tail_critic(h2, h2_hs, w2, b2, w_hs, h2_t, h2_t_hs, w2_t, b2_t, w_t_hs, nlp_next, rewards, dones_u8, rd_row_div, log_alpha, gamma,
+                  reward_scale, ignore_dones, group, M, H, q, q_target, dq, dh2, part, stat_part):
+    """See include/pcrl.h; q / dq are [M, 2], dh2 [2, M, H]."""
+    with _span("q_tail"):
+        check(lib().pcrl_q_tail_critic_f32(_ptr(h2), ctypes.c_int64(h2_hs), _ptr(w2), _ptr(b2), ctypes.c_int64(w_hs), _ptr(h2_t),
+                                           ctypes.c_int64(h2_t_hs), _ptr(w2_t), _ptr(b2_t), ctypes.c_int64(w_t_hs), _ptr(nlp_next), _ptr(rewards),
+                                           _ptr(dones_u8), int(rd_row_div), _ptr(log_alpha), _f(gamma), _f(reward_scale), int(ignore_dones),
+                                           int(group), M, H, _ptr(q), ctypes.c_int64(2), _ptr(q_target), _ptr(dq), ctypes.c_int64(2), _ptr(dh2),
+                                           ctypes.c_int64(M * H), _ptr(part), _ptr(stat_part), _stream()))
+
+
+def q_tail_actor(h2, h2_hs, w2, b2, w_hs, neg_logp, log_alpha, M, H, q, dq, dh2, d_neglogp, stat_part):
+    with _span("q_tail"):
+        check(lib().pcrl_q_tail_actor_f32(_ptr(h2), ctypes.c_int64(h2_hs), _ptr(w2), _ptr(b2), ctypes.c_int64(w_hs), _ptr(neg_logp), _ptr(log_alpha),
+                                          M, H, _ptr(q), ctypes.c_int64(2), _ptr(dq), ctypes.c_int64(2), _ptr(dh2), ctypes.c_int64(M * H),
+                                          _ptr(d_neglogp), _ptr(stat_part), _stream()))
+
+
+def actor_finalize(stat_part, M, log_alpha, target_entropy, alpha_grad, stats):
+    check(lib().pcrl_actor_finalize_f32(_ptr(stat_part), M, _ptr(log_alpha), _f(target_entropy), _ptr(alpha_grad), _ptr(stats), _stream()))
+
+
+def policy_tail_fwd(h2, M, H, w2, b2, A, eps, seed, step_counter, draw_id, eps_out, scale, bias, ls_min, ls_max, epsilon, feat, action, ld_action,
+                    neg_logp, saved=None, action2_ptr=None, ld_action2=0):
+    """The policy's last Linear + TanhGaussianHead "max-entropy"; eps None: Philox draws in the kernel (written to eps_out)."""
+    _check_f32_vec(scale, A, "scale"), _check_f32_vec(bias, A, "bias")
+    with _span("policy_tail"):
+        check(lib().pcrl_policy_tail_fwd_f32(_ptr(h2), M, H, _ptr(w2), _ptr(b2), A, _ptr(eps), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(step_counter),
+                                             int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), _f(ls_min), _f(ls_max), _f(epsilon), _ptr(feat),
+                                             ctypes.c_int64(2 * A), _ptr(action), ctypes.c_int64(ld_action),
+                                             ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2), _ptr(neg_logp),
+                                             _ptr(saved), _stream()))
+
+
 def gather_segments(pairs):
     """ctypes segment table for replay_gather / replay_sample_gather (build once, reuse every step):
     pairs = [(storage [capacity, ...], staging [B, ...])] contiguous tensors of equal row size."""

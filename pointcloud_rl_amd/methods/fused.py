@@ -147,6 +147,9 @@ class FusedStep:
         assert self.Din_q == self.Din_a + self.A and self.S >= 0
         self.ldq, self.lda = ceil4(self.Din_q), ceil4(self.Din_a)
         self.bufs = {}
+        # head tails (csrc/headtail.hip): the last Linear of a head fused with the loss / squashed-Gaussian head that follows
+        self.tails = (self.H % 256 == 0 and self.H <= 1024 and 2 * self.A <= 64 and self.q.dims[2][1] == 1
+                      and not bool(int(__import__("os").environ.get("PCRL_NO_TAILS", "0"))))
         dev = fc.data.device
         self.stats_c = torch.zeros(4, device=dev)
         self.stats_a = torch.zeros(3, device=dev)
@@ -212,12 +215,19 @@ class FusedStep:
         a, A, H = self.a, self.A, self.H
         h1, h2 = self._buf(f"pi_h1_{tag}", 1, M, H), self._buf(f"pi_h2_{tag}", 1, M, H)
         feat = self._buf(f"pi_out_{tag}", M, 2 * A)
-        mlp_forward(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
         head = a.actor.head
         eps = self._buf(f"pi_eps_{tag}", M, A)
         act = self._buf(f"pi_act_{tag}", M, A)
         nlp = self._buf(f"pi_nlp_{tag}", M)
         saved = self._buf(f"pi_saved_{tag}", M, 2 * A) if save else None
+        if self.tails:                   # two layers as GEMMs, the last one inside the head kernel
+            launch_layers(mlp_forward_descs(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)[:2])
+            eps_in = head._standard_normal(eps) if head.noise_override else None
+            hip.policy_tail_fwd(h2, M, H, self.pi.W(2), self.pi.Bv(2), A, eps_in, self.seed, a.critic_optim.step_counter,
+                                0 if tag == "n" else 1, eps, self.head_scale, self.head_bias, head.log_std_min, head.log_std_max,
+                                head.epsilon, feat, act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+            return feat, (eps_in if eps_in is not None else eps), saved, nlp, h1, h2
+        mlp_forward(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
         if head.noise_override:          # parity tests inject the draws
             eps = head._standard_normal(eps)
             hip.tanh_gaussian_fwd(feat, 2 * A, eps, self.head_scale, self.head_bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
@@ -279,27 +289,55 @@ class FusedStep:
         tgt = a._target_flat.data
         q_h1, q_h2 = self._buf("q_h1", 2, M, H), self._buf("q_h2", 2, M, H)
         q = self._buf("q", M, 2)
-        launch_layers(mlp_forward_descs(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1),
-                      mlp_forward_descs(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1))
-
-        # ---- critic loss, backward through heads, feature head and encoder (sac.py:137-148) ----
+        q_tgt_descs = mlp_forward_descs(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1)
+        q_on_descs = mlp_forward_descs(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1)
         q_target, dq = self._buf("q_target", M), self._buf("dq", M, 2)
         dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
-        hip.sac_critic_loss(q_next, 2, nlp_n, rewards, dones_u8, a.log_alpha, a.gamma,
-                            a.reward_scale if a.metric_prefix == "sac" else 1.0, a.ignore_dones, group, q, 2, M, 2,
-                            q_target, dq, 2, self.stats_c, rd_row_div=repeat)
+        reward_scale = a.reward_scale if a.metric_prefix == "sac" else 1.0
         dh1, dh2 = self._buf("q_dh1", 2, M, H), self._buf("q_dh2", 2, M, H)
         dX0 = self._buf("q_dX0", 2, M, ceil4(F))
-        mlp_backward(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F), ld_dx=ceil4(F))
+        off, pre = self.off, "values.0.backbone.visual_nn.final_mlp."
+        dy = self._buf("feat_dy", M, F)
+        ws = self._buf("ln_ws", ((M + 3) // 4) * 2 * F)
+        bwd_stages = mlp_backward_descs(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F),
+                                        ld_dx=ceil4(F))
+        if self.tails and group in (1, 2, 4):
+            # ---- two layers as GEMMs; the last layer of the four heads, the TD target / critic loss (sac.py:125-157) and the first
+            # backward stage in ONE launch; its per-workgroup partials (dW2, db2, the logged statistics) are reduced by the same
+            # column-sum launch that finishes the feature LayerNorm's backward ----
+            launch_layers(q_tgt_descs[:2], q_on_descs[:2])
+            n_part, n_stat = hip.q_tail_workspace_floats(M, H)
+            part, stat_part = self._buf("q_tail_part", n_part), self._buf("q_tail_stat", n_stat)
+            hs = self.q.hs
+            hip.q_tail_critic(q_h2, M * H, self.q.W(2), self.q.Bv(2), hs, qn_h2, M * H, self.q.W(2, tgt, -self.q_base),
+                              self.q.Bv(2, tgt, -self.q_base), hs, nlp_n, rewards, dones_u8, repeat, a.log_alpha, a.gamma, reward_scale,
+                              a.ignore_dones, group, M, H, q, q_target, dq, dh2, part, stat_part)
+            launch_layers(*[bwd_stages[1:]])
+            hip.layernorm_rows_bwd_partials(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd,
+                                            fc.data[off[pre + "1.weight"]:], M, F, dy, F, ws)
+            n_wg, n_ln, Hp = (M + 3) // 4, (M + 3) // 4, H + 4
+            g = fc.grad.data_ptr()
+            jobs = [(ws.data_ptr(), 2 * F, n_ln, F, g + 4 * off[pre + "1.weight"], 1.0, 0),
+                    (ws.data_ptr() + 4 * F, 2 * F, n_ln, F, g + 4 * off[pre + "1.bias"], 1.0, 0)]
+            for h in range(2):
+                jobs.append((part.data_ptr() + 4 * h * Hp, 2 * Hp, n_wg, H, g + 4 * (self.q.w[2] + h * hs), 1.0, 0))
+                jobs.append((part.data_ptr() + 4 * (h * Hp + H), 2 * Hp, n_wg, 1, g + 4 * (self.q.b[2] + h * hs), 1.0, 0))
+            sc = self.stats_c.data_ptr()
+            for k, (scale_k, op) in enumerate(((1.0 / M, 0), (1.0, 1), (1.0 / M, 0), (1.0 / M, 0))):
+                jobs.append((stat_part.data_ptr() + 4 * k, 4, n_wg, 1, sc + 4 * k, scale_k, op))
+            hip.colsum_jobs(jobs)
+        else:
+            launch_layers(q_tgt_descs, q_on_descs)
+            # ---- critic loss, backward through heads, feature head and encoder (sac.py:137-148) ----
+            hip.sac_critic_loss(q_next, 2, nlp_n, rewards, dones_u8, a.log_alpha, a.gamma, reward_scale, a.ignore_dones, group, q, 2, M, 2,
+                                q_target, dq, 2, self.stats_c, rd_row_div=repeat)
+            launch_layers(*[bwd_stages])
+            hip.layernorm_rows_bwd(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd, fc.data[off[pre + "1.weight"]:], M, F,
+                                   dy, F, fc.grad[off[pre + "1.weight"]:], fc.grad[off[pre + "1.bias"]:], ws)
         # The Q heads' gradients (the tail of the critic's flat buffer: 2 x 1.1 M floats at K1 of 2.27 M) are final: their
         # all-reduce runs under the feature-head and encoder backward, only the small head of the buffer waits for those.
         if exchanging:
             yield ("start", [fc.grad[self.q_base:]])
-        off, pre = self.off, "values.0.backbone.visual_nn.final_mlp."
-        dy = self._buf("feat_dy", M, F)
-        ws = self._buf("ln_ws", ((M + 3) // 4) * 2 * F)
-        hip.layernorm_rows_bwd(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd, fc.data[off[pre + "1.weight"]:], M, F,
-                               dy, F, fc.grad[off[pre + "1.weight"]:], fc.grad[off[pre + "1.bias"]:], ws)
         c3 = self.c3
         dpooled = self._buf("dpooled", M, c3)
         hip.gemm_group([hip.gemm_desc(dy, pooled_o, fc.grad[off[pre + "0.weight"]:], F, c3 + 1, M, (1, F), (c3, 1), c3, ones_col=c3,
@@ -322,14 +360,24 @@ class FusedStep:
             feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)
             q_pi = self._buf("q_pi", Ma, 2)
-            mlp_forward(self.q, None, 0, XQ_a, ldq, Ma, (qa_h1, qa_h2), 2, q_pi, 1)
             dq_pi = self._buf("dq_pi", Ma, 2)
             fal = a._flat["alpha"]
-            hip.sac_actor_loss(q_pi, 2, nlp, a.log_alpha, a.target_entropy, Ma, 2, dq_pi, 2, self.d_nlp, fal.grad, self.stats_a)
             da_h1, da_h2 = self._buf("qa_dh1", 2, Ma, H), self._buf("qa_dh2", 2, Ma, H)
             d_act = self._buf("d_act", 2, Ma, ceil4(A))
-            mlp_backward(self.q, XQ_a, ldq, Ma, qa_h1, qa_h2, dq_pi, (2, 1), 1, da_h1, da_h2, grad=None, dX=d_act,
-                         dx_cols=(F + S, A), ld_dx=ceil4(A))
+            qa_descs = mlp_forward_descs(self.q, None, 0, XQ_a, ldq, Ma, (qa_h1, qa_h2), 2, q_pi, 1)
+            qa_bwd = mlp_backward_descs(self.q, XQ_a, ldq, Ma, qa_h1, qa_h2, dq_pi, (2, 1), 1, da_h1, da_h2, grad=None, dX=d_act,
+                                        dx_cols=(F + S, A), ld_dx=ceil4(A))
+            if self.tails:
+                launch_layers(qa_descs[:2])
+                _, n_stat = hip.q_tail_workspace_floats(Ma, H)
+                stat_a = self._buf("qa_tail_stat", n_stat)
+                hip.q_tail_actor(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp, stat_a)
+                hip.actor_finalize(stat_a, Ma, a.log_alpha, a.target_entropy, fal.grad, self.stats_a)
+                launch_layers(*[qa_bwd[1:]])
+            else:
+                launch_layers(qa_descs)
+                hip.sac_actor_loss(q_pi, 2, nlp, a.log_alpha, a.target_entropy, Ma, 2, dq_pi, 2, self.d_nlp, fal.grad, self.stats_a)
+                launch_layers(*[qa_bwd])
             head = a.actor.head
             dfeat = self._buf("pi_dfeat", Ma, 2 * A)
             hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, self.head_scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
