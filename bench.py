@@ -248,7 +248,8 @@ def main():
         # (same kernels, same launch geometry; rocprofv3 --kernel-trace of this command sees both passes).
         agent.enable_graphs(False)
         hip.TIMER = hip.KernelTimer()
-        for _ in range(min(args.steps, 40)):
+        timed_eager_steps = min(args.steps, 40) // 2 * 2 or 2          # an even count: actor steps are every second one
+        for _ in range(timed_eager_steps):
             updates += 1
             agent.update_parameters(memory, updates)
         sync()
@@ -266,8 +267,10 @@ def main():
         # the launches of one step have different cloud counts only for DrQ; for SAC every launch encodes b_rank clouds
         is_bf16 = getattr(agent.encoder, "compute_dtype", "f32") == "bf16"
         num_aug = getattr(agent, "num_aug", 1)
-        # clouds per encoder launch, averaged over a step's 2.5 launches: SAC b; DrQ: s' and s on b*num_aug clouds, the actor pass on b
-        clouds_per_launch = b_rank * (2 * num_aug + 0.5) / 2.5
+        # clouds per encoder launch: a step encodes s' and s (b * num_aug clouds each; ONE launch when the replay stages them back
+        # to back) and, every second step, s again for the actor (b clouds) -- divided by the launches the timer counted
+        steps_timed = timed_eager_steps if graphed else args.steps
+        clouds_per_launch = b_rank * (2 * num_aug + 0.5) * steps_timed / max(n_fwd, 1)
         flops_per_launch = f_pt * clouds_per_launch * wl["N"]
         achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
         peak = 2500.0 if is_bf16 else 157.3        # dense MFMA peaks of MI355X_MICROARCH.md (bf16 / fp32)

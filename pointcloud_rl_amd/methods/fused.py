@@ -104,6 +104,24 @@ def mlp_backward(*args, **kwargs):
     launch_layers(mlp_backward_descs(*args, **kwargs))
 
 
+def _adjacent_halves(first, second):
+    """{key: [2 B, ...] view} when every tensor of `second` starts where the same key of `first` ends (same storage, shape,
+    dtype, contiguous) and neither carries an augmentation or a virtual repeat; else None."""
+    if getattr(first, "aug", None) or getattr(second, "aug", None) or getattr(first, "repeat", 1) != 1 or getattr(second, "repeat", 1) != 1:
+        return None
+    if not isinstance(first, dict) or not isinstance(second, dict) or first.keys() != second.keys():
+        return None
+    out = {}
+    for k, a in first.items():
+        b = second[k]
+        if not (torch.is_tensor(a) and torch.is_tensor(b) and a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+                and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and b.storage_offset() == a.storage_offset() + a.numel()):
+            return None
+        out[k] = a.as_strided((2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return out
+
+
 class FusedStep:
     """Buffers + launch sequence of one update step for a fixed (rows, actor rows) geometry."""
 
@@ -275,9 +293,16 @@ class FusedStep:
         # (sac.py:136).  Both encoder passes first, then the head GEMMs of the two independent branches pairwise in
         # one launch each (feature Linear of s' and s; target Q heads on s' and online Q heads on s).
         vis_n, state_n = split(next_obs)
-        pooled_n, _, _ = enc.encode_raw(vis_n)
         vis_o, state_o = split(obs)
-        pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
+        both = _adjacent_halves(vis_o, vis_n)
+        if both is not None:              # s and s' sit back to back (DeviceReplay's staging): one launch of 2 M clouds
+            pooled_all, argmax_all, _ = enc.encode_raw(both)
+            Mo = pooled_all.shape[0] // 2
+            pooled_o, pooled_n, argmax_o = pooled_all[:Mo], pooled_all[Mo:], argmax_all[:Mo]
+            ctx_o = enc.ctx_for(vis_o, pooled_o)
+        else:
+            pooled_n, _, _ = enc.encode_raw(vis_n)
+            pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
         XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
         (_, _), (xhat, rstd) = self._features([

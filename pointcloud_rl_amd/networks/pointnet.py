@@ -189,6 +189,14 @@ class PointNet(ExtendedModule):
         pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16")
         return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed, pooled)
 
+    def ctx_for(self, inputs, pooled):
+        """The backward context of encode_raw for `inputs` when its rows were encoded as part of a larger launch (`pooled`:
+        their rows of that launch's output)."""
+        aug = getattr(inputs, "aug", None)
+        desc, keep = hip.make_cloud_desc(inputs)
+        ew, packed = self._weights_desc()
+        return desc, keep, aug, (hip.make_aug_desc(**aug) if aug else None), ew, packed, pooled
+
     def backward_raw(self, ctx, argmax, grad_pooled, out):
         """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
         desc, keep, aug, aug_desc, ew, packed, pooled = ctx

@@ -122,6 +122,13 @@ class DeviceReplay:
     def _stage(self, batch_size):
         if batch_size not in self._staging:
             flat = {k: torch.zeros((batch_size,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in self.storage.items()}
+            # obs/<key> and next_obs/<key> are the two halves of ONE [2 B, ...] allocation: an encoder that sees them adjacent
+            # encodes s and s' in one launch (methods/fused.py)
+            for k in list(flat):
+                twin = "next_obs/" + k[len("obs/"):]
+                if k.startswith("obs/") and twin in flat and flat[twin].shape == flat[k].shape and flat[twin].dtype == flat[k].dtype:
+                    pair = torch.zeros((2 * batch_size,) + tuple(flat[k].shape[1:]), dtype=flat[k].dtype, device=self.device)
+                    flat[k], flat[twin] = pair[:batch_size], pair[batch_size:]
             segs = hip.gather_segments([(self.storage[k], flat[k]) for k in self.storage])
             flat["is_valid"] = torch.ones(batch_size, 1, dtype=torch.bool, device=self.device)        # sampling_strategy.py:101
             idx = torch.zeros(batch_size, dtype=torch.int32, device=self.device)

@@ -379,3 +379,37 @@ def test_acting_matches_the_reference_agent_loaded_from_its_checkpoint(cuda):
         np.testing.assert_allclose(got.cpu().numpy(), z[mode], atol=1e-5, rtol=0, err_msg=mode)
     acts, states = agent(obs, mode="eval", rnn_mode="with_states")
     assert states is None and torch.equal(acts, agent(obs, mode="eval"))
+
+
+def test_device_replay_batches_are_encoded_in_one_launch_with_the_same_result(cuda):
+    """DeviceReplay stages obs/<key> and next_obs/<key> as the halves of one allocation; the fused step then encodes s and s'
+    in ONE launch.  Same metrics and parameters (bitwise) as the two-launch path on the same data."""
+    import torch
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent, fused
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 16, 128, 6
+
+    def run(merge):
+        cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        mem = DeviceReplay(64, device=cuda, seed=3)
+        mem.push_batch(make_batch_np(64, N, A, seed=5))
+        orig = fused._adjacent_halves
+        seen = []
+        fused._adjacent_halves = (lambda a, b: seen.append(orig(a, b)) or seen[-1]) if merge else (lambda a, b: None)
+        try:
+            rets = [agent.update_parameters(mem, u) for u in range(1, 5)]
+        finally:
+            fused._adjacent_halves = orig
+        if merge:
+            assert all(s is not None and s["xyz"].shape[0] == 2 * B for s in seen)
+        return rets, {n: p.detach().clone() for n, p in agent.named_parameters()}
+
+    (r1, p1), (r2, p2) = run(True), run(False)
+    assert r1 == r2
+    for n in p1:
+        assert torch.equal(p1[n], p2[n]), n
