@@ -195,6 +195,30 @@ class SAC(BaseAgent):
         self.use_fused_step = True   # autograd-free launch sequence (methods/fused.py) when the topology allows
         self.sync_alpha = True     # data-parallel: all-reduce log_alpha's gradient too (the reference does not)
 
+    # -- acting ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, obs, **kwargs):
+        """BaseAgent.forward (module_utils.py:147-159).  On the MI355X and with the shipped actor topology the action comes from
+        the fused acting path (methods/acting.py: seven launches); anything else goes through the module tree."""
+        from ..utils.torch_utils import to_torch
+        from .acting import MEAN_MODES, SAMPLE_MODES, FusedActor
+        mode = kwargs.get("mode", "explore")
+        extra = {k: v for k, v in kwargs.items() if k not in ("mode", "rnn_mode", "rnn_states", "prev_actions", "episode_dones", "is_valid")}
+        fast = self.__dict__.get("_fused_actor")
+        if fast is None and self.device.type == "cuda" and not extra and mode in SAMPLE_MODES + MEAN_MODES and FusedActor.supported(self.actor) \
+                and getattr(self, "use_fused_acting", True):
+            fast = self.__dict__["_fused_actor"] = FusedActor(self.actor)
+        if fast is None or extra or mode not in SAMPLE_MODES + MEAN_MODES or self.device.type != "cuda" or kwargs.get("num_samples", 1) != 1:
+            return super().forward(obs, **kwargs)
+        obs = to_torch(obs, device=self.device, non_blocking=True)
+        if self.obs_processor is not None:
+            obs = self.obs_processor({"obs": obs})["obs"]
+        actions = fast(obs, mode=mode)
+        rnn_mode = kwargs.get("rnn_mode", "base")
+        if rnn_mode == "base":
+            return actions
+        return actions, ([None] * 3 if rnn_mode == "full_states" else None)
+
     # ---------------------------------------------------------------------------------------------
     @property
     def encoder(self):

@@ -166,7 +166,15 @@ def to_torch(x, device=None, non_blocking=False):
     """Nested dict/list of numpy arrays or tensors -> tensors on `device` (GDict.to_torch, dict_array.py:308-318)."""
     import numpy as np
     if isinstance(x, dict):
-        return {k: to_torch(v, device, non_blocking) for k, v in x.items()}
+        out = {k: to_torch(v, device, non_blocking) for k, v in x.items()}
+        if type(x) is not dict:            # an observation that carries a pending augmentation / virtual repeat keeps them
+            try:
+                kept = type(x)(out)
+                kept.__dict__.update(getattr(x, "__dict__", {}))
+                return kept
+            except Exception:
+                return out
+        return out
     if isinstance(x, (list, tuple)):
         return type(x)(to_torch(v, device, non_blocking) for v in x)
     if isinstance(x, np.ndarray):

@@ -413,3 +413,32 @@ def test_device_replay_batches_are_encoded_in_one_launch_with_the_same_result(cu
     assert r1 == r2
     for n in p1:
         assert torch.equal(p1[n], p2[n]), n
+
+
+def test_fused_acting_path_equals_the_module_tree(cuda):
+    """methods/acting.py (seven launches) against the actor's module tree on the same observation: mean action to 1e-5 (fp32
+    GEMMs in a different order), sampled action with the same injected noise, (actions, None) for rnn_mode="with_states"."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.methods.acting import FusedActor
+    cfg = configs.sac_maniskill(7, 8, 10, 4, head_hidden=256)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 150], "rgb": [3, 150]}, 8)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda).eval()
+    assert FusedActor.supported(agent.actor)
+    obs = make_obs(3, 150, seed=4, seg=1)
+    obs["agent"] = np.random.RandomState(0).randn(3, 10).astype(np.float32)
+    eps = torch.randn(3, 8)
+    out = {}
+    for fused in (True, False):
+        agent.use_fused_acting = fused
+        agent.__dict__.pop("_fused_actor", None)
+        mean_a = agent(obs, mode="eval")
+        agent.actor.head.noise_override = [eps.to(cuda)]
+        samp, states = agent(obs, mode="explore", rnn_mode="with_states")
+        assert states is None and not agent.actor.head.noise_override
+        out[fused] = (mean_a, samp)
+        assert ("_fused_actor" in agent.__dict__) == fused
+    for a, b in zip(out[True], out[False]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=0)
+    assert not torch.equal(out[True][0], out[True][1])
