@@ -72,10 +72,13 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="analysis only: override the global batch size (the JSON line then is NOT the "
                     "BASELINE metric; used to look at the per-GPU share of a multi-GPU run on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16", "f32split"], help="override the workload's encoder arithmetic; "
+                    "f32split = the EXPERIMENTAL three-term bf16 split of the fp32 contractions (~1e-6 of fp32, not bit-comparable): the JSON "
+                    "line then says dtype f32split and is not the headline configuration")
     return ap.parse_args()
 
 
-def build_agent(wl, batch_per_rank, device):
+def build_agent(wl, batch_per_rank, device, encoder_dtype=None):
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent as _build
     C = 6 + wl["obs_kw"].get("seg", 0) + wl["obs_kw"].get("pos_encoding", 0)
@@ -87,6 +90,8 @@ def build_agent(wl, batch_per_rank, device):
         cfg = configs.sac_maniskill(C, wl["A"], wl["S"], batch_per_rank)
     obs_shape = {"xyz": [3, wl["N"]], "rgb": [3, wl["N"]]}
     cfg["env_params"] = configs.env_params(obs_shape, wl["A"])
+    if encoder_dtype is not None:
+        cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"]["compute_dtype"] = encoder_dtype
     torch.manual_seed(0)                       # random-init weights of the named architecture
     return _build(cfg).to(device), C
 
@@ -162,7 +167,7 @@ def main():
 
     from pointcloud_rl_amd import hip
     from pointcloud_rl_amd.synthetic import SyntheticReplay
-    agent, C = build_agent(wl, b_rank, device)
+    agent, C = build_agent(wl, b_rank, device, args.encoder_dtype)
     if world > 1:
         agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
@@ -290,7 +295,7 @@ def main():
             "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
             "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if getattr(agent.encoder, "compute_dtype", "f32") == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32"), "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
                        "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},

@@ -143,6 +143,16 @@ int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* au
                          float* pooled, int32_t* argmax,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* EXPERIMENTAL split-precision forward: conv1 / conv2 in ~fp32 accuracy on the bf16 matrix cores -- every fp32 weight and
+ * activation is the exact sum of three bf16 terms (8 significand bits each), six of the nine term products are kept (what is
+ * dropped is below 3 x 2^-24 of |w| |a| per product), fp32 accumulation.  2.7x less matrix time than the exact fp32 kernel,
+ * results within ~1e-6 of it but NOT bit-comparable (a max-pool near-tie of that size can pick another point): offered next
+ * to pcrl_encoder_fwd_f32, which stays the default; the backward is pcrl_encoder_bwd_f32.  Same arguments and outputs. */
+int pcrl_encoder_fwd_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug /* may be NULL */,
+                              const pcrl_encoder_weights* w, const void* packed,
+                              float* pooled, int32_t* argmax,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Number of floats of the flat encoder gradient, laid out in the reference's parameter order
  * inside visual_nn.conv.mlp: conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias,
  * conv2.weight, norm2.weight, norm2.bias. */

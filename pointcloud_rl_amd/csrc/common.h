@@ -54,7 +54,11 @@ struct PackedLayout {
     __host__ __device__ constexpr int w2b() const { return align4(w1b() + C1 * C2 / 2); } // conv2: C3 x C2 bf16
     __host__ __device__ constexpr int w2tb() const { return align4(w2b() + C2 * C3 / 2); } // conv2 transposed: C2 rows x C3 k, bf16
     __host__ __device__ constexpr int w1tb() const { return align4(w2tb() + C2 * C3 / 2); } // conv1 transposed: C1 rows x C2 k, bf16
-    __host__ __device__ constexpr int total() const { return align4(w1tb() + C1 * C2 / 2); }
+    // split-precision forward (experimental): three bf16 images per layer, hi / mid / lo with w = hi + mid + lo exactly, same
+    // [row block][16-channel group][64 lanes][8 bf16] order as w1b / w2b
+    __host__ __device__ constexpr int w1s(int k) const { return align4(w1tb() + C1 * C2 / 2) + k * (C1 * C2 / 2); }
+    __host__ __device__ constexpr int w2s(int k) const { return align4(w1s(3)) + k * (C2 * C3 / 2); }
+    __host__ __device__ constexpr int total() const { return align4(w2s(3)); }
     __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
 };
 
@@ -68,6 +72,13 @@ __host__ __device__ inline unsigned bf16_rne_bits(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
     if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// w = hi + mid + lo with three bf16 terms, exactly (8 + 8 + 8 significand bits by truncation): term k of x.
+__host__ __device__ inline unsigned bf16_split_bits(float x, int k) {
+    float r = x;
+    for (int i = 0; i < k; ++i) r = r - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
+    return __builtin_bit_cast(unsigned, r) >> 16;
 }
 
 // Buffer addressing: SGPR resource + one 32-bit VGPR byte offset + scalar/immediate offset.  Used

@@ -359,6 +359,70 @@ __device__ __forceinline__ void dense_layer_bf16(f32x16 (&acc)[MB], LoadFn load,
     }
 }
 
+// Split-precision dense layer (experimental): acc[mb] = W[32mb.., :] . act in ~fp32 accuracy on the bf16 matrix cores.  Every
+// fp32 operand is the exact sum of three bf16 terms (hi + mid + lo, 8 significand bits each, by truncation); of the nine
+// term products the six largest are kept -- hi hi, hi mid, mid hi, hi lo, lo hi, mid mid -- so what is dropped is below
+// 3 x 2^-24 of |w| |a| per product, the size of fp32's own rounding.  Six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace
+// eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 16 input channels: 2.7x less matrix time, paid with ~6 vector
+// instructions per activation for the split.  Not bit-comparable with the fp32 chain (the products are exact, the
+// accumulation order differs): offered next to the exact kernel, never instead of it.
+// load(k, mb, g) -> 16 bytes = the 8 bf16 A operands of term k; act(t) -> activation register t.
+template <int MB, int G, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_split(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        u32x4 bw[3];                       // the three B operands: 8 bf16 = four 32-bit words each
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            float x0 = act(8 * g + r), x1 = act(8 * g + r + 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // the upper halves of the two fp32 words = their truncated bf16 terms, element r in the low half: one v_perm
+                bw[k][r >> 1] = __builtin_amdgcn_perm(f2u(x1), f2u(x0), 0x07060302u);
+                if (k < 2) {               // exact remainders: at most 16 (then 8) significand bits are left
+                    x0 = x0 - u2f(f2u(x0) & 0xFFFF0000u);
+                    x1 = x1 - u2f(f2u(x1) & 0xFFFF0000u);
+                }
+            }
+        }
+        bf16x8 b[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) b[k] = __builtin_bit_cast(bf16x8, bw[k]);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // Row blocks in pairs: the twelve MFMAs of a pair alternate between two accumulators (no MFMA waits for its
+        // predecessor's result), and the six operand pieces of the next pair are in flight meanwhile.
+        constexpr int NP = (MB + 1) / 2;
+        f32x4 w[2][2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (e < MB) w[0][e][k] = load(k, e, g);
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+            if (pr + 1 < NP) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (2 * (pr + 1) + e < MB) w[(pr + 1) & 1][e][k] = load(k, 2 * (pr + 1) + e, g);
+            }
+            const int m0 = 2 * pr, m1 = 2 * pr + 1 < MB ? 2 * pr + 1 : 2 * pr;
+            const bool two = 2 * pr + 1 < MB;
+            f32x16 a0 = g == 0 ? zero : acc[m0], a1 = g == 0 ? zero : acc[m1];
+            // term pairs from the smallest product to the largest: (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
+            constexpr int WK[6] = {2, 0, 1, 1, 0, 0}, BK[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[pr & 1][0][WK[t]]), b[BK[t]], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[pr & 1][1][WK[t]]), b[BK[t]], a1, 0, 0, 0);
+            }
+            acc[m0] = a0;
+            if (two) acc[m1] = a1;
+        }
+    }
+}
+
 bool encoder_dims_supported(int c1, int c2, int c3);
 // Host side: validate the descriptors of the C ABI and flatten them into CloudParams.
 int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out);

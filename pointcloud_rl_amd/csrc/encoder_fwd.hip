@@ -32,7 +32,9 @@ struct FwdParams {
 
 // BF16: conv1 / conv2 contract bf16 operands (weights rounded once by the pack kernel, activations rounded as they are
 // fed to the next layer) with fp32 accumulation; conv0, both LayerNorms and the max-pool are unchanged fp32 code.
-template <int T0, int C1, int C2, int C3, bool BF16>
+// SPLIT (experimental, never together with BF16): conv1 / conv2 in ~fp32 accuracy on the bf16 matrix cores, every operand split
+// into three bf16 terms (dense_layer_split); conv2's hi and mid weight images live in LDS, the lo image streams from L2.
+template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
     constexpr PackedLayout L{T0, C1, C2, C3};
     constexpr int MB1 = C1 / 32, MB2 = C2 / 32, MB3 = C3 / 32;
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
 
     {   // prologue: weights -> LDS, once per workgroup
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (SPLIT ? L.w2s(0) : BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
         constexpr int N16 = BF16 ? C3 * C2 / 8 : C3 * C2 / 4;
         if (nthreads == 512) stage_to_lds<512, N16>(s, g, tid);
@@ -102,7 +104,11 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
             // ---- conv1 + LN + ReLU --------------------------------------------------------
             f32x16 a1[MB2];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB2, C1 / 16>(
+                    a1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1s(k) + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB2, C1 / 16>(
                     a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
@@ -114,7 +120,13 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB3, C2 / 16>(
+                    a2, [&](int k, int mb, int g) {
+                        return k < 2 ? s_w2v[k * (C3 * C2 / 8) + (mb * (C2 / 16) + g) * 64 + lane]
+                                     : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2s(2) + (mb * (C2 / 16) + g) * 256)); },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB3, C2 / 16>(
                     a2, [&](int mb, int g) { return s_w2v[(mb * (C2 / 16) + g) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
@@ -291,6 +303,26 @@ __global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __res
         }
         v = u2f(bits);
     }
+    else {
+        // split images: three bf16 terms of every weight, same element order as the bf16 images
+        for (int layer = 1; layer <= 2; ++layer) {
+            const int rows_k = layer == 1 ? w.c1 : w.c2;                 // contraction length
+            const int n_img = (layer == 1 ? w.c1 * w.c2 : w.c2 * w.c3) / 2;
+            for (int term = 0; term < 3; ++term) {
+                const int base = layer == 1 ? L.w1s(term) : L.w2s(term);
+                if (i >= base && i < base + n_img) {
+                    unsigned bits = 0;
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = 2 * (i - base) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+                        const int G = rows_k / 16, g = q % G, mb = q / G;
+                        const float* src = layer == 1 ? w.w1 : w.w2;
+                        bits |= bf16_split_bits(src[(32 * mb + (ln & 31)) * rows_k + acc_chan(8 * g + r, ln >> 5)], term) << (16 * k);
+                    }
+                    v = u2f(bits);
+                }
+            }
+        }
+    }
     out[i] = v;
 }
 
@@ -351,10 +383,10 @@ static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16) {
            sizeof(float) * ((size_t)C3 * C2 / (bf16 ? 2 : 1) + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
 }
 
-template <int T0, int C1, int C2, int C3, bool BF16>
+template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16);
-    auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16>;
+    auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16, SPLIT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
     PCRL_CHECK_LAUNCH("encoder_fwd_kernel");
@@ -415,7 +447,7 @@ extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void
     return PCRL_OK;
 }
 
-static int encoder_fwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
                             float* pooled, int32_t* argmax,
                             void* workspace, size_t workspace_bytes, void* stream) {
@@ -439,7 +471,8 @@ static int encoder_fwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     int rc = PCRL_E_ARG;
 #define PCRL_FWD_CASE(T0_, C1_, C2_, C3_)                                         \
     if (T0 == T0_ && w->c1 == C1_ && w->c2 == C2_ && w->c3 == C3_)                \
-        rc = bf16 ? launch_fwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : launch_fwd<T0_, C1_, C2_, C3_, false>(p, grid, st);
+        rc = mode == 1 ? launch_fwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : mode == 2 ? launch_fwd<T0_, C1_, C2_, C3_, false, true>(p, grid, st) \
+                       : launch_fwd<T0_, C1_, C2_, C3_, false>(p, grid, st);
     PCRL_FWD_CASE(2, 64, 128, 256) PCRL_FWD_CASE(3, 64, 128, 256) PCRL_FWD_CASE(4, 64, 128, 256) PCRL_FWD_CASE(5, 64, 128, 256)
     PCRL_FWD_CASE(2, 128, 128, 256) PCRL_FWD_CASE(3, 128, 128, 256) PCRL_FWD_CASE(4, 128, 128, 256) PCRL_FWD_CASE(5, 128, 128, 256)
     PCRL_FWD_CASE(2, 32, 64, 128) PCRL_FWD_CASE(3, 32, 64, 128) PCRL_FWD_CASE(4, 32, 64, 128) PCRL_FWD_CASE(5, 32, 64, 128)
@@ -459,12 +492,19 @@ extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
                                     const pcrl_encoder_weights* w, const void* packed,
                                     float* pooled, int32_t* argmax,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_fwd_impl(false, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+    return encoder_fwd_impl(0, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                                      const pcrl_encoder_weights* w, const void* packed,
                                      float* pooled, int32_t* argmax,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_fwd_impl(true, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+    return encoder_fwd_impl(1, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcrl_encoder_fwd_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                         const pcrl_encoder_weights* w, const void* packed,
+                                         float* pooled, int32_t* argmax,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(2, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
 }

@@ -199,7 +199,7 @@ def color_jitter_u8(rgb, color):
     return out
 
 
-def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False):
+def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False, split=False):
     """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device).  bf16=True: conv1 / conv2 on
     the bf16 matrix cores with fp32 accumulation (pcrl_encoder_fwd_bf16)."""
     B, c3 = desc.B, ew.c3
@@ -212,7 +212,7 @@ def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False):
     if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
         workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
     with _span("encoder_fwd"):
-        fn = lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
+        fn = lib().pcrl_encoder_fwd_f32split if split else lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
         check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
                                          ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
                                          _ptr(workspace), ctypes.c_size_t(need.value), _stream()))

@@ -80,7 +80,8 @@ class _EncoderFn(torch.autograd.Function):
     def forward(ctx, net, desc, keep, aug, *weights):
         ew, packed = net._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
-        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=net._workspace("fwd"), bf16=net.compute_dtype == "bf16")
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=net._workspace("fwd"), bf16=net.compute_dtype == "bf16",
+                                         split=net.compute_dtype == "f32split")
         ctx.net, ctx.desc, ctx.keep, ctx.aug_desc, ctx.aug = net, desc, keep, aug_desc, aug
         ctx.ew, ctx.packed = ew, packed
         ctx.save_for_backward(argmax, pooled)
@@ -109,8 +110,10 @@ class PointNet(ExtendedModule):
         super().__init__()
         # compute_dtype (not a reference keyword): "bf16" runs conv1 / conv2 of the per-point MLP on the bf16 matrix cores
         # with fp32 accumulation, fp32 master weights and fp32 gradient GEMMs (BASELINE.json config 3); "f32" is exact.
-        if compute_dtype not in ("f32", "bf16"):
-            raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {compute_dtype!r}")
+        # "f32split" (experimental): forward conv1 / conv2 as three-term bf16 splits on the bf16 matrix cores (~fp32 accuracy, not
+        # bit-comparable with "f32"); the backward is the fp32 one.
+        if compute_dtype not in ("f32", "bf16", "f32split"):
+            raise ValueError(f"compute_dtype must be 'f32', 'bf16' or 'f32split', got {compute_dtype!r}")
         self.compute_dtype = compute_dtype
         # The fused kernel implements the configuration every shipped point-cloud SAC/DrQ config uses
         # (configs/mfrl/{sac,drq}/*/pn*.py): no T-Nets, LN1d + ReLU, first LayerNorm dropped.
@@ -186,7 +189,8 @@ class PointNet(ExtendedModule):
         desc, keep = hip.make_cloud_desc(inputs)
         ew, packed = self._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
-        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16")
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16",
+                                         split=self.compute_dtype == "f32split")
         return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed, pooled)
 
     def ctx_for(self, inputs, pooled):

@@ -227,3 +227,46 @@ def test_virtual_repeat_equals_materialised_repeat(cuda):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert not torch.equal(a[0][0], a[0][1])          # the two augmentations of a sample differ (their jitter rows do)
+
+
+@pytest.mark.parametrize("fixture", ["encoder_dmc_c6", "encoder_dmc_c9_posenc", "encoder_maniskill_c7", "encoder_dmc_motivating_c6"])
+def test_split_precision_forward_on_the_reference_fixtures(cuda, fixture):
+    """EXPERIMENTAL pcrl_encoder_fwd_f32split (three-term bf16 split of the fp32 contractions) on the encoder fixtures captured
+    from the reference: pooled within 1e-5 of the reference's, argmax exact (the fixtures' smallest top-2 gap is > 1e-5)."""
+    import os
+    import torch
+    from pointcloud_rl_amd import hip
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + ".npz"))
+    obs = {k[4:]: torch.from_numpy(d[k]).to(cuda) for k in d.files if k.startswith("obs/")}
+    g = lambda k: torch.from_numpy(np.ascontiguousarray(d["w/" + k])).to(cuda)
+    w0, w1, w2 = g("conv.mlp.conv0.weight")[..., 0].contiguous(), g("conv.mlp.conv1.weight")[..., 0].contiguous(), g("conv.mlp.conv2.weight")[..., 0].contiguous()
+    ew, keep = hip.make_encoder_weights(w0, g("conv.mlp.conv0.bias"), w1, g("conv.mlp.norm1.weight"), g("conv.mlp.norm1.bias"), w2,
+                                        g("conv.mlp.norm2.weight"), g("conv.mlp.norm2.bias"), 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep2 = hip.make_cloud_desc(obs)
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, split=True)
+    assert np.array_equal(argmax.cpu().numpy(), d["argmax"])
+    np.testing.assert_allclose(pooled.cpu().numpy(), d["pooled"], rtol=0, atol=1e-5)
+
+
+def test_split_precision_forward_k1_shape_against_the_exact_kernel(cuda):
+    """K1 shape (256 x 1024): |pooled - exact fp32| <= 1e-5 everywhere; argmax may differ only where the two candidates' values
+    are within 1e-6 (measured: 0 of 65 536 entries on this data, max |diff| 3.1e-6)."""
+    import torch
+    from pointcloud_rl_amd import hip
+    obs_np = make_obs(256, 1024, seed=1)
+    w = {k: torch.from_numpy(v).to(cuda) for k, v in make_encoder_weights(6, 64, 128, 256, seed=0).items()}
+    ew, _ = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    desc, keep = hip.make_cloud_desc(obs)
+    p0, a0 = hip.encoder_fwd(desc, ew, packed)
+    p1, a1 = hip.encoder_fwd(desc, ew, packed, split=True)
+    diff = (p0 - p1).abs()
+    assert float(diff.max()) <= 1e-5
+    moved = a0 != a1
+    assert int(moved.sum()) <= 8 and (not moved.any() or float(diff[moved].max()) <= 1e-6)
+    p2, a2 = hip.encoder_fwd(desc, ew, packed, split=True)
+    assert torch.equal(p1, p2) and torch.equal(a1, a2)              # deterministic

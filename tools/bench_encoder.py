@@ -9,7 +9,7 @@ from pointcloud_rl_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256); ap.add_argument("--N", type=int, default=1024)
 ap.add_argument("--c1", type=int, default=64); ap.add_argument("--seg", type=int, default=0)
-ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--no-pooled", action="store_true")
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--split", action="store_true"); ap.add_argument("--no-pooled", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 obs_np = make_obs(a.B, a.N, seed=1, seg=a.seg)
@@ -20,18 +20,24 @@ packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4
 hip.encoder_pack_weights(ew, packed)
 obs = {k: torch.from_numpy(v).to(dev) for k, v in obs_np.items()}
 desc, keep = hip.make_cloud_desc(obs)
-for _ in range(5): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
+for _ in range(5): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16, split=a.split)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(a.iters): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
+for _ in range(a.iters): hip.encoder_fwd(desc, ew, packed, bf16=a.bf16, split=a.split)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.iters
 flop = 2.0 * (C * a.c1 + a.c1 * 128 + 128 * 256) * a.B * a.N
 print(f"encoder_fwd B={a.B} N={a.N} C={C} c1={a.c1}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s ({flop/ms/1e9/157.3*100:.1f}% of 157.3 fp32 MFMA peak)")
 
+if a.split:
+    p0, a0 = hip.encoder_fwd(desc, ew, packed)
+    p1, a1 = hip.encoder_fwd(desc, ew, packed, split=True)
+    d = (p0 - p1).abs()
+    print(f"split vs fp32: max |pooled diff| {float(d.max()):.3e}, mean {float(d.mean()):.3e}, argmax differs on {int((a0 != a1).sum())} of {a0.numel()} "
+          f"(largest value gap there {float((p0 - p1).abs()[a0 != a1].max()) if (a0 != a1).any() else 0.0:.3e})")
 # ---- backward (sparse exact backward through the max-pool) ----
-pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=a.bf16)
+pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=a.bf16, split=a.split)
 gp = torch.randn_like(pooled)
 import ctypes
 need = ctypes.c_size_t()
