@@ -343,7 +343,7 @@ def main():
             sync()
             dt2 = time.perf_counter() - t2
             out["experimental_f32split"] = {"value": n2 / dt2, "unit": "gradient steps/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
-                                            "note": "encoder forward conv1/conv2 as three-term bf16 splits (pcrl_encoder_fwd_f32split); "
+                                            "note": "encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); "
                                                     "opt-in, not the reported value"}
         print(json.dumps(out))
     if world > 1:

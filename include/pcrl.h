@@ -153,6 +153,14 @@ int pcrl_encoder_fwd_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc
                               float* pooled, int32_t* argmax,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of pcrl_encoder_fwd_f32split: the recompute uses the same split arithmetic (bit-identical to that forward, so ReLU masks
+ * and argmax relations are its own) and so do the two data-gradient GEMMs; the weight-gradient GEMMs are exact fp32.  EXPERIMENTAL. */
+int pcrl_encoder_bwd_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                              const pcrl_encoder_weights* w, const void* packed,
+                              const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                              float* grads, int32_t* n_active,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* Number of floats of the flat encoder gradient, laid out in the reference's parameter order
  * inside visual_nn.conv.mlp: conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias,
  * conv2.weight, norm2.weight, norm2.bias. */

@@ -58,7 +58,10 @@ struct PackedLayout {
     // [row block][16-channel group][64 lanes][8 bf16] order as w1b / w2b
     __host__ __device__ constexpr int w1s(int k) const { return align4(w1tb() + C1 * C2 / 2) + k * (C1 * C2 / 2); }
     __host__ __device__ constexpr int w2s(int k) const { return align4(w1s(3)) + k * (C2 * C3 / 2); }
-    __host__ __device__ constexpr int total() const { return align4(w2s(3)); }
+    // ... and of the transposed matrices for the backward's data-gradient GEMMs (rows = c2 / c1, contraction over c3 / c2)
+    __host__ __device__ constexpr int w2ts(int k) const { return align4(w2s(3)) + k * (C2 * C3 / 2); }
+    __host__ __device__ constexpr int w1ts(int k) const { return align4(w2ts(3)) + k * (C1 * C2 / 2); }
+    __host__ __device__ constexpr int total() const { return align4(w1ts(3)); }
     __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
 };
 

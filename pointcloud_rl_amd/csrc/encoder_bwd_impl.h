@@ -27,6 +27,13 @@
 //     results are bit-reproducible run to run.
 #include "encoder_common.h"
 
+// This file is compiled three times (encoder_bwd_{f32,bf16,split}.hip define PCRL_BWD_MODE 0 / 1 / 2): each translation unit
+// instantiates the kernels of ONE arithmetic mode for the twelve supported shapes, so the three compile in parallel; the
+// C entry points, the reduce kernel and the host-side helpers live in the mode-0 unit.
+#ifndef PCRL_BWD_MODE
+#error "include through encoder_bwd_{f32,bf16,split}.hip"
+#endif
+
 namespace pcrl {
 
 constexpr int kPiece = 256;   // floats per piece (64 lanes x 4)
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256) void encoder_bwd_prep_kernel(const BwdParams p
 // The cloud's tables (active list by a bitonic sort of the argmax keys, slots, per-channel / per-point sums) live in LDS and
 // are built by the workgroup itself.  Same per-tile chain as the tile-mode kernel below; kept as its own kernel because
 // every value the tile-mode kernel carries per wave (cloud index, table pointers, resources) is a spilled register here.
-template <int T0, int C1, int kC2, int kC3, bool BF16>
+template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (SPLIT ? L.w2s(0) : BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
         stage_to_lds<512, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
         for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
@@ -409,7 +416,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             }
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
-            if (BF16)
+            if (SPLIT)      // the split-precision forward's arithmetic: the recompute is bit-identical to that forward
+                dense_layer_split<MB2, C1 / 16>(
+                    a1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1s(k) + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB2, C1 / 16>(
                     a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
@@ -432,7 +443,13 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB3, kC2 / 16>(
+                    a2, [&](int k, int mb, int g) {
+                        return k < 2 ? s_w2v[k * (kC3 * kC2 / 8) + (mb * (kC2 / 16) + g) * 64 + lane]
+                                     : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2s(2) + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB3, kC2 / 16>(
                     a2, [&](int mb, int g) { return s_w2v[(mb * (kC2 / 16) + g) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
@@ -506,7 +523,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                 }
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
-            if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
+            if (SPLIT)
+                dense_layer_split<MB2, kC3 / 16>(
+                    d1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2ts(k) + (mb * (kC3 / 16) + g) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
+            else if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
                 dense_layer_bf16<MB2, kC3 / 16>(
                     d1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2tb() + (mb * (kC3 / 16) + g) * 256)); },
                     [&](int t) { return a2[t >> 4][t & 15]; });
@@ -559,7 +580,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                 }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB1, kC2 / 16>(
+                    d0, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1ts(k) + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB1, kC2 / 16>(
                     d0, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1tb() + (mb * (kC2 / 16) + g) * 256)); },
                     [&](int t) { return d1[t >> 4][t & 15]; });
@@ -595,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
 // through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
 constexpr int kTileTabBytes = 256 + 4 * 256;       // per wave: slot bytes + dx floats of the tile's cloud (c3 <= 256)
 constexpr int kMaxTileModeClouds = 256;           // tile mode needs the clouds' tile prefix in LDS
-template <int T0, int C1, int kC2, int kC3, bool BF16>
+template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
@@ -614,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
-        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (SPLIT ? L.w2s(0) : BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
         stage_to_lds<512, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
         for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
@@ -704,7 +729,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
-            if (BF16)
+            if (SPLIT)      // the split-precision forward's arithmetic: the recompute is bit-identical to that forward
+                dense_layer_split<MB2, C1 / 16>(
+                    a1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1s(k) + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB2, C1 / 16>(
                     a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
@@ -727,7 +756,13 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB3, kC2 / 16>(
+                    a2, [&](int k, int mb, int g) {
+                        return k < 2 ? s_w2v[k * (kC3 * kC2 / 8) + (mb * (kC2 / 16) + g) * 64 + lane]
+                                     : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2s(2) + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB3, kC2 / 16>(
                     a2, [&](int mb, int g) { return s_w2v[(mb * (kC2 / 16) + g) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
@@ -801,7 +836,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
-            if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
+            if (SPLIT)
+                dense_layer_split<MB2, kC3 / 16>(
+                    d1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2ts(k) + (mb * (kC3 / 16) + g) * 256)); },
+                    [&](int t) { return a2[t >> 4][t & 15]; });
+            else if (BF16)     // the gradient is rounded to bf16 as it enters the contraction, like the activations of the forward
                 dense_layer_bf16<MB2, kC3 / 16>(
                     d1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2tb() + (mb * (kC3 / 16) + g) * 256)); },
                     [&](int t) { return a2[t >> 4][t & 15]; });
@@ -852,7 +891,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
-            if (BF16)
+            if (SPLIT)
+                dense_layer_split<MB1, kC2 / 16>(
+                    d0, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1ts(k) + (mb * (kC2 / 16) + g) * 256)); },
+                    [&](int t) { return d1[t >> 4][t & 15]; });
+            else if (BF16)
                 dense_layer_bf16<MB1, kC2 / 16>(
                     d0, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1tb() + (mb * (kC2 / 16) + g) * 256)); },
                     [&](int t) { return d1[t >> 4][t & 15]; });
@@ -1023,6 +1066,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
     }
 }
 
+#if PCRL_BWD_MODE == 0
 // ---- reduce: grads[i] = sum_b pw[b][i], fixed order ---------------------------------------------
 // HBM/L2-bound (B x n floats read once).  A 1024-thread block owns 64 consecutive elements; thread (g, c) sums the
 // clouds b = g, g + 16, ... of element c with four loads in flight, then the 16 partials are added in g order.
@@ -1049,6 +1093,8 @@ __global__ __launch_bounds__(1024) void encoder_bwd_reduce_kernel(const float* _
     }
 }
 
+#endif
+
 static size_t bwd_lds_bytes_cloud(int T0, int C1, int kC2, int kC3) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)kC3 * 2 + 4 * (size_t)kC3 + 32 + kC3 + 4 * (size_t)kC3 +
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + 8 * kC2 * 2 + 2 * (size_t)kC3 + 2 * (size_t)kC3 + 3 * (size_t)kC3 + (size_t)kC3 * kC2);
@@ -1059,7 +1105,7 @@ static size_t bwd_lds_bytes_tile(int T0, int C1, int kC2, int kC3) {
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + (size_t)kC3 * kC2);
 }
 
-template <int T0, int C1, int C2, int C3, bool BF16>
+template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
     if (p.tile_mode) {
         // small batch: prep (tables) -> one wave per tile, dealt over every CU
@@ -1069,13 +1115,13 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
         hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(256), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_prep_kernel");
         const size_t lds = bwd_lds_bytes_tile(T0, C1, C2, C3);
-        auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16>;
+        auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
     } else {
         const size_t lds = bwd_lds_bytes_cloud(T0, C1, C2, C3);
-        auto kern = encoder_bwd_points_cloud_kernel<T0, C1, C2, C3, BF16>;
+        auto kern = encoder_bwd_points_cloud_kernel<T0, C1, C2, C3, BF16, SPLIT>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_points_cloud_kernel");
@@ -1110,8 +1156,26 @@ static BwdWorkspace bwd_workspace(int B, int C, int C1, int kC2, int kC3) {
     return w;
 }
 
+// The kernels of this unit's mode for every supported shape.
+int PCRL_BWD_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st) {
+    constexpr bool kBf16 = PCRL_BWD_MODE == 1, kSplit = PCRL_BWD_MODE == 2;
+    int rc = PCRL_E_ARG;
+#define PCRL_BWD_CASE(T0_, C1_, C2_, C3_) \
+    if (T0 == T0_ && c1 == C1_ && c2 == C2_ && c3 == C3_) rc = launch_bwd<T0_, C1_, C2_, C3_, kBf16, kSplit>(p, grid, st);
+    PCRL_BWD_CASE(2, 64, 128, 256) PCRL_BWD_CASE(3, 64, 128, 256) PCRL_BWD_CASE(4, 64, 128, 256) PCRL_BWD_CASE(5, 64, 128, 256)
+    PCRL_BWD_CASE(2, 128, 128, 256) PCRL_BWD_CASE(3, 128, 128, 256) PCRL_BWD_CASE(4, 128, 128, 256) PCRL_BWD_CASE(5, 128, 128, 256)
+    PCRL_BWD_CASE(2, 32, 64, 128) PCRL_BWD_CASE(3, 32, 64, 128) PCRL_BWD_CASE(4, 32, 64, 128) PCRL_BWD_CASE(5, 32, 64, 128)
+#undef PCRL_BWD_CASE
+    return rc;
+}
+
+int encoder_bwd_launch_f32(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st);
+int encoder_bwd_launch_bf16(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st);
+int encoder_bwd_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st);
+
 }  // namespace pcrl
 
+#if PCRL_BWD_MODE == 0
 using namespace pcrl;
 
 extern "C" int pcrl_encoder_num_grads(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* n) {
@@ -1130,7 +1194,7 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     return PCRL_OK;
 }
 
-static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
                             const int32_t* argmax, const float* grad_pooled, const float* pooled,
                             float* grads, int32_t* n_active,
@@ -1164,13 +1228,9 @@ static int encoder_bwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl
     const int grid = min(p.cl.B, num_cus());
     const int T0 = (p.cl.C + 1) / 2;
     int rc = PCRL_E_ARG;
-#define PCRL_BWD_CASE(T0_, C1_, C2_, C3_) \
-    if (T0 == T0_ && w->c1 == C1_ && w->c2 == C2_ && w->c3 == C3_) \
-        rc = bf16 ? launch_bwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : launch_bwd<T0_, C1_, C2_, C3_, false>(p, grid, st);
-    PCRL_BWD_CASE(2, 64, 128, 256) PCRL_BWD_CASE(3, 64, 128, 256) PCRL_BWD_CASE(4, 64, 128, 256) PCRL_BWD_CASE(5, 64, 128, 256)
-    PCRL_BWD_CASE(2, 128, 128, 256) PCRL_BWD_CASE(3, 128, 128, 256) PCRL_BWD_CASE(4, 128, 128, 256) PCRL_BWD_CASE(5, 128, 128, 256)
-    PCRL_BWD_CASE(2, 32, 64, 128) PCRL_BWD_CASE(3, 32, 64, 128) PCRL_BWD_CASE(4, 32, 64, 128) PCRL_BWD_CASE(5, 32, 64, 128)
-#undef PCRL_BWD_CASE
+    rc = mode == 1 ? encoder_bwd_launch_bf16(T0, w->c1, w->c2, w->c3, p, grid, st)
+       : mode == 2 ? encoder_bwd_launch_split(T0, w->c1, w->c2, w->c3, p, grid, st)
+                   : encoder_bwd_launch_f32(T0, w->c1, w->c2, w->c3, p, grid, st);
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
     const int n = GL.total();
@@ -1185,7 +1245,7 @@ extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
                                     const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                     float* grads, int32_t* n_active,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_bwd_impl(false, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
+    return encoder_bwd_impl(0, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
@@ -1193,5 +1253,14 @@ extern "C" int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_a
                                      const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                      float* grads, int32_t* n_active,
                                      void* workspace, size_t workspace_bytes, void* stream) {
-    return encoder_bwd_impl(true, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
+    return encoder_bwd_impl(1, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
 }
+
+extern "C" int pcrl_encoder_bwd_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                         const pcrl_encoder_weights* w, const void* packed,
+                                         const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                                         float* grads, int32_t* n_active,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_bwd_impl(2, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
+}
+#endif  // PCRL_BWD_MODE == 0

@@ -306,17 +306,27 @@ __global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __res
     else {
         // split images: three bf16 terms of every weight, same element order as the bf16 images
         for (int layer = 1; layer <= 2; ++layer) {
-            const int rows_k = layer == 1 ? w.c1 : w.c2;                 // contraction length
-            const int n_img = (layer == 1 ? w.c1 * w.c2 : w.c2 * w.c3) / 2;
+            const int in_c = layer == 1 ? w.c1 : w.c2;                   // the layer's input channels = row length of its weight
+            const int out_c = layer == 1 ? w.c2 : w.c3;
+            const int n_img = in_c * out_c / 2;
+            const float* src = layer == 1 ? w.w1 : w.w2;
             for (int term = 0; term < 3; ++term) {
-                const int base = layer == 1 ? L.w1s(term) : L.w2s(term);
+                const int base = layer == 1 ? L.w1s(term) : L.w2s(term);         // forward: rows = outputs, contraction over inputs
+                const int base_t = layer == 1 ? L.w1ts(term) : L.w2ts(term);     // transposed: rows = inputs, contraction over outputs
                 if (i >= base && i < base + n_img) {
                     unsigned bits = 0;
                     for (int k = 0; k < 2; ++k) {
                         const int e = 2 * (i - base) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-                        const int G = rows_k / 16, g = q % G, mb = q / G;
-                        const float* src = layer == 1 ? w.w1 : w.w2;
-                        bits |= bf16_split_bits(src[(32 * mb + (ln & 31)) * rows_k + acc_chan(8 * g + r, ln >> 5)], term) << (16 * k);
+                        const int G = in_c / 16, g = q % G, mb = q / G;
+                        bits |= bf16_split_bits(src[(32 * mb + (ln & 31)) * in_c + acc_chan(8 * g + r, ln >> 5)], term) << (16 * k);
+                    }
+                    v = u2f(bits);
+                } else if (i >= base_t && i < base_t + n_img) {
+                    unsigned bits = 0;
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = 2 * (i - base_t) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+                        const int G = out_c / 16, g = q % G, mb = q / G;
+                        bits |= bf16_split_bits(src[acc_chan(8 * g + r, ln >> 5) * in_c + 32 * mb + (ln & 31)], term) << (16 * k);
                     }
                     v = u2f(bits);
                 }

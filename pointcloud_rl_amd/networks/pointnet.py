@@ -95,6 +95,7 @@ class _EncoderFn(torch.autograd.Function):
         net = ctx.net
         flat, n_active = hip.encoder_bwd(ctx.desc, ctx.ew, ctx.packed, argmax, grad_pooled, aug=ctx.aug_desc,
                                          workspace=net._workspace("bwd", ctx.desc.B), want_n_active=True, bf16=net.compute_dtype == "bf16",
+                                         split=net.compute_dtype == "f32split",
                                          pooled=pooled)
         net.last_n_active = n_active
         views = hip.encoder_grad_views(flat, ctx.ew)
@@ -110,8 +111,8 @@ class PointNet(ExtendedModule):
         super().__init__()
         # compute_dtype (not a reference keyword): "bf16" runs conv1 / conv2 of the per-point MLP on the bf16 matrix cores
         # with fp32 accumulation, fp32 master weights and fp32 gradient GEMMs (BASELINE.json config 3); "f32" is exact.
-        # "f32split" (experimental): forward conv1 / conv2 as three-term bf16 splits on the bf16 matrix cores (~fp32 accuracy, not
-        # bit-comparable with "f32"); the backward is the fp32 one.
+        # "f32split" (experimental): conv1 / conv2 and the backward's data-gradient GEMMs as three-term bf16 splits on the bf16
+        # matrix cores (~fp32 accuracy, not bit-comparable with "f32"); weight-gradient GEMMs, LayerNorms, pool stay fp32.
         if compute_dtype not in ("f32", "bf16", "f32split"):
             raise ValueError(f"compute_dtype must be 'f32', 'bf16' or 'f32split', got {compute_dtype!r}")
         self.compute_dtype = compute_dtype
@@ -205,7 +206,7 @@ class PointNet(ExtendedModule):
         """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
         desc, keep, aug, aug_desc, ew, packed, pooled = ctx
         hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out,
-                        bf16=self.compute_dtype == "bf16", pooled=pooled)
+                        bf16=self.compute_dtype == "bf16", pooled=pooled, split=self.compute_dtype == "f32split")
 
     def forward(self, inputs, object_feature=True, concat_state=None, **kwargs):
         feature, _ = self.pooled(inputs)

@@ -200,3 +200,29 @@ def test_bwd_small_gamma_large_beta_stays_accurate(cuda):
     # exact ties are possible on nearly-constant channels: compare gradients only where argmax agrees everywhere
     assert np.array_equal(idx, idx_ref)
     assert_grads_close(got, ref)
+
+
+@pytest.mark.parametrize("B,N,extra,c1", [(3, 260, dict(), 64), (4, 300, dict(seg=1), 128), (2, 200, dict(), 32), (260, 120, dict(), 64)])
+def test_split_precision_backward_matches_torch_autograd(cuda, B, N, extra, c1):
+    """EXPERIMENTAL pcrl_encoder_{fwd,bwd}_f32split: gradients against fp32 autograd of the restatement at the exact kernel's
+    tolerance (2e-5 of each tensor's largest entry); bitwise reproducible."""
+    from pointcloud_rl_amd import hip
+    obs = make_obs(B, N, seed=3 * B + N, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    c2, c3 = (64, 128) if c1 == 32 else (128, 256)
+    w = make_encoder_weights(C, c1, c2, c3, seed=N + 2)
+    gpool = np.random.RandomState(N).randn(B, c3).astype(np.float32)
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda) for k, v in w.items()}
+    ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep = hip.make_cloud_desc({k: torch.from_numpy(v).to(cuda) for k, v in obs.items()})
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, split=True)
+    gp = torch.from_numpy(gpool).to(cuda)
+    flat = hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled, split=True)
+    ref, idx_ref, pooled_ref = torch_reference_grads(obs, w, gpool, route=argmax.cpu().numpy())
+    np.testing.assert_allclose(pooled.cpu().numpy(), pooled_ref, atol=1e-5, rtol=0)
+    assert (argmax.cpu().numpy() != idx_ref).mean() < 1e-3
+    got = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
+    assert_grads_close(got, ref)
+    assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled, split=True))

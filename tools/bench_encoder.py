@@ -44,9 +44,9 @@ need = ctypes.c_size_t()
 hip.check(hip.lib().pcrl_encoder_bwd_workspace_bytes(a.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
 ws = torch.empty(need.value, dtype=torch.uint8, device=dev)
 out = torch.empty(hip.encoder_num_grads(ew), device=dev)
-for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, pooled=None if a.no_pooled else pooled)
+for _ in range(5): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, split=a.split, pooled=None if a.no_pooled else pooled)
 torch.cuda.synchronize()
 e0.record()
-for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, pooled=None if a.no_pooled else pooled)
+for _ in range(a.iters): hip.encoder_bwd(desc, ew, packed, argmax, gp, workspace=ws, out=out, bf16=a.bf16, split=a.split, pooled=None if a.no_pooled else pooled)
 e1.record(); torch.cuda.synchronize()
 print(f"encoder_bwd B={a.B} N={a.N}: {e0.elapsed_time(e1) / a.iters * 1e3:.1f} us (points + wgrad + reduce kernels)")
