@@ -67,6 +67,9 @@ CASES = {
     # BASELINE config 3 (K2) in fp32 (the bf16 kernels have no reference counterpart, see test_encoder_*_gpu.py):
     # DrQ, 2 augmentations, fused jitter, 64 x 2 clouds
     "k2_drq_maniskill_b64x2_n1200_f32": dict(kind="drq", cfg="drq_maniskill", B=64, N=1200, A=22, S=68, obs_kw=dict(seg=1)),
+    # the EXPERIMENTAL split-precision encoder (compute_dtype="f32split": conv1 / conv2 and the backward's data-gradient GEMMs
+    # as three-term bf16 splits) on the K1 workload, same tolerances as the exact kernels
+    "k1_sac_dmc_b256_n1024_f32split": dict(kind="sac", cfg="sac_dmc", B=256, N=1024, A=6, S=0, obs_kw={}, encoder_dtype="f32split"),
 }
 
 # measured maxima (MI355X, round 2) x ~2-3; see profiles/r02_parity_errors.md
@@ -92,6 +95,8 @@ def _build(case, dev):
     else:
         cfg = configs.drq_maniskill(C, case["A"], case["S"], case["B"])
     cfg["env_params"] = configs.env_params({"xyz": [3, case["N"]], "rgb": [3, case["N"]]}, case["A"])
+    if case.get("encoder_dtype"):
+        cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"]["compute_dtype"] = case["encoder_dtype"]
     torch.manual_seed(0)
     return build_agent(cfg)
 
