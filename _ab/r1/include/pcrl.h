@@ -1,0 +1,312 @@
+/*
+ * pcrl.h -- C ABI of libpcrl_hip.so, the MI355X (gfx950) implementation of the
+ * point-cloud actor-critic hot path of lz1oceani/pointcloud_rl.
+ *
+ * The reference has no FFI on this path: it is pure Python on stock ATen ops
+ * (SURVEY.md section 2.1).  This header is therefore the boundary a maintainer
+ * would bind with ctypes from the reference's own modules;
+ * each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative PCRL_E_* code otherwise;
+ *    pcrl_last_error() returns a thread-local message for the last failure;
+ *  - all pointers except descriptor structs are DEVICE pointers; nothing is
+ *    allocated, freed or retained by the library; scratch is caller-provided;
+ *  - `stream` is a hipStream_t passed as void*; all work is asynchronous on it,
+ *    no call synchronises;
+ *  - tensors are dense row-major unless strides are given (strides in elements).
+ */
+#ifndef PCRL_H_
+#define PCRL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCRL_OK 0
+#define PCRL_E_ARG (-1)         /* invalid argument / unsupported shape */
+#define PCRL_E_WORKSPACE (-2)   /* workspace too small */
+#define PCRL_E_LAUNCH (-3)      /* HIP launch / runtime error */
+
+#define PCRL_MAX_SEG 4
+#define PCRL_MAX_CHANNELS 16
+
+enum { PCRL_DT_F32 = 0, PCRL_DT_U8 = 1, PCRL_DT_BOOL = 2 };
+
+/* One observation key ("xyz", "rgb", "pos_encoding", "seg") of the batched
+ * observation dict the reference feeds PointCloudBase.preprocess
+ * (pyrl/networks/backbones/pointnet.py:49-73).  Planar [B, channels, N] uses
+ * stride_b = channels*N, stride_c = N, stride_n = 1; an interleaved [B, N, C]
+ * tensor uses stride_b = N*C, stride_c = 1, stride_n = C. */
+typedef struct pcrl_feat_seg {
+    const void* ptr;
+    int32_t dtype;     /* PCRL_DT_* */
+    int32_t channels;
+    int32_t div255;    /* 1: value / 255.0f (uint8 rgb, pointnet.py:57-58) */
+    int32_t _pad;
+    int64_t stride_b, stride_c, stride_n;
+} pcrl_feat_seg;
+
+/* A batch of B clouds of N points; channels are the concatenation of the
+ * segments in order (torch.cat(feature, dim=-2), pointnet.py:63).  Segment 0
+ * must be xyz (3 channels, f32) when an augmentation is requested. */
+typedef struct pcrl_cloud_desc {
+    int32_t B, N, nseg, _pad;
+    pcrl_feat_seg seg[PCRL_MAX_SEG];
+} pcrl_cloud_desc;
+
+/* DrQ point-cloud augmentations fused into the encoder's load
+ * (pyrl/utils/augmentations/pcd_aug.py).  flags is an OR of PCRL_AUG_*.
+ *  JITTER  : xyz += noise, noise either explicit (jitter_noise [B,3,N] f32, the
+ *            tensor RandomJitterPoints.process_single draws, pcd_aug.py:318) or,
+ *            when jitter_noise == NULL, Philox4x32-10 U(lo,hi) keyed by
+ *            (seed, offset) -- one draw per (b, axis, n).
+ *  AFFINE  : xyz = M[b] (3x4, row-major) applied as R x + t
+ *            (GlobalRotScaleTrans.process_single -> apply_rot_trans,
+ *            pcd_aug.py:178-215, 84-123); M is built by the host class.
+ * Order when both are set: AFFINE first, then JITTER.
+ * Cloud b uses row (b * row_mul + row_add) of jitter_noise / affine / the Philox counter
+ * (row_mul == 0 means 1), so a strided sub-batch (DrQ's actor step uses augmentation #0 of every
+ * sample, drq.py:115) sees exactly the noise the full batch saw. */
+/*  SUBSAMPLE : the cloud the encoder sees is points point_index[0..n_index) of the stored cloud, the same index for
+ *            every cloud and every key (RandomDownSample.process_single: one shared random permutation prefix,
+ *            pcd_aug.py:231-257 + array_ops.py:659-680); N becomes n_index and the returned argmax counts
+ *            positions of the subsampled cloud, as it does in the reference where the tensors are sliced.
+ *            Jitter noise / Philox counters are indexed by the subsampled position. */
+enum { PCRL_AUG_JITTER = 1, PCRL_AUG_AFFINE = 2, PCRL_AUG_SUBSAMPLE = 4 };
+typedef struct pcrl_aug_desc {
+    int32_t flags, row_mul, row_add, _pad;
+    const float* jitter_noise;
+    float jitter_lo, jitter_hi;
+    uint64_t seed, offset;
+    const float* affine;
+    const uint64_t* offset_ptr;   /* device; when non-NULL the Philox offset is read from here at run
+                                     time (a launch replayed from a hipGraph then draws fresh noise) */
+    const int32_t* point_index;   /* device [n_index], values in [0, N): PCRL_AUG_SUBSAMPLE */
+    int32_t n_index, _pad2;
+} pcrl_aug_desc;
+
+/* Weights of the shared per-point MLP in the reference's own state_dict layout
+ * (ConvMLP built by PointNet.__init__, pointnet.py:106-109; mlp.py:43-56):
+ *   conv0.weight [c1,C,1] conv0.bias [c1] ; conv1.weight [c2,c1,1] norm1.{weight,bias} [c2] ;
+ *   conv2.weight [c3,c2,1] norm2.{weight,bias} [c3] ; LN eps (1e-6 in every shipped config). */
+typedef struct pcrl_encoder_weights {
+    int32_t c_in, c1, c2, c3;
+    const float *w0, *b0, *w1, *g1, *be1, *w2, *g2, *be2;
+    float eps;
+    int32_t _pad;
+} pcrl_encoder_weights;
+
+const char* pcrl_last_error(void);
+int pcrl_version(void);
+
+/* Bytes needed for the MFMA-operand-ordered weight image and for the forward
+ * scratch (cross-workgroup partial maxima when a cloud is split). */
+int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes);
+int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3, size_t* bytes);
+
+/* Re-order the weights into the operand order the forward kernel streams.
+ * Must be re-run whenever the weights change (after every optimizer step). */
+int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream);
+
+/* Fused PointNet encoder forward, fp32:
+ *   preprocess (pointnet.py:49-73) -> [augment] -> conv0+ReLU -> conv1+LN1d+ReLU ->
+ *   conv2+LN1d+ReLU (mlp.py:43-56, nn_layer.py:207-219) -> max over N with first-index
+ *   argmax (pointnet.py:151).
+ * pooled [B,c3] f32, argmax [B,c3] int32 (the index torch's autograd keeps as int64). */
+int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug /* may be NULL */,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         float* pooled, int32_t* argmax,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* Mixed-precision forward (BASELINE.json config 3): conv1 and conv2 contract bf16 operands on v_mfma_f32_32x32x16_bf16
+ * with fp32 accumulation -- weights rounded (RNE) once by pcrl_encoder_pack_weights_f32 into a second image, activations
+ * rounded as they are fed to the next layer; conv0 (raw coordinates), both LayerNorms, ReLU and the max-pool stay fp32.
+ * Same arguments and outputs as pcrl_encoder_fwd_f32; results differ from it by bf16 rounding (tests: |diff| <= 3e-2
+ * on O(1) outputs against a torch emulation of the same rounding points, argmax agreement >= 95 %). */
+int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug /* may be NULL */,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         float* pooled, int32_t* argmax,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Number of floats of the flat encoder gradient, laid out in the reference's parameter order
+ * inside visual_nn.conv.mlp: conv0.weight, conv0.bias, conv1.weight, norm1.weight, norm1.bias,
+ * conv2.weight, norm2.weight, norm2.bias. */
+int pcrl_encoder_num_grads(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* n);
+int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes);
+
+/* Encoder backward, fp32: gradient of the shared per-point MLP's parameters given d(loss)/d(pooled).
+ * Replaces autograd through feature.max(-1), LayerNorm1D, ReLU and Conv1d(k=1)
+ * (pointnet.py:148-151, nn_layer.py:207-219, mlp.py:43-56).  Exact: the max-pool routes gradient to
+ * at most c3 points per cloud (argmax), so only those points are recomputed and back-propagated.
+ * `clouds`/`aug` must describe the same inputs (and the same noise) as the forward call that
+ * produced `argmax`.  grads [pcrl_encoder_num_grads] f32 is overwritten; n_active [B] int32 (optional)
+ * receives the number of distinct argmax points per cloud.  Deterministic (no float atomics).
+ * pooled [B, c3] (optional, may be NULL): the forward's output for the same inputs.  With it the LayerNorm-2 / max-pool
+ * backward sums are formed per channel from pooled (y at the argmax point; xhat = (y - beta) / gamma) instead of by searching
+ * every point's registers for the channels it owns -- same gradients to ~1e-7 relative, about 8 % less kernel time. */
+int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                         float* grads, int32_t* n_active,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of pcrl_encoder_fwd_bf16: the forward of the active points is recomputed with the same bf16 contractions (so
+ * LayerNorm inputs, ReLU masks and argmax relations are the forward's) and the two data-gradient GEMMs contract bf16 too
+ * (gradients rounded as they enter, fp32 accumulate); the weight-gradient GEMMs are fp32 on the unrounded operands and the
+ * result is the gradient w.r.t. the fp32 master weights (roundings straight-through).  `argmax` must come from the bf16
+ * forward. */
+int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                         const pcrl_encoder_weights* w, const void* packed,
+                         const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                         float* grads, int32_t* n_active,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fused Adam (+ Polyak + gradient 2-norm) over one flat parameter buffer.
+ * Replaces torch.optim.Adam over one parameter group per tensor (build_optimizer,
+ * pyrl/utils/torch/optimizer_utils.py:43-57; Adam defaults: no weight decay, no amsgrad), the
+ * per-parameter soft_update (pyrl/utils/torch/ops.py:59-90) and grad_norm
+ * (pyrl/utils/torch/module_utils.py:40-45).
+ *   g = grad * grad_scale (1/world after a sum all-reduce); m, v, param updated in place;
+ *   step_counter (device int32) is incremented first and used for the bias corrections, so the call
+ *   can be replayed from a hipGraph; grad_norm_out (device float, optional) <- ||g||_2;
+ *   target (optional): for target_begin <= i < target_end,
+ *   target[i - target_begin] <- (1 - tau) * target[..] + tau * param_new[i]. */
+/* A pass whose second half (sum of the per-block partial sums of grad^2 -> grad_norm_out, step_counter += 1) has been
+ * deferred: filled by pcrl_adam_step_f32 when defer_finalize != NULL and handed to pcrl_gather_scalars_f32 at the end of
+ * the step, which saves one dependent launch per optimizer per step.  Until then the step counter still holds the
+ * number of COMPLETED steps, and the workspace must stay untouched. */
+typedef struct pcrl_adam_pending { const float* partial; int32_t n_partial, _pad; float* grad_norm_out; int32_t* step_counter; } pcrl_adam_pending;
+int pcrl_adam_workspace_bytes(size_t n, size_t* bytes);
+int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                       int32_t* step_counter, float* grad_norm_out,
+                       float* target, size_t target_begin, size_t target_end, float tau,
+                       void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream);
+/* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
+int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
+
+/* ---- stand-alone memory-shaped kernels -----------------------------------------------------------
+ * Symmetric max-pool with first-index argmax over a materialised [rows, N] f32 tensor (rows = B*c) and
+ * its backward: `feature.max(-1)` (pointnet.py:151).  torch CPU rules: first index among equal values;
+ * a NaN wins and the first NaN's index is returned.  HBM-bound: 4 B/element read (forward) or written
+ * (backward). */
+int pcrl_segmax_fwd_f32(const float* x, int64_t rows, int32_t N, float* out, int32_t* idx, void* stream);
+int pcrl_segmax_bwd_f32(const float* grad_out, const int32_t* idx, int64_t rows, int32_t N, float* grad_x, void* stream);
+/* RandomJitterPoints / GlobalRotScaleTrans applied to a [B,3,N] f32 tensor (in place when xyz_out ==
+ * xyz_in): pcd_aug.py:306-327, 84-123.  Same pcrl_aug_desc semantics as the fused encoder load. */
+int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t B, int32_t N, const pcrl_aug_desc* aug, void* stream);
+
+/* ---- dense heads --------------------------------------------------------------------------------
+ * Batched fp32 GEMM  C[z] = epilogue(A[z] . B[z])  with generic operand strides (elements):
+ *   A[m][k] at A + z*a_batch_stride + m*a_stride_m + k*a_stride_k,  B[k][n] likewise,  C row-major (ldc).
+ * Epilogue: + bias[n]; relu; * (mask[m][n] > 0); accumulate into C.  ones_col >= 0 makes column
+ * `ones_col` of B read as 1 for every k (bias gradient as an extra output column).
+ * A Linear layer y = x W^T + b of the reference's LinearMLP heads (pyrl/networks/backbones/mlp.py:97-100)
+ * maps to:  forward  A = x, B[k][n] = W[n][k] (b_stride_k = 1, b_stride_n = K);
+ *           dx = dy W:   A = dy, B = W (b_stride_k = K_in, b_stride_n = 1), mask = the layer input
+ *           (its ReLU output);  dW|db = dy^T [x | 1]:  A[m][k] = dy[k][m], B = x, ones_col = K_in. */
+typedef struct pcrl_gemm_desc {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* mask;
+    int32_t M, N, K, batch;
+    int64_t a_stride_m, a_stride_k, b_stride_k, b_stride_n, ldc, ld_mask;
+    int64_t a_batch_stride, b_batch_stride, c_batch_stride, bias_batch_stride, mask_batch_stride;
+    int32_t relu, ones_col, accumulate, _pad;
+    float* C_ones;                 /* when non-NULL, output column `ones_col` is written to C_ones[m] instead of C */
+    int64_t c_ones_batch_stride;
+} pcrl_gemm_desc;
+int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
+/* Up to 4 INDEPENDENT problems in one launch (no problem may read what another writes): dW and dx of
+ * one layer, or the online and target Q heads of one layer.  Same per-problem semantics as above. */
+int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
+
+/* Row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1] = nn.LayerNorm(out), pointnet.py:110).
+ * The result is written to n_dst <= 4 destinations (dst[i] with leading dimension ld_dst[i]): the
+ * concatenated input buffers of the actor / Q heads (Visuomotor's torch.cat, visuomotor.py:130-141).
+ * xhat [M,F] and rstd [M] are saved for the backward.  Backward: dy = dy0 (+ dy1), dx, and
+ * dgamma/dbeta (optionally accumulated); workspace >= ceil(M/4)*2*F floats. */
+int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,
+                                float eps, float* const* dst, const int64_t* ld_dst, int32_t n_dst,
+                                float* xhat, float* rstd, void* stream);
+/* Up to 3 row batches through the same LayerNorm in one launch (features of s and s' in the critic phase), each
+ * optionally passing up to two blocks of columns through unchanged into a destination (robot state and replay
+ * actions of Visuomotor's concatenations, visuomotor.py:130-141): cat_dst[c][m][0..cat_n[c]) = cat_src[c][m][..]. */
+typedef struct pcrl_ln_job {
+    const float* x; int64_t ldx; int32_t M, n_dst;
+    float* dst[4]; int64_t ld_dst[4];
+    float* xhat; float* rstd;
+    const float* cat_src[2]; float* cat_dst[2]; int64_t cat_ld_src[2], cat_ld_dst[2]; int32_t cat_n[2];
+} pcrl_ln_job;
+int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_t n_jobs, const float* gamma, const float* beta, int32_t F,
+                                      float eps, void* stream);
+int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                float* dgamma, float* dbeta, int32_t accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- update tail ---------------------------------------------------------------------------------
+ * Squashed-Gaussian policy head, mode "max-entropy" (TanhGaussianHead + ScaledTanhNormal,
+ * pyrl/networks/regression_heads/gaussian.py:23-50,83-87; pyrl/utils/torch/distributions.py:89,116-127):
+ *   std = exp(clamp(log_std)), u = mean + eps*std, action = tanh(u)*scale + bias,
+ *   log p = sum_j [ -(u-mean)^2/(2 std^2) - log std - log sqrt(2 pi) - log(scale*(1-tanh(u)^2) + epsilon) ].
+ * feat [B, 2A] = mean | log_std.  The action is written to `action` and optionally `action2` (the Q heads'
+ * concatenated input).  saved [B, 2A] keeps tanh(u) | std for the backward.
+ * Backward: d_action = d_action0 (+ d_action1), d_neglogp = device scalar shared by all rows. */
+int pcrl_tanh_gaussian_fwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* scale, const float* bias,
+                               int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                               float* action, int64_t ld_action, float* action2, int64_t ld_action2,
+                               float* neg_logp, float* saved, void* stream);
+/* Same forward with the standard-normal draws made in the kernel (Philox4x32-10 keyed by `seed`, counter =
+ * (element, draw_id, *step_counter), Box-Muller) and returned in eps_out [B, A] for the backward.  The reference
+ * draws from torch's global generator (distributions.py:122-127); any N(0,1) stream is a valid replacement.
+ * step_counter is a device int32 that the caller advances between steps (the critic optimizer's step count),
+ * so a captured launch draws fresh noise on every hipGraph replay. */
+int pcrl_tanh_gaussian_sample_fwd_f32(const float* feat, int64_t ld_feat, uint64_t seed, const int32_t* step_counter, int32_t draw_id,
+                                      float* eps_out, const float* scale, const float* bias,
+                                      int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                                      float* action, int64_t ld_action, float* action2, int64_t ld_action2,
+                                      float* neg_logp, float* saved, void* stream);
+int pcrl_tanh_gaussian_bwd_f32(const float* feat, int64_t ld_feat, const float* eps, const float* saved, const float* scale,
+                               int32_t B, int32_t A, float log_std_min, float log_std_max, float epsilon,
+                               const float* d_action0, const float* d_action1, int64_t ld_d_action, const float* d_neglogp,
+                               float* d_feat, int64_t ld_d_feat, void* stream);
+
+/* Double-Q TD target + critic loss (sac.py:125-157; drq.py:76-103 with group = num_aug):
+ *   y = r*reward_scale + (1-done)*gamma*(min_h q_next + exp(log_alpha)*neg_logp_next)  [mean over each
+ *   group of `group` consecutive rows], loss = mse_loss(q, y)*H, dq = d loss / d q,
+ *   stats = {loss, max|q-y|, mean_b min_h q, mean y}. */
+int pcrl_sac_critic_loss_f32(const float* q_next, int64_t ld_q_next, const float* neg_logp_next, const float* rewards,
+                             const uint8_t* dones, const float* log_alpha, float gamma, float reward_scale,
+                             int32_t ignore_dones, int32_t group, const float* q, int64_t ld_q, int32_t B, int32_t H,
+                             float* q_target, float* dq, int64_t ld_dq, float* stats, void* stream);
+/* Actor and temperature losses (sac.py:177-195): actor_loss = -(mean_b min_h q_pi + alpha*mean neg_logp),
+ * alpha_loss = exp(log_alpha)*(entropy - target_entropy); outputs dq_pi, d_neglogp (= -alpha/B),
+ * alpha_grad (= d alpha_loss / d log_alpha), stats = {actor_loss, entropy, alpha_loss}. */
+int pcrl_sac_actor_loss_f32(const float* q_pi, int64_t ld_q, const float* neg_logp, const float* log_alpha, float target_entropy,
+                            int32_t B, int32_t H, float* dq, int64_t ld_dq, float* d_neglogp, float* alpha_grad, float* stats,
+                            void* stream);
+
+/* ---- device-resident replay ------------------------------------------------------------------------
+ * dst_k[b] = src_k[idx[b]] for every stored key k in one launch (rows of row_bytes bytes; idx is a device
+ * array of B row numbers, clamped to [0, capacity)).  Replaces ReplayMemory.sample's per-key numpy take and
+ * the host->device copy of the batch (replay_buffer.py:297-322, sac.py:104). */
+typedef struct pcrl_gather_seg { const void* src; void* dst; int64_t row_bytes; } pcrl_gather_seg;
+int pcrl_replay_gather(const pcrl_gather_seg* segs, int32_t n_segs, const int32_t* idx, int32_t B, int64_t capacity, void* stream);
+/* Same gather with the B row numbers drawn in the kernel: uniform with replacement on [0, size) as
+ * OneStepTransition does with numpy (sampling_strategy.py:30-31), from Philox4x32-10 keyed by `seed` with counter
+ * (b, draw); `draw` is the host's sample-call count.  The rows used are written to idx_out (may be NULL). */
+int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t size, int64_t capacity,
+                              uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream);
+
+/* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
+ * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196).  Up to 4 deferred optimizer
+ * passes (pcrl_adam_pending) are finished first, so their gradient norms can be among the gathered scalars. */
+int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                            const pcrl_adam_pending* pending, int32_t n_pending, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRL_H_ */

@@ -1,0 +1,287 @@
+"""PyTorch-CPU restatement of the reference's point-cloud SAC / DrQ hot path -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+It mirrors the reference op for op -- including what makes the reference slow: one encoder pass
+per Q head (3x next_obs, 2x obs, +1 for the actor), the permute->contiguous->layer_norm->permute->
+contiguous LayerNorm1D, one Adam parameter group per tensor -- so that it can serve both as the
+parity oracle for the update step and as the timed CPU baseline (`cpu_baseline.kind = "port"`).
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks it against tests/golden/*.npz, which
+tools/gen_golden.py captured from the reference itself (weights, batches, random draws, metrics,
+gradients, post-update parameters).
+
+Parameters live in one flat dict keyed by the reference's own `named_parameters()` names
+(e.g. "actor.backbone.visual_nn.conv.mlp.conv0.weight"), see SURVEY.md section 5.
+"""
+import math
+import re
+
+import torch
+import torch.nn.functional as F
+
+ENC = "actor.backbone.visual_nn."
+
+
+# ---------------------------------------------------------------------------------------------
+# networks
+# ---------------------------------------------------------------------------------------------
+def preprocess(obs):
+    """PointCloudBase.preprocess (pyrl/networks/backbones/pointnet.py:49-73)."""
+    feature = [obs["xyz"]]
+    if "rgb" in obs:
+        rgb = obs["rgb"]
+        if rgb.dtype == torch.uint8:
+            rgb = rgb / 255.0
+        feature.append(rgb)
+    for key in ("pos_encoding", "seg"):
+        if key in obs:
+            feature.append(obs[key].to(dtype=torch.float32))
+    return torch.cat(feature, dim=-2)
+
+
+def layer_norm_1d(x, weight, bias, eps):
+    """LayerNormkD.forward, channels_first (pyrl/networks/modules/nn_layer.py:207-219)."""
+    x = x.permute(0, 2, 1).contiguous()
+    x = F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    return x.permute(0, 2, 1).contiguous()
+
+
+def pointnet_prepool(P, obs, prefix=ENC, ln_eps=1e-6):
+    """ConvMLP of PointNet (mlp.py:43-56 via pointnet.py:106-109): conv0+ReLU, conv1+LN+ReLU, conv2+LN+ReLU."""
+    x = preprocess(obs)
+    c = prefix + "conv.mlp."
+    x = F.relu(F.conv1d(x, P[c + "conv0.weight"], P[c + "conv0.bias"]))
+    x = F.relu(layer_norm_1d(F.conv1d(x, P[c + "conv1.weight"]), P[c + "norm1.weight"], P[c + "norm1.bias"], ln_eps))
+    x = F.relu(layer_norm_1d(F.conv1d(x, P[c + "conv2.weight"]), P[c + "norm2.weight"], P[c + "norm2.bias"], ln_eps))
+    return x
+
+
+def pointnet_forward(P, obs, prefix=ENC, ln_eps=1e-6):
+    """PointNet.forward (pointnet.py:148-153): shared MLP, max over points, Linear + LayerNorm(eps=1e-5)."""
+    feat = pointnet_prepool(P, obs, prefix, ln_eps).max(-1)[0]
+    f = prefix + "final_mlp."
+    feat = F.linear(feat, P[f + "0.weight"], P[f + "0.bias"])
+    return F.layer_norm(feat, (feat.shape[-1],), P[f + "1.weight"], P[f + "1.bias"], 1e-5)
+
+
+def linear_mlp(P, prefix, x):
+    """LinearMLP with norm_cfg=None, ReLU between layers, linear output (mlp.py:97-100, 48-49)."""
+    i = 0
+    while f"{prefix}linear{i}.weight" in P:
+        x = F.linear(x, P[f"{prefix}linear{i}.weight"], P[f"{prefix}linear{i}.bias"])
+        if f"{prefix}linear{i + 1}.weight" in P:
+            x = F.relu(x)
+        i += 1
+    return x
+
+
+def visuomotor(P, mlp_prefix, obs, actions=None, visual_feature=None, detach_visual=False, count=None):
+    """Visuomotor.forward (pyrl/networks/backbones/visuomotor.py:56-146), non-recurrent path.
+    Returns (output of final_mlp, visual feature before the robot state is appended)."""
+    obs = dict(obs)
+    for key in list(obs.keys()):
+        if "_box" in key or "_seg" in key or "_sem_label" in key or key == "visual_state":
+            obs.pop(key)
+    robot_state = None
+    for key in ("state", "agent"):
+        if key in obs:
+            assert robot_state is None
+            robot_state = obs.pop(key)
+    if visual_feature is None:
+        feat = pointnet_forward(P, obs)
+        if count is not None:
+            count[0] += 1
+        if detach_visual:
+            feat = feat.detach()
+    else:
+        feat = visual_feature
+    saved = feat
+    if robot_state is not None:
+        feat = torch.cat([feat, robot_state], dim=-1)
+    if actions is not None:
+        feat = torch.cat([feat, actions], dim=-1)
+    return linear_mlp(P, mlp_prefix, feat), saved
+
+
+def tanh_gaussian(feature, eps, scale, bias, log_std_bound=(-10.0, 2.0), epsilon=1e-6):
+    """TanhGaussianHead mode="max-entropy" (regression_heads/gaussian.py:23-50, 83-87;
+    regression_base.py:50-74) with ScaledTanhNormal.rsample_with_log_prob
+    (pyrl/utils/torch/distributions.py:89, 116-119) and the sum over the action axis (122-127).
+    Returns (action, neg_logp[..., None])."""
+    mean, log_std = feature.chunk(2, dim=-1)
+    std = torch.clamp(log_std, min=log_std_bound[0], max=log_std_bound[1]).exp()
+    logit = mean + eps * std
+    var = std ** 2
+    log_prob = -((logit - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+    log_prob = log_prob - torch.log(scale * (1 - torch.tanh(logit).pow(2)) + epsilon)
+    sample = torch.tanh(logit) * scale + bias
+    return sample, -log_prob.sum(-1)[..., None]
+
+
+class RefAgent:
+    """SAC / DrQ agent state + update_parameters, restated from pyrl/methods/mfrl/sac.py and drq.py.
+
+    params: dict name -> tensor (reference names; shared encoder stored once under
+    "actor.backbone.visual_nn.*").  Random draws are injected (eps_list, jitter_list) so that a
+    run can be compared with captured reference runs.
+    """
+
+    def __init__(self, params, kind="sac", gamma=0.99, reward_scale=1.0, alpha=0.1, target_entropy=None,
+                 actor_update_interval=2, target_update_interval=2, update_coeff=0.01, num_aug=2,
+                 jitter_range=None, lr=1e-3, alpha_betas=(0.5, 0.999), mirror_redundancy=True):
+        self.kind, self.gamma, self.reward_scale = kind, gamma, reward_scale
+        self.actor_update_interval, self.target_update_interval = actor_update_interval, target_update_interval
+        self.update_coeff, self.num_aug, self.jitter_range = update_coeff, num_aug, jitter_range
+        self.mirror_redundancy = mirror_redundancy
+        self.P = {k: v.clone().float() for k, v in params.items()}
+        self.action_dim = self.P["actor.head.scale"].shape[0]
+        self.target_entropy = -float(self.action_dim) if target_entropy is None else target_entropy
+        if "log_alpha" not in self.P:
+            self.P["log_alpha"] = torch.ones(1) * float(torch.log(torch.tensor(alpha, dtype=torch.float32)))
+        enc = [k for k in self.P if k.startswith(ENC)]
+        self.critic_names = enc + [k for k in self.P if k.startswith("critic.")]
+        self.actor_names = [k for k in self.P if k.startswith("actor.backbone.final_mlp.")]   # visual_nn excluded (pn.py:41)
+        self.actor_module_names = enc + self.actor_names
+        for k in self.critic_names + self.actor_names + ["log_alpha"]:
+            self.P[k].requires_grad_(True)
+        # build_optimizer: one param group per tensor (pyrl/utils/torch/optimizer_utils.py:43-57)
+        self.critic_optim = torch.optim.Adam([{"params": self.P[k]} for k in self.critic_names], lr=lr)
+        self.actor_optim = torch.optim.Adam([{"params": self.P[k]} for k in self.actor_names], lr=lr)
+        self.alpha_optim = torch.optim.Adam([self.P["log_alpha"]], lr=lr, betas=alpha_betas)
+        self.alpha = float(self.P["log_alpha"].exp().item())
+        self.encoder_passes = [0]
+        self.last_grads = {}
+
+    # -- modules ---------------------------------------------------------------------------
+    def actor(self, obs, eps, detach_visual=False):
+        feat, saved = visuomotor(self.P, "actor.backbone.final_mlp.mlp.", obs, detach_visual=detach_visual, count=self.encoder_passes)
+        a, neg_logp = tanh_gaussian(feat, eps, self.P["actor.head.scale"], self.P["actor.head.bias"])
+        return a, neg_logp, saved
+
+    def critic(self, obs, actions, which="critic", visual_feature=None):
+        """ContinuousCritic.forward (applications/actor_critic.py:122-133): one Visuomotor pass per head."""
+        outs = []
+        shared = None
+        for h in (0, 1):
+            vf = visual_feature
+            if vf is None and not self.mirror_redundancy:
+                if shared is None:
+                    shared = pointnet_forward(self.P, {k: v for k, v in obs.items() if k not in ("state", "agent")})
+                    self.encoder_passes[0] += 1
+                vf = shared
+            q, _ = visuomotor(self.P, f"{which}.values.{h}.backbone.final_mlp.mlp.", obs, actions=actions, visual_feature=vf, count=self.encoder_passes)
+            outs.append(q)
+        return torch.cat(outs, dim=-1)
+
+    @staticmethod
+    def grad_norm(tensors):
+        """ExtendedModuleBase.grad_norm (pyrl/utils/torch/module_utils.py:40-45)."""
+        grads = [torch.norm(t.grad.detach(), 2) for t in tensors if t.requires_grad and t.grad is not None]
+        return torch.norm(torch.stack(grads), 2).item() if grads else 0.0
+
+    def soft_update(self):
+        """soft_update (pyrl/utils/torch/ops.py:59-90); the shared visual_nn is skipped by identity."""
+        tau = self.update_coeff
+        with torch.no_grad():
+            for k in self.P:
+                if k.startswith("critic."):
+                    t = self.P["target_" + k]
+                    t.copy_(t * (1.0 - tau) + self.P[k] * tau)
+
+    # -- augmentation ----------------------------------------------------------------------
+    def _aug(self, obs, noise):
+        """GDict.repeat(num_aug, 0) = repeat_interleave of every leaf (array_ops.py:106-121), then
+        RandomJitterPoints on xyz (pcd_aug.py:316-322) with the injected noise."""
+        rep = {k: torch.repeat_interleave(v, self.num_aug, dim=0) for k, v in obs.items()}
+        if noise is not None:
+            rep["xyz"] = rep["xyz"] + noise
+        return rep
+
+    # -- the update step ---------------------------------------------------------------------
+    def update_parameters(self, batch, updates, eps_list, jitter_list=None):
+        P = self.P
+        pre = self.kind
+        eps_list = list(eps_list)
+        obs, next_obs = batch["obs"], batch["next_obs"]
+        actions, rewards, dones = batch["actions"], batch["rewards"], batch["dones"]
+        B = actions.shape[0]
+        if self.kind == "drq":
+            # drq.py:52-63
+            obs = self._aug(obs, jitter_list[0] if jitter_list else None)
+            next_obs = self._aug(next_obs, jitter_list[1] if jitter_list else None)
+            actions = torch.repeat_interleave(actions, self.num_aug, dim=0)
+            rewards = torch.repeat_interleave(rewards, self.num_aug, dim=0)
+            dones = torch.repeat_interleave(dones, self.num_aug, dim=0)
+        with torch.no_grad():
+            next_a, neg_logp, _ = self.actor(next_obs, eps_list.pop(0))
+            q_next = self.critic(next_obs, next_a, which="target_critic")
+            min_q_next = torch.min(q_next, dim=-1, keepdim=True).values
+            min_q_next = min_q_next + self.alpha * neg_logp
+            if self.kind == "drq":    # drq.py:79-87 (no reward_scale; mean over the aug axis)
+                q_target = rewards + (1 - dones.float()) * self.gamma * min_q_next
+                q_target = q_target.reshape(B, self.num_aug).mean(1, keepdim=True)
+                q_target = torch.repeat_interleave(q_target, self.num_aug, dim=0).repeat(1, q_next.shape[-1])
+            else:                      # sac.py:131-134
+                q_target = rewards * self.reward_scale + (1 - dones.float()) * self.gamma * min_q_next
+                q_target = q_target.repeat_interleave(q_next.shape[-1], dim=-1)
+        q = self.critic(obs, actions)
+        critic_loss = F.mse_loss(q, q_target) * q_target.shape[-1]
+        with torch.no_grad():
+            abs_err = torch.abs(q - q_target).max().item()
+        self.critic_optim.zero_grad()
+        critic_loss.backward()
+        self.last_grads = {"critic": {k: P[k].grad.detach().clone() for k in self.critic_names if P[k].grad is not None}}
+        self.critic_optim.step()
+        critic_grad = self.grad_norm([P[k] for k in self.critic_names])
+        self.critic_optim.zero_grad()   # shared_backbone (sac.py:147-148)
+        ret = {
+            f"{pre}/critic_loss": critic_loss.item(), f"{pre}/max_critic_abs_err": abs_err, f"{pre}/alpha": self.alpha,
+            f"{pre}/q": torch.min(q, dim=-1).values.mean().item(), f"{pre}/q_target": torch.mean(q_target).item(),
+            f"{pre}/target_entropy": self.target_entropy, f"{pre}/critic_grad": critic_grad, f"{pre}/grad_steps": 1,
+        }
+        if updates % self.actor_update_interval == 0:
+            if self.kind == "drq":    # drq.py:115: first augmentation of every sample
+                a_obs = {k: v.reshape(B, self.num_aug, *v.shape[1:])[:, 0] for k, v in obs.items()}
+            else:
+                a_obs = obs
+            pi, neg_logp, saved = self.actor(a_obs, eps_list.pop(0), detach_visual=True)
+            entropy = neg_logp.mean()
+            q_pi = self.critic(a_obs, pi, visual_feature=saved.detach())
+            q_pi = torch.min(q_pi, dim=-1, keepdim=True).values
+            actor_loss = -(q_pi.mean() + self.alpha * entropy)
+            self.actor_optim.zero_grad()
+            actor_loss.backward()
+            self.last_grads["actor"] = {k: P[k].grad.detach().clone() for k in self.actor_names}
+            self.actor_optim.step()
+            actor_grad = self.grad_norm([P[k] for k in self.actor_module_names])
+            alpha_loss = P["log_alpha"].exp() * (entropy - self.target_entropy).detach()
+            self.alpha_optim.zero_grad()
+            alpha_loss.backward()
+            self.last_grads["alpha"] = {"log_alpha": P["log_alpha"].grad.detach().clone()}
+            self.alpha_optim.step()
+            self.alpha = P["log_alpha"].exp().item()
+            ret.update({f"{pre}/actor_loss": actor_loss.item(), f"{pre}/alpha_loss": alpha_loss.item(),
+                        f"{pre}/entropy": entropy.item(), f"{pre}/actor_grad": actor_grad})
+        if updates % self.target_update_interval == 0:
+            self.soft_update()
+        return ret
+
+
+def params_from_fixture(d, section="init/"):
+    return {k[len(section):]: torch.from_numpy(d[k]) for k in d.files if k.startswith(section)}
+
+
+def batch_from_fixture(d, u):
+    pre = f"u{u}/batch/"
+    batch = {"obs": {}, "next_obs": {}}
+    for k in d.files:
+        if not k.startswith(pre):
+            continue
+        rest = k[len(pre):]
+        t = torch.from_numpy(d[k])
+        if "/" in rest:
+            side, key = rest.split("/")
+            batch[side][key] = t
+        else:
+            batch[rest] = t
+    return batch

@@ -1,0 +1,3 @@
+"""pointcloud_rl_amd -- MI355X (gfx950) implementation of the point-cloud actor-critic hot path of
+lz1oceani/pointcloud_rl: PointNet encoder + SAC/DrQ update step behind the reference's registry API."""
+__version__ = "0.1.0"

@@ -1,0 +1,93 @@
+"""ctypes binding of libpcrl_hip.so (the C ABI declared in include/pcrl.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C pointcloud_rl_amd/csrc``.
+There is no CPU fallback: if the shared object is missing, loading raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PCRL_HIP_LIB") or os.path.join(_HERE, "libpcrl_hip.so")     # env override: A/B builds during kernel work
+
+PCRL_MAX_SEG = 4
+PCRL_MAX_CHANNELS = 16
+DT_F32, DT_U8, DT_BOOL = 0, 1, 2
+AUG_JITTER, AUG_AFFINE, AUG_SUBSAMPLE = 1, 2, 4
+
+
+class FeatSeg(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("div255", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("stride_b", ctypes.c_int64), ("stride_c", ctypes.c_int64), ("stride_n", ctypes.c_int64)]
+
+
+class CloudDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("nseg", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("seg", FeatSeg * PCRL_MAX_SEG)]
+
+
+class AugDesc(ctypes.Structure):
+    _fields_ = [("flags", ctypes.c_int32), ("row_mul", ctypes.c_int32), ("row_add", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("jitter_noise", ctypes.c_void_p),
+                ("jitter_lo", ctypes.c_float), ("jitter_hi", ctypes.c_float),
+                ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p),
+                ("offset_ptr", ctypes.c_void_p), ("point_index", ctypes.c_void_p), ("n_index", ctypes.c_int32), ("_pad2", ctypes.c_int32)]
+
+
+class EncoderWeights(ctypes.Structure):
+    _fields_ = [("c_in", ctypes.c_int32), ("c1", ctypes.c_int32), ("c2", ctypes.c_int32), ("c3", ctypes.c_int32),
+                ("w0", ctypes.c_void_p), ("b0", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("g1", ctypes.c_void_p),
+                ("be1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("g2", ctypes.c_void_p), ("be2", ctypes.c_void_p),
+                ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
+
+
+class AdamPending(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("n_partial", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("grad_norm_out", ctypes.c_void_p), ("step_counter", ctypes.c_void_p)]
+
+
+class LnJob(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
+                ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("cat_src", ctypes.c_void_p * 2), ("cat_dst", ctypes.c_void_p * 2), ("cat_ld_src", ctypes.c_int64 * 2),
+                ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2)]
+
+
+class GatherSeg(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("row_bytes", ctypes.c_int64)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("mask", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("batch", ctypes.c_int32),
+                ("a_stride_m", ctypes.c_int64), ("a_stride_k", ctypes.c_int64), ("b_stride_k", ctypes.c_int64), ("b_stride_n", ctypes.c_int64),
+                ("ldc", ctypes.c_int64), ("ld_mask", ctypes.c_int64),
+                ("a_batch_stride", ctypes.c_int64), ("b_batch_stride", ctypes.c_int64), ("c_batch_stride", ctypes.c_int64),
+                ("bias_batch_stride", ctypes.c_int64), ("mask_batch_stride", ctypes.c_int64),
+                ("relu", ctypes.c_int32), ("ones_col", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("C_ones", ctypes.c_void_p), ("c_ones_batch_stride", ctypes.c_int64)]
+
+
+class PcrlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libpcrl_hip.so once.  Raises if it has not been built -- the product has no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PcrlError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C pointcloud_rl_amd/csrc)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.pcrl_last_error.restype = ctypes.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PcrlError(f"pcrl error {rc}: {lib().pcrl_last_error().decode(errors='replace')}")

@@ -1,0 +1,225 @@
+"""DrQ point-cloud augmentations, fused into the encoder's load.
+
+Registry and class contracts follow the reference's pyrl/utils/augmentations/{builder.py:7-104,
+pcd_aug.py:125-227, 306-327}.  Instead of materialising an augmented xyz tensor, an augmentation
+returns the observation as an `AugmentedObs` carrying the parameters; the encoder kernel applies
+them while loading points (include/pcrl.h, pcrl_aug_desc).  `materialize()` runs the stand-alone
+kernel for consumers other than the encoder.
+"""
+from collections.abc import Sequence
+
+import numpy as np
+import torch
+
+from .networks.pointnet import AugmentedObs
+from .utils.registry import Registry, build_from_cfg
+
+AUGMENTATIONS = Registry("data augmentation")
+
+
+class DataAugmentations:
+    """Sequence of augmentations applied in order (builder.py:11-46)."""
+
+    def __init__(self, transforms):
+        assert isinstance(transforms, Sequence)
+        self.transforms = []
+        for t in transforms:
+            if isinstance(t, dict):
+                t = build_from_cfg(t, AUGMENTATIONS)
+            elif not callable(t):
+                raise TypeError(f"transform must be callable or a dict, but got {type(t)}")
+            self.transforms.append(t)
+
+    def __call__(self, data, begin_index=0):
+        for t in self.transforms[begin_index:]:
+            data = t(data)
+            if data is None:
+                return None
+        return data
+
+    def __getitem__(self, key):
+        return self.transforms[key]
+
+    def __repr__(self):
+        return type(self).__name__ + "(" + "".join(f"\n    {t}" for t in self.transforms) + "\n)"
+
+
+def build_data_augmentations(cfg, default_args=None):
+    if cfg is None:
+        return None
+    if not isinstance(cfg, (list, tuple)):
+        cfg = [cfg]
+    return DataAugmentations(cfg)
+
+
+def _as_augmented(data):
+    out = AugmentedObs(data)
+    out.aug = dict(getattr(data, "aug", None) or {})
+    return out
+
+
+class _PointAug:
+    def __init__(self, main_key, req_keys):
+        self.main_key = main_key
+        self.req_keys = req_keys or [main_key]
+        assert main_key in self.req_keys, f"{main_key}, {self.req_keys} do not satisfy the requirement!"
+        if list(self.req_keys) != ["xyz"]:
+            raise NotImplementedError("the fused augmentations act on the 'xyz' key of a point-cloud observation "
+                                      "(main_key='xyz', req_keys=['xyz'], as in configs/mfrl/drq/*/pn_*.py)")
+
+    def _check(self, data):
+        assert self.main_key in data, f"{self.main_key}, {list(data.keys())}"
+        assert data["xyz"].shape[-2] == 3
+
+
+@AUGMENTATIONS.register_module()
+class RandomJitterPoints(_PointAug):
+    """xyz + U(lo, hi) i.i.d. per coordinate (pcd_aug.py:306-327).  The reference draws the noise on
+    the CPU and copies it to the device every step; here it is generated in-kernel (Philox4x32-10,
+    keyed by `seed` and a per-call counter) unless `noise_override` is set (parity tests)."""
+
+    def __init__(self, main_key="inputs/xyz", req_keys=None, jitter_range=[-0.1, 0.1], seed=None):
+        super().__init__(main_key, req_keys)
+        self.jitter_range = [float(jitter_range[0]), float(jitter_range[1])]
+        self.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+        self.calls = 0
+        self._counter = None           # device int64 call counter: a hipGraph replay must draw fresh noise
+        self.noise_override = []       # parity tests queue explicit noise tensors here (consumed in call order)
+
+    def __call__(self, data):
+        self._check(data)
+        out = _as_augmented(data)
+        if self.noise_override:
+            noise = self.noise_override.pop(0)
+            assert noise.shape == data["xyz"].shape, f"{noise.shape} vs {data['xyz'].shape}"
+            out.aug["jitter_noise"] = noise.to(device=data["xyz"].device, dtype=torch.float32).contiguous()
+        else:
+            dev = data["xyz"].device
+            if self._counter is None or self._counter.device != dev:
+                self._counter = torch.full((1,), self.calls, dtype=torch.int64, device=dev)
+            self._counter += 1
+            out.aug.update(jitter_range=self.jitter_range, seed=self.seed, offset=self.calls,
+                           offset_tensor=self._counter.clone())   # this call's own slot, filled on the device
+        self.calls += 1
+        return out
+
+    def __repr__(self):
+        return f"{type(self).__name__}(jitter_range={self.jitter_range},"
+
+
+@AUGMENTATIONS.register_module()
+class RandomDownSample:
+    """Keep a random subset of the points, the same subset for every cloud of the batch and every key
+    (pcd_aug.py:231-268: `batch_perm(data[:1, 0, :], 1, max_num_points)[0]` = the first k entries of
+    `rand(N).argsort()`, drawn once per call and applied to all `req_keys`).  With drop_ratio and
+    fixed_ratio=False the number of dropped points is itself random per call (`np.random.randint(int(N * ratio))`),
+    exactly as in the reference -- the cloud size then changes from step to step, which a captured hipGraph cannot
+    follow: use fixed_ratio=True (or max_num_points) together with `agent.enable_graphs()`.
+    Nothing is gathered: the index travels with the observation and the encoder reads point index[p] for position p."""
+
+    def __init__(self, main_key="inputs/xyz", req_keys=["input/xyz"], max_num_points=None, drop_ratio=None, fixed_ratio=True):
+        assert (drop_ratio is not None) ^ (max_num_points is not None)
+        self.main_key, self.req_keys = main_key, list(req_keys)
+        self.max_num_points, self.drop_ratio, self.fixed_ratio = max_num_points, drop_ratio, fixed_ratio
+        self.index_override = []       # parity tests queue explicit index tensors here
+
+    def __call__(self, data):
+        assert self.main_key in data, f"{self.main_key}, {list(data.keys())}"
+        point_keys = [k for k, v in data.items() if torch.is_tensor(v) and v.ndim == 3]
+        missing = [k for k in point_keys if k not in self.req_keys]
+        if missing:
+            raise NotImplementedError(f"RandomDownSample: point-cloud keys {missing} are not in req_keys {self.req_keys}; "
+                                      "the fused encoder reads every per-point key through the same index")
+        x = data[self.main_key]
+        N = x.shape[-1]
+        if self.drop_ratio is not None:
+            n_drop = int(N * self.drop_ratio) if self.fixed_ratio else int(np.random.randint(int(N * self.drop_ratio)))
+            k = N - n_drop
+        else:
+            k = min(self.max_num_points, N)
+        out = _as_augmented(data)
+        if self.index_override:
+            index = self.index_override.pop(0).to(device=x.device, dtype=torch.int32).contiguous()
+        elif k >= N:
+            return out
+        else:
+            index = torch.rand(N, device=x.device).argsort()[:k].to(torch.int32)
+        out.aug["point_index"] = index
+        return out
+
+    def __repr__(self):
+        if self.drop_ratio is not None:
+            return f"{type(self).__name__}(drop_ratio={self.drop_ratio}) (fixed_ratio={self.fixed_ratio})"
+        return f"{type(self).__name__}(max_num_points={self.max_num_points})"
+
+
+def batch_rot_with_axis(angle, rot_axis=2):
+    """[.., 1] angles -> [.., 3, 3] rotations about `rot_axis` (reference pyrl/utils/torch/ops.py:171-183)."""
+    assert angle.shape[-1] == 1
+    c, s = torch.cos(angle)[..., 0], torch.sin(angle)[..., 0]
+    j, k = (rot_axis + 1) % 3, (rot_axis + 2) % 3
+    rot = torch.zeros(list(angle.shape[:-1]) + [3, 3], dtype=angle.dtype, device=angle.device)
+    rot[..., rot_axis, rot_axis] = 1
+    rot[..., j, j] = c
+    rot[..., k, k] = c
+    rot[..., j, k] = -s
+    rot[..., k, j] = s
+    return rot
+
+
+@AUGMENTATIONS.register_module()
+class GlobalRotScaleTrans(_PointAug):
+    """Per-cloud rotation about one axis, per-axis scale and translation (pcd_aug.py:125-227): the
+    [B,3,4] matrix is drawn here exactly as the reference builds it (including scale applied to the
+    rows of [R|0] before the translation is written, and `delta_xyz[-1] = 0` zeroing the LAST CLOUD's
+    translation when shift_height is False); the encoder kernel applies it as R x + t."""
+
+    def __init__(self, main_key=["obs/pointcloud/xyz"], req_keys=None, rot_range=[-0.78539816, 0.78539816], rot_axis="z",
+                 scale_ratio_range=[0.95, 1.05], translation_range=[0, 0, 0], shift_height=False):
+        super().__init__(main_key, req_keys)
+        if rot_range is not None and not isinstance(rot_range, (list, tuple, np.ndarray)):
+            rot_range = [-rot_range, rot_range]
+        self.rot_range = rot_range
+        assert rot_axis in ["x", "y", "z", 0, 1, 2]
+        self.rot_axis = ord(rot_axis) - ord("x") if isinstance(rot_axis, str) else rot_axis
+        self.scale_ratio_range = scale_ratio_range
+        if translation_range is not None:
+            translation_range = torch.tensor(translation_range, dtype=torch.float)
+            assert (translation_range >= 0).all(), "translation_range should be positive"
+        self.translation_range = translation_range
+        self.shift_height = shift_height
+        self.matrix_override = []
+
+    def sample_matrix(self, batch_size, device):
+        mat = torch.zeros([batch_size, 3, 4], device=device)
+        if self.rot_range is not None:
+            angle = torch.zeros([batch_size, 1], device=device).uniform_(*self.rot_range)
+            mat[..., :3, :3] = batch_rot_with_axis(angle, self.rot_axis)
+        if self.scale_ratio_range is not None:
+            mat[..., :3, :] *= torch.zeros([batch_size, 3, 1], device=device).uniform_(*self.scale_ratio_range)
+        if self.translation_range is not None:
+            delta = (torch.rand([batch_size, 3], device=device) - 0.5) * 2 * self.translation_range.to(device)
+            if not self.shift_height:
+                delta[-1] = 0
+            mat[..., :3, 3] = delta
+        if self.rot_range is None:
+            # apply_rot_trans(with_rot=False) skips the matrix product altogether (pcd_aug.py:205-214)
+            mat[..., :3, :3] = torch.eye(3, device=device)
+        return mat
+
+    def __call__(self, data):
+        self._check(data)
+        out = _as_augmented(data)
+        if self.matrix_override:
+            mat = self.matrix_override.pop(0)
+        else:
+            mat = self.sample_matrix(data["xyz"].shape[0], data["xyz"].device)
+        if self.translation_range is None:
+            mat = mat.clone()
+            mat[..., :3, 3] = 0
+        out.aug["affine"] = mat.to(torch.float32).contiguous()
+        return out
+
+    def __repr__(self):
+        return (f"{type(self).__name__}(rot_range={self.rot_range}, scale_ratio_range={self.scale_ratio_range}, "
+                f"translation_range={self.translation_range}, shift_height={self.shift_height})")

@@ -1,0 +1,151 @@
+// Internal helpers shared by the HIP translation units of libpcrl_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pcrl.h"
+
+namespace pcrl {
+
+// Records a thread-local error message and returns `code` (see pcrl_last_error()).
+int fail(int code, const char* fmt, ...);
+// Number of compute units of the current device (cached).
+int num_cus();
+
+#define PCRL_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) return ::pcrl::fail(PCRL_E_LAUNCH, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define PCRL_CHECK_LAUNCH(name)                                                               \
+    do {                                                                                      \
+        hipError_t _e = hipGetLastError();                                                    \
+        if (_e != hipSuccess) return ::pcrl::fail(PCRL_E_LAUNCH, "launch %s: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- 32x32 MFMA accumulator geometry -------------------------------------------------
+// v_mfma_f32_32x32x2_f32: lane l holds column (l & 31); register r of the tile holds row
+// (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).  With output channels on rows and points on
+// columns, accumulator slot R = 16 * block + r of lane-half h holds channel acc_chan(R, h)
+// of point (l & 31) -- which is exactly the B-operand layout of k-step R of the next
+// layer (B[k = l >> 5][j = l & 31]), so activations never leave registers between layers.
+__host__ __device__ constexpr int acc_chan(int R, int h) {
+    return 32 * (R >> 4) + ((R & 15) & 3) + 8 * ((R & 15) >> 2) + 4 * h;
+}
+
+// Offsets (in floats) inside the packed weight image, shared by pack kernel, forward and backward.
+struct PackedLayout {
+    int T0, C1, C2, C3;
+    __host__ __device__ constexpr int w0() const { return 0; }                       // [C1/32][T0][64]
+    __host__ __device__ constexpr int b0() const { return w0() + (C1 / 32) * T0 * 64; }  // [C1]
+    __host__ __device__ constexpr int w1() const { return align4(b0() + C1); }       // [C2/32][C1/8][64][4]
+    __host__ __device__ constexpr int ln1() const { return w1() + C2 * C1; }         // [C2][2] (gamma, beta)
+    __host__ __device__ constexpr int w2() const { return align4(ln1() + 2 * C2); }  // [C3/32][C2/8][64][4]
+    __host__ __device__ constexpr int ln2() const { return w2() + C3 * C2; }         // [C3][2]
+    __host__ __device__ constexpr int w2t() const { return align4(ln2() + 2 * C3); } // [C2/32][C3/8][64][4]
+    __host__ __device__ constexpr int w1t() const { return w2t() + C2 * C3; }        // [C1/32][C2/8][64][4]
+    // bf16 images for the mixed-precision forward: [row block][16-channel group][64 lanes][8 bf16], two per float slot
+    __host__ __device__ constexpr int w1b() const { return align4(w1t() + C1 * C2); }    // conv1: C2 x C1 bf16
+    __host__ __device__ constexpr int w2b() const { return align4(w1b() + C1 * C2 / 2); } // conv2: C3 x C2 bf16
+    __host__ __device__ constexpr int w2tb() const { return align4(w2b() + C2 * C3 / 2); } // conv2 transposed: C2 rows x C3 k, bf16
+    __host__ __device__ constexpr int w1tb() const { return align4(w2tb() + C2 * C3 / 2); } // conv1 transposed: C1 rows x C2 k, bf16
+    __host__ __device__ constexpr int total() const { return align4(w1tb() + C1 * C2 / 2); }
+    __host__ __device__ static constexpr int align4(int x) { return (x + 3) & ~3; }
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// fp32 -> bf16 bits, round to nearest even, NaN stays NaN (same rule as v_cvt_pk_bf16_f32 / torch.Tensor.bfloat16()).
+__host__ __device__ inline unsigned bf16_rne_bits(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// Buffer addressing: SGPR resource + one 32-bit VGPR byte offset + scalar/immediate offset.  Used
+// wherever a wave walks many constant-stride pieces of one array, so that no 64-bit VGPR address
+// is materialised per piece.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load_f1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store_f1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+__device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+// lo for the lower wave half, hi for the upper one, as ONE bit-select (written as `half ? hi : lo` on two elements of a
+// vector the compiler turns it into a 15-deep compare/select chain over a run-time element index).
+__device__ __forceinline__ float half_select(float lo, float hi, unsigned half_mask) {
+    return u2f((f2u(hi) & half_mask) | (f2u(lo) & ~half_mask));
+}
+
+// ReLU that propagates NaN and maps -0 to +0 (torch.relu semantics).
+__device__ __forceinline__ float relu_nan(float x) { return !(x <= 0.0f) ? x : 0.0f; }
+
+// Values of lane (l & 31) in the low half and in the high half of the wave, in every lane:
+// v_permlane32_swap exchanges vdst[32..63] with vsrc[0..31].
+__device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
+    auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(x), false, false);
+    lo = u2f(r[0]);
+    hi = u2f(r[1]);
+}
+
+// Max over the 32 lanes of each wave half, result in every lane, unsigned compare.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned allreduce_umax32(unsigned v) {
+    v = umax_(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = umax_(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = umax_(v, dpp_u<0x141>(v));   // row_half_mirror
+    v = umax_(v, dpp_u<0x140>(v));   // row_mirror
+    // lane ^ 16 without the LDS pipe: v_permlane16_swap exchanges row 1 of vdst with row 0 of vsrc and
+    // row 3 of vdst with row 2 of vsrc (rows = 16 lanes), so with both operands = v the two results
+    // hold {row0,row0,row2,row2} and {row1,row1,row3,row3}.
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return umax_(r[0], r[1]);
+}
+
+__device__ __forceinline__ unsigned umin_(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned allreduce_umin32(unsigned v) {
+    v = umin_(v, dpp_u<0xB1>(v));
+    v = umin_(v, dpp_u<0x4E>(v));
+    v = umin_(v, dpp_u<0x141>(v));
+    v = umin_(v, dpp_u<0x140>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return umin_(r[0], r[1]);
+}
+
+// Philox4x32-10 (Salmon et al. 2011); one call yields four 32-bit words.
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// U[lo, hi) from a 32-bit word with 24 bits of mantissa.
+__host__ __device__ inline float u01_to_range(uint32_t w, float lo, float hi) {
+    return lo + (float)(w >> 8) * (1.0f / 16777216.0f) * (hi - lo);
+}
+
+}  // namespace pcrl

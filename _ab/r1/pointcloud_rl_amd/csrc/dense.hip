@@ -1,0 +1,444 @@
+// Dense actor / critic heads for gfx950 (MI355X), fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Replaces the reference's LinearMLP heads (pyrl/networks/backbones/mlp.py:97-100: Linear + ReLU
+// stacks, actor D->1024->1024->2A, each Q head D+A->1024->1024->1) and their autograd backward,
+// plus PointNet.final_mlp's Linear (pointnet.py:110).  One batched GEMM kernel with generic operand
+// strides serves the three shapes of a Linear layer:
+//     forward        Y  = act(X W^T + b)        A = X [M,K]      B[k][n] = W[n][k]
+//     data gradient  dX = (dY W) (.) relu-mask  A = dY [M,N']    B[k][n] = W[k][n]
+//     weight grad    dW = dY^T X, db = dY^T 1   A[m][k] = dY[k][m]  B = X (+ a virtual ones column)
+// and up to four independent problems (dW and dX of one layer, the online and the target Q heads)
+// share one launch, so that small ones overlap instead of paying a dispatch each.
+//
+// The batch is small (M = 256 rows): a 32x32 output tile is owned by one 8-wave workgroup that splits
+// K eight ways and reduces through LDS in a fixed order.  With only 64 MFMAs per wave at K = 1024 the
+// kernel lives or dies by its scalar overhead (measured: an earlier, more general version spent more
+// wave-cycles on addressing and guards than on MFMAs), hence:
+//   * operands are addressed as SGPR buffer resource + one 32-bit lane offset + scalar offset, rows
+//     clamped into range instead of guarded (out-of-range tile rows compute garbage that is never stored);
+//   * a k-contiguous operand is four 16-byte loads per lane per 32 k-steps (lane (i,h) holds
+//     k = k0 + 16h + 4t + j of row i -- any k order works as long as A and B agree), an m/n-contiguous
+//     one is sixteen coalesced 4-byte loads; two 32-k chunks are in flight per wave;
+//   * only the ragged K tail (K % 32) takes a guarded path, where out-of-range k reads as zero through
+//     the buffer bounds check;
+//   * the epilogue issues its bias / mask loads before the split-K barrier and stores through the
+//     buffer path with out-of-range rows / columns dropped by the bounds check.
+#include "common.h"
+
+namespace pcrl {
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    const float* bias;       // [N] added to every row (may be NULL)
+    const float* mask;       // [M][ld_mask]: C = acc * (mask > 0) (ReLU backward; may be NULL)
+    float* C_ones;           // optional separate destination of column `ones_col`
+    long long a_bs, b_bs, c_bs, bias_bs, mask_bs, c_ones_bs;    // batch strides (elements)
+    unsigned a_sm4, a_sk4, b_sn4, b_sk4, ldc4, ld_mask4;        // strides in bytes
+    int M, N, K;
+    int relu;                // C = max(acc + bias, 0)
+    int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
+    int accumulate;          // C += result
+    int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
+    int wg_n, wg_nm;         // n tiles, n tiles * m tiles
+    float inv_wg_n, inv_wg_nm;
+    int wg_begin;            // first workgroup of this problem inside the launch
+};
+
+constexpr int kGemmWaves = 8;
+constexpr int kGemmGroup = 4;
+constexpr unsigned kGemmOob = 0x80000000u;          // beyond every resource's num_records: loads give 0, stores are dropped
+constexpr unsigned kGemmRecords = 0x7FFFFFFFu;
+// wg_begin[] first: one scalar load finds the problem, a second clause fetches its whole descriptor
+struct GemmGroup { int wg_begin[kGemmGroup]; int n; int _pad[3]; GemmParams p[kGemmGroup]; };
+
+// 32 k-steps of one operand for lane (i,h): v[t][j] = X[row i][32 sc + 16 h + 4 t + j].  `off` is the lane's byte
+// offset of (row i, k = 16 h).
+__device__ __forceinline__ void gemm_load_full(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned sk4, bool k4, int sc, f32x4 (&v)[4]) {
+    if (k4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = buf_load_f4(rs, off + 16 * t, sc * 128);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[t][j] = buf_load_f1(rs, off, (unsigned)(32 * sc + 4 * t + j) * sk4);
+    }
+}
+// The ragged last chunk: k >= K reads as zero (offset forced out of the resource's range).
+__device__ __forceinline__ void gemm_load_tail(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned sk4, int kbase, int K, f32x4 (&v)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kbase + 4 * t + j;
+            v[t][j] = buf_load_f1(rs, k < K ? off + (unsigned)(k - (kbase & 16)) * sk4 : kGemmOob, 0);
+        }
+}
+
+// A wave-uniform pointer as the compiler can prove it (keeps buffer resources in SGPRs).
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* ptr) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ void gemm_mfma16(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x16& acc) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[t][j], acc, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(64 * kGemmWaves) void gemm_f32_kernel(const GemmGroup g) {
+    __shared__ __attribute__((aligned(16))) float s_red[kGemmWaves][16][64];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    const int wg = blockIdx.x;
+    int gi = 0;
+#pragma unroll
+    for (int j = 1; j < kGemmGroup; ++j)
+        if (j < g.n && wg >= g.wg_begin[j]) gi = j;
+    const GemmParams p = g.p[gi];
+    // every field is needed within the next microsecond: one clause of scalar loads instead of dependent waits
+    asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.C), "s"(p.bias), "s"(p.mask), "s"(p.C_ones), "s"(p.a_bs), "s"(p.b_bs), "s"(p.c_bs),
+                 "s"(p.bias_bs), "s"(p.mask_bs), "s"(p.c_ones_bs));
+    asm volatile("" ::"s"(p.a_sm4), "s"(p.a_sk4), "s"(p.b_sn4), "s"(p.b_sk4), "s"(p.ldc4), "s"(p.ld_mask4), "s"(p.M), "s"(p.N), "s"(p.K),
+                 "s"(p.relu), "s"(p.ones_col), "s"(p.accumulate), "s"(p.a_k4), "s"(p.b_k4), "s"(p.wg_n), "s"(p.wg_nm), "s"(p.inv_wg_n),
+                 "s"(p.inv_wg_nm), "s"(p.wg_begin));
+    // tile decode without integer division (exact for < 2^20 workgroups; checked on the host)
+    const int local = wg - p.wg_begin;
+    const int bz = __builtin_amdgcn_readfirstlane((int)(((float)local + 0.5f) * p.inv_wg_nm));
+    const int rem = local - bz * p.wg_nm;
+    const int my = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * p.inv_wg_n));
+    const int nx = rem - my * p.wg_n;
+    const int m0 = my * 32, n0 = nx * 32;
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(uniform_ptr(p.A + bz * p.a_bs), kGemmRecords);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(uniform_ptr(p.B + bz * p.b_bs), kGemmRecords);
+    const int n = n0 + i;
+    int n_read = min(n, p.N - 1);
+    if (n_read == p.ones_col) n_read = 0;                       // that column is never read from memory
+    const unsigned a_off = (unsigned)min(m0 + i, p.M - 1) * p.a_sm4 + 16u * h * p.a_sk4;
+    const unsigned b_off = (unsigned)n_read * p.b_sn4 + 16u * h * p.b_sk4;
+    const bool a4 = p.a_k4 != 0, b4 = p.b_k4 != 0, ones = p.ones_col >= 0, n_ones = n == p.ones_col;
+    const int n_sc = (p.K + 31) >> 5, per = (n_sc + kGemmWaves - 1) / kGemmWaves;
+    const int sc_begin = wave * per, sc_end = min(sc_begin + per, n_sc), full_end = min(sc_end, p.K >> 5);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    auto load = [&](int sc, f32x4 (&a)[4], f32x4 (&b)[4]) {
+        gemm_load_full(rs_a, a_off, p.a_sk4, a4, sc, a);
+        gemm_load_full(rs_b, b_off, p.b_sk4, b4, sc, b);
+        if (ones) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[t][j] = n_ones ? 1.0f : b[t][j];
+        }
+    };
+    int sc = sc_begin;
+    if (sc < full_end) load(sc, a0, b0);
+    if (sc + 1 < full_end) load(sc + 1, a1, b1);
+    while (sc < full_end) {             // two 32-k chunks in flight
+        gemm_mfma16(a0, b0, acc);
+        if (sc + 2 < full_end) load(sc + 2, a0, b0);
+        if (++sc >= full_end) break;
+        gemm_mfma16(a1, b1, acc);
+        if (sc + 2 < full_end) load(sc + 2, a1, b1);
+        ++sc;
+    }
+    if (sc < sc_end) {                  // the ragged last chunk (K % 32 != 0), owned by one k-slice
+        const int kbase = 32 * sc + 16 * h;
+        gemm_load_tail(rs_a, a_off, p.a_sk4, kbase, p.K, a0);
+        gemm_load_tail(rs_b, b_off, p.b_sk4, kbase, p.K, b0);
+        if (ones) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[t][j] = n_ones ? (kbase + 4 * t + j < p.K ? 1.0f : 0.0f) : b0[t][j];
+        }
+        gemm_mfma16(a0, b0, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
+
+    // Epilogue: thread (wave, lane) owns column n0 + (lane & 31) of accumulator rows r = wave and wave + 8.
+    const int col = n0 + (lane & 31);
+    const bool col_ok = col < p.N;
+    float bv = 0.0f, mv[2] = {1.0f, 1.0f}, old[2] = {0.0f, 0.0f};
+    unsigned c_off[2];
+    int row[2];
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(uniform_ptr(p.C + bz * p.c_bs), kGemmRecords);
+    if (p.bias) bv = (p.bias + bz * p.bias_bs)[min(col, p.N - 1)];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = wave + 8 * e;
+        row[e] = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        c_off[e] = (row[e] < p.M && col_ok) ? (unsigned)row[e] * p.ldc4 + 4u * col : kGemmOob;
+    }
+    if (p.mask) {
+        const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(uniform_ptr(p.mask + bz * p.mask_bs), kGemmRecords);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            mv[e] = buf_load_f1(rs_m, c_off[e] == kGemmOob ? kGemmOob : (unsigned)row[e] * p.ld_mask4 + 4u * col, 0);
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) old[e] = buf_load_f1(rs_c, c_off[e], 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int r = wave + 8 * e;
+        float v = ((s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane])) +
+                  ((s_red[4][r][lane] + s_red[5][r][lane]) + (s_red[6][r][lane] + s_red[7][r][lane]));
+        v = v + bv;
+        if (p.relu) v = v > 0.0f ? v : 0.0f;
+        v = mv[e] > 0.0f ? v : 0.0f;
+        v = old[e] + v;
+        if (p.C_ones && col == p.ones_col) {
+            if (c_off[e] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row[e]] = v;
+        } else {
+            buf_store_f1(rs_c, c_off[e], 0, v);
+        }
+    }
+}
+
+// Row-wise LayerNorm over a short feature vector (PointNet.final_mlp[1]: nn.LayerNorm(out), eps 1e-5,
+// pointnet.py:110), one wave per row; the output may be scattered into several destination
+// buffers (the concatenated inputs of the actor and Q heads).
+struct LnJob {
+    const float* x; long long ldx;       // [M][F]
+    int M, n_dst, blk_begin;
+    float* y[4]; long long ldy[4];
+    float* xhat; float* rstd;            // saved for backward (may be NULL)
+    // optional pass-through columns (robot state / replay actions of Visuomotor's torch.cat, visuomotor.py:130-141):
+    // cat_dst[m][0..cat_n) = cat_src[m][0..cat_n)
+    const float* cat_src[2]; float* cat_dst[2]; long long cat_lds[2], cat_ldd[2]; int cat_n[2];
+};
+constexpr int kLnJobs = 3;
+struct LnParams {
+    const float* gamma; const float* beta; int F; float eps; int n_jobs;
+    LnJob job[kLnJobs];
+};
+
+__global__ __launch_bounds__(256) void layernorm_rows_fwd_kernel(const LnParams p) {
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < kLnJobs; ++j)
+        if (j < p.n_jobs && (int)blockIdx.x >= p.job[j].blk_begin) ji = j;
+    const LnJob& jb = p.job[ji];
+    const int row = ((int)blockIdx.x - jb.blk_begin) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= jb.M) return;
+    const float* x = jb.x + (long long)row * jb.ldx;
+    float v[4], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; v[j] = f < p.F ? x[f] : 0.0f; s += v[j]; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)p.F;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; const float d = f < p.F ? v[j] - mean : 0.0f; q += d * d; }
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / __builtin_sqrtf(q / (float)p.F + p.eps);
+    if (jb.rstd && lane == 0) jb.rstd[row] = rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = lane + 64 * j;
+        if (f < p.F) {
+            const float xh = (v[j] - mean) * rstd;
+            if (jb.xhat) jb.xhat[(long long)row * p.F + f] = xh;
+            const float y = xh * p.gamma[f] + p.beta[f];
+            for (int d = 0; d < jb.n_dst; ++d) jb.y[d][(long long)row * jb.ldy[d] + f] = y;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (jb.cat_src[c])
+            for (int f = lane; f < jb.cat_n[c]; f += 64) jb.cat_dst[c][(long long)row * jb.cat_ldd[c] + f] = jb.cat_src[c][(long long)row * jb.cat_lds[c] + f];
+}
+
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma, where dy is the
+// sum of up to two upstream gradients (one per Q head); per-block partial dgamma / dbeta.
+struct LnBwdParams {
+    const float* dy0; const float* dy1; long long lddy;   // dy1 may be NULL
+    const float* xhat; const float* rstd; const float* gamma;
+    int M, F;
+    float* dx; long long lddx;
+    float* part;             // [gridDim.x][2][F] partial sums of dy*xhat and dy
+};
+
+__global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const LnBwdParams p) {
+    __shared__ float s_acc[4][2][256];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < p.M) {
+        float dxh[4], xh[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = lane + 64 * j;
+            dxh[j] = xh[j] = 0.0f;
+            if (f < p.F) {
+                float dy = p.dy0[(long long)row * p.lddy + f];
+                if (p.dy1) dy += p.dy1[(long long)row * p.lddy + f];
+                xh[j] = p.xhat[(long long)row * p.F + f];
+                dg[j] = dy * xh[j]; db[j] = dy;
+                dxh[j] = dy * p.gamma[f];
+                s1 += dxh[j]; s2 += dxh[j] * xh[j];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        const float m1 = s1 / (float)p.F, m2 = s2 / (float)p.F, rstd = p.rstd[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = lane + 64 * j;
+            if (f < p.F) p.dx[(long long)row * p.lddx + f] = rstd * ((dxh[j] - m1) - xh[j] * m2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_acc[wave][0][lane + 64 * j] = dg[j]; s_acc[wave][1][lane + 64 * j] = db[j]; }
+    __syncthreads();
+    const int f = threadIdx.x;
+    if (f < p.F) {
+        p.part[((long long)blockIdx.x * 2 + 0) * p.F + f] = (s_acc[0][0][f] + s_acc[1][0][f]) + (s_acc[2][0][f] + s_acc[3][0][f]);
+        p.part[((long long)blockIdx.x * 2 + 1) * p.F + f] = (s_acc[0][1][f] + s_acc[1][1][f]) + (s_acc[2][1][f] + s_acc[3][1][f]);
+    }
+}
+
+__global__ void colsum_partials_kernel(const float* part, int nblk, int n, float* out0, float* out1, int half, int accumulate) {
+    // out0[f] = sum_b part[b][0][f], out1[f] = sum_b part[b][1][f]  (fixed order), n = F
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n) return;
+    float a = 0.0f, c = 0.0f;
+    int b = 0;
+    for (; b + 16 <= nblk; b += 16) {          // 32 independent loads in flight, summed in block order
+        float va[16], vc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { va[u] = part[((long long)(b + u) * 2 + 0) * n + f]; vc[u] = part[((long long)(b + u) * 2 + 1) * n + f]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { a += va[u]; c += vc[u]; }
+    }
+    for (; b < nblk; ++b) { a += part[((long long)b * 2 + 0) * n + f]; c += part[((long long)b * 2 + 1) * n + f]; }
+    out0[f] = accumulate ? out0[f] + a : a;
+    out1[f] = accumulate ? out1[f] + c : c;
+}
+
+}  // namespace pcrl
+
+using namespace pcrl;
+
+static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total) {
+    if (!d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
+    if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 1) return fail(PCRL_E_ARG, "bad GEMM shape");
+    p = GemmParams{};
+    p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.mask = d->mask; p.C_ones = d->C_ones;
+    p.a_bs = d->a_batch_stride; p.b_bs = d->b_batch_stride; p.c_bs = d->c_batch_stride;
+    p.bias_bs = d->bias_batch_stride; p.mask_bs = d->mask_batch_stride; p.c_ones_bs = d->c_ones_batch_stride;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.relu = d->relu; p.ones_col = d->ones_col; p.accumulate = d->accumulate;
+    // 32-bit byte offsets inside one batch element (buffer addressing)
+    const int64_t lim = 0x7FFFFFFF / 4;
+    auto span = [](int64_t rows, int64_t rs, int64_t cols, int64_t cs) {
+        return (rows > 0 ? (rows - 1) * rs : 0) + (cols > 0 ? (cols - 1) * cs : 0);
+    };
+    if (d->a_stride_m < 0 || d->a_stride_k < 0 || d->b_stride_k < 0 || d->b_stride_n < 0 || d->ldc < 0 || d->ld_mask < 0 ||
+        span(d->M, d->a_stride_m, d->K, d->a_stride_k) >= lim || span(d->N, d->b_stride_n, d->K, d->b_stride_k) >= lim ||
+        span(d->M, d->ldc, d->N, 1) >= lim || span(d->M, d->ld_mask, d->N, 1) >= lim)
+        return fail(PCRL_E_ARG, "GEMM operand strides must be non-negative and span < 2 GiB per batch element");
+    p.a_sm4 = 4u * (unsigned)d->a_stride_m; p.a_sk4 = 4u * (unsigned)d->a_stride_k;
+    p.b_sn4 = 4u * (unsigned)d->b_stride_n; p.b_sk4 = 4u * (unsigned)d->b_stride_k;
+    p.ldc4 = 4u * (unsigned)d->ldc; p.ld_mask4 = 4u * (unsigned)d->ld_mask;
+    auto aligned = [](const float* ptr, long long sm, long long bs) {
+        return (reinterpret_cast<uintptr_t>(ptr) % 16 == 0) && sm % 4 == 0 && bs % 4 == 0;
+    };
+    p.a_k4 = d->a_stride_k == 1 && aligned(p.A, d->a_stride_m, p.a_bs);
+    p.b_k4 = d->b_stride_k == 1 && aligned(p.B, d->b_stride_n, p.b_bs);
+    p.wg_n = (p.N + 31) / 32;
+    p.wg_nm = p.wg_n * ((p.M + 31) / 32);
+    p.inv_wg_n = 1.0f / (float)(p.wg_n > 0 ? p.wg_n : 1);
+    p.inv_wg_nm = 1.0f / (float)(p.wg_nm > 0 ? p.wg_nm : 1);
+    p.wg_begin = wg_total;
+    wg_total += p.wg_nm * d->batch;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream) {
+    if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
+    GemmGroup g{};
+    int wg_total = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = gemm_fill(&descs[i], g.p[g.n], wg_total);
+        if (rc != PCRL_OK) return rc;
+        g.wg_begin[g.n] = g.p[g.n].wg_begin;
+        if (descs[i].M > 0 && descs[i].N > 0) ++g.n;        // empty problems contribute no workgroups
+    }
+    if (g.n == 0 || wg_total == 0) return PCRL_OK;
+    if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), 0, (hipStream_t)stream, g);
+    PCRL_CHECK_LAUNCH("gemm_f32_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream) {
+    if (!d) return fail(PCRL_E_ARG, "NULL argument");
+    return pcrl_gemm_group_f32(d, 1, stream);
+}
+
+extern "C" int pcrl_layernorm_rows_fwd_multi_f32(const pcrl_ln_job* jobs, int32_t n_jobs, const float* gamma, const float* beta, int32_t F,
+                                                 float eps, void* stream) {
+    if (!jobs || !gamma || !beta) return fail(PCRL_E_ARG, "NULL argument");
+    if (F < 1 || F > 256 || n_jobs < 1 || n_jobs > kLnJobs) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, 1 <= n_jobs <= %d", kLnJobs);
+    LnParams p{};
+    p.gamma = gamma; p.beta = beta; p.F = F; p.eps = eps;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const pcrl_ln_job& s = jobs[j];
+        if (s.M == 0) continue;
+        if (!s.x || s.M < 0 || s.n_dst < 0 || s.n_dst > 4) return fail(PCRL_E_ARG, "bad LayerNorm job %d", j);
+        LnJob& d = p.job[p.n_jobs++];
+        d.x = s.x; d.ldx = s.ldx; d.M = s.M; d.n_dst = s.n_dst; d.blk_begin = blocks; d.xhat = s.xhat; d.rstd = s.rstd;
+        for (int i = 0; i < s.n_dst; ++i) { if (!s.dst[i]) return fail(PCRL_E_ARG, "NULL destination"); d.y[i] = s.dst[i]; d.ldy[i] = s.ld_dst[i]; }
+        for (int c = 0; c < 2; ++c) {
+            if (s.cat_n[c] > 0 && (!s.cat_src[c] || !s.cat_dst[c])) return fail(PCRL_E_ARG, "NULL pass-through columns");
+            d.cat_src[c] = s.cat_n[c] > 0 ? s.cat_src[c] : nullptr; d.cat_dst[c] = s.cat_dst[c];
+            d.cat_lds[c] = s.cat_ld_src[c]; d.cat_ldd[c] = s.cat_ld_dst[c]; d.cat_n[c] = s.cat_n[c];
+        }
+        blocks += (s.M + 3) / 4;
+    }
+    if (blocks == 0) return PCRL_OK;
+    hipLaunchKernelGGL(layernorm_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("layernorm_rows_fwd_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_layernorm_rows_fwd_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, int32_t M, int32_t F,
+                                           float eps, float* const* dst, const int64_t* ld_dst, int32_t n_dst,
+                                           float* xhat, float* rstd, void* stream) {
+    if (!x || !dst || !ld_dst) return fail(PCRL_E_ARG, "NULL argument");
+    if (n_dst < 1 || n_dst > 4) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, 1 <= n_dst <= 4");
+    pcrl_ln_job job{};
+    job.x = x; job.ldx = ldx; job.M = M; job.n_dst = n_dst; job.xhat = xhat; job.rstd = rstd;
+    for (int i = 0; i < n_dst; ++i) { job.dst[i] = dst[i]; job.ld_dst[i] = ld_dst[i]; }
+    return pcrl_layernorm_rows_fwd_multi_f32(&job, 1, gamma, beta, F, eps, stream);
+}
+
+extern "C" int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                           const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                           float* dgamma, float* dbeta, int32_t accumulate,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy0 || !xhat || !rstd || !gamma || !dx || !dgamma || !dbeta) return fail(PCRL_E_ARG, "NULL argument");
+    if (F < 1 || F > 256) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256");
+    if (M == 0) return PCRL_OK;
+    const int nblk = (M + 3) / 4;
+    const size_t need = sizeof(float) * (size_t)nblk * 2 * F;
+    if (!workspace || workspace_bytes < need) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+    LnBwdParams p{dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, static_cast<float*>(workspace)};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_rows_bwd_kernel, dim3(nblk), dim3(256), 0, st, p);
+    PCRL_CHECK_LAUNCH("layernorm_rows_bwd_kernel");
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((F + 255) / 256), dim3(256), 0, st, p.part, nblk, F, dgamma, dbeta, 0, accumulate);
+    PCRL_CHECK_LAUNCH("colsum_partials_kernel");
+    return PCRL_OK;
+}

@@ -1,0 +1,274 @@
+// Device code shared by the encoder forward and backward kernels: observation loading
+// (PointCloudBase.preprocess, reference pyrl/networks/backbones/pointnet.py:49-73), the fused
+// DrQ augmentations (pyrl/utils/augmentations/pcd_aug.py) and the per-point LayerNorm.
+#pragma once
+#include "common.h"
+
+namespace pcrl {
+
+struct ChanSrc {
+    const void* base;     // already offset to this channel
+    long long stride_b;   // elements
+    long long stride_n;   // elements
+    int dtype;            // PCRL_DT_*
+    int div255;
+};
+
+// Where the points come from and how they are augmented (shared by forward and backward so that
+// the backward recomputes exactly the forward's inputs).
+struct CloudParams {
+    int B, N, C;
+    int aug_flags;
+    int row_mul, row_add;     // augmentation row of cloud b = b * row_mul + row_add
+    float jitter_lo, jitter_hi;
+    const float* jitter_noise;
+    const float* affine;
+    unsigned long long seed, offset;
+    const unsigned long long* offset_ptr;
+    const int* point_index;   // SUBSAMPLE: stored point of position n (N is then the subsampled count)
+    ChanSrc ch[PCRL_MAX_CHANNELS];
+};
+
+// Channel descriptors are staged in LDS (not SGPRs: 16 x 32 B of kernel arguments would stay
+// live across the whole tile body).  All lanes read the same descriptor; the dtype flags are
+// made scalar again so the branches stay wave-uniform.
+__device__ __forceinline__ float load_chan(const ChanSrc* s_desc, int c, int b, int n) {
+    const ChanSrc d = s_desc[c];
+    const long long off = (long long)b * d.stride_b + (long long)n * d.stride_n;
+    const int dtype = __builtin_amdgcn_readfirstlane(d.dtype);
+    const int div255 = __builtin_amdgcn_readfirstlane(d.div255);
+    float v;
+    if (dtype == PCRL_DT_F32) {
+        v = static_cast<const float*>(d.base)[off];
+    } else {
+        v = (float)static_cast<const unsigned char*>(d.base)[off];
+        if (dtype == PCRL_DT_BOOL) v = v != 0.0f ? 1.0f : 0.0f;
+    }
+    if (div255) v = v / 255.0f;
+    return v;
+}
+
+// Features of point n of cloud b, channels 0..2*T0-1 (zero beyond C), augmentation applied to xyz.
+template <int T0>
+__device__ __forceinline__ f32x16 load_point(const CloudParams& p, const ChanSrc* s_desc, int b, int n) {
+    f32x16 x;
+    const int n_src = p.point_index ? p.point_index[n] : n;
+#pragma unroll
+    for (int c = 0; c < 2 * T0; ++c) x[c] = c < p.C ? load_chan(s_desc, c, b, n_src) : 0.0f;
+    const long long row = (long long)b * p.row_mul + p.row_add;
+    if (p.aug_flags & PCRL_AUG_AFFINE) {
+        const float* M = p.affine + row * 12;
+        const float x0 = x[0], x1 = x[1], x2 = x[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            x[j] = ((M[4 * j + 0] * x0 + M[4 * j + 1] * x1) + M[4 * j + 2] * x2) + M[4 * j + 3];
+    }
+    if (p.aug_flags & PCRL_AUG_JITTER) {
+        if (p.jitter_noise) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[j] = x[j] + p.jitter_noise[(row * 3 + j) * p.N + n];
+        } else {
+            const unsigned long long e = (unsigned long long)row * p.N + n;
+            const unsigned long long off = p.offset_ptr ? *p.offset_ptr : p.offset;
+            uint32_t w[4];
+            philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), (uint32_t)off, (uint32_t)(off >> 32),
+                          (uint32_t)p.seed, (uint32_t)(p.seed >> 32), w);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) x[j] = x[j] + u01_to_range(w[j], p.jitter_lo, p.jitter_hi);
+        }
+    }
+    return x;
+}
+
+// Two accumulator registers at a time: gfx950's v_pk_{add,mul,fma}_f32 do two fp32 operations per VALU issue, and a
+// VALU issue costs the same FP32 ALU cycles as the MFMAs (tools/probes/mfma_valu_overlap.hip).  The element order of
+// the sums is unchanged (partial sums over registers r % 4, as in oracle/pcrl_oracle.c): results are bit-identical.
+#define PCRL_PAIR(v, r) (f32x2{(v)[(r)], (v)[(r) + 1]})
+
+template <int C>
+__device__ __forceinline__ float ln_center_rstd(f32x16 (&a)[C / 32], float eps, bool* var_is_nan) {
+    // mean and variance in the canonical order (oracle/pcrl_oracle.c); `a` is replaced by a - mean.
+    constexpr int MB = C / 32;
+    f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            p01 = p01 + PCRL_PAIR(a[mb], r);
+            p23 = p23 + PCRL_PAIR(a[mb], r + 2);
+        }
+    }
+    float lo, hi;
+    both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
+    const float mean = (lo + hi) / (float)C;
+    const f32x2 mean2 = {mean, mean};
+    p01 = f32x2{0.f, 0.f}; p23 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) {
+            const f32x2 c01 = PCRL_PAIR(a[mb], r) - mean2, c23 = PCRL_PAIR(a[mb], r + 2) - mean2;
+            a[mb][r + 0] = c01[0]; a[mb][r + 1] = c01[1]; a[mb][r + 2] = c23[0]; a[mb][r + 3] = c23[1];
+            p01 = __builtin_elementwise_fma(c01, c01, p01);
+            p23 = __builtin_elementwise_fma(c23, c23, p23);
+        }
+    }
+    both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
+    const float var = (lo + hi) / (float)C;
+    *var_is_nan = var != var;
+    return 1.0f / __builtin_sqrtf(var + eps);
+}
+
+// Per-point LayerNorm (biased variance, eps inside the sqrt, affine) + ReLU on an accumulator
+// set (LayerNormkD.forward, reference pyrl/networks/modules/nn_layer.py:207-219).
+// s_ln holds, per channel pair (2j, 2j + 1), {gamma_2j, gamma_2j+1, beta_2j, beta_2j+1} (ln_pair_table).
+// Returns true for a point whose variance is NaN (all outputs NaN).
+template <int C, bool INT_RELU>
+__device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
+    constexpr int MB = C / 32;
+    bool nan_pt;
+    const float rstd = ln_center_rstd<C>(a, eps, &nan_pt);
+    const f32x2 rstd2 = {rstd, rstd};
+    // gamma/beta of the 16 channels of a row block are fetched with 8 back-to-back 16-byte LDS reads
+    // (one wait per block, the next block's reads already in flight) instead of a read + wait per pair.
+    const f32x4* s_gb = reinterpret_cast<const f32x4*>(s_ln);
+    f32x4 gb[2][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gb[0][q] = s_gb[(acc_chan(2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        if (mb + 1 < MB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                gb[(mb + 1) & 1][q] = s_gb[(acc_chan((mb + 1) * 16 + 2 * (q & 1) + 4 * (q >> 1), 0) + 4 * half) >> 1];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            // registers r, r + 1 of the block: channel pair (r & 3) / 2 of quad r >> 2 -> gb slot q = (r >> 2) * 2 + ((r & 3) >> 1)
+            const f32x4 g4 = gb[mb & 1][(r >> 2) * 2 + ((r & 3) >> 1)];
+            const f32x2 y = __builtin_elementwise_fma(PCRL_PAIR(a[mb], r) * rstd2, __builtin_shufflevector(g4, g4, 0, 1),
+                                                      __builtin_shufflevector(g4, g4, 2, 3));
+            const float y0 = y[0], y1 = y[1];
+            if (INT_RELU) {
+                const int i0 = __builtin_bit_cast(int, y0), i1 = __builtin_bit_cast(int, y1);
+                a[mb][r] = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
+                a[mb][r + 1] = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);
+            } else {
+                a[mb][r] = relu_nan(y0);
+                a[mb][r + 1] = relu_nan(y1);
+            }
+        }
+    }
+    return nan_pt;
+}
+
+// Copy `n16` 16-byte pieces from global memory to LDS with all of a thread's loads in flight before the first LDS
+// write.  (Written as a plain strided loop over blockDim.x the compiler emits load -> wait -> write per piece: 16
+// dependent L2 round trips = 11 us for the 128 KB conv2 image.)
+template <int THREADS, int N16>
+__device__ __forceinline__ void stage_to_lds(f32x4* __restrict__ dst, const f32x4* __restrict__ src, int tid) {
+    constexpr int PER = (N16 + THREADS - 1) / THREADS;
+    f32x4 tmp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + THREADS * k < N16) tmp[k] = src[tid + THREADS * k];
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+        if (tid + THREADS * k < N16) dst[tid + THREADS * k] = tmp[k];
+}
+
+// LDS image of a LayerNorm's affine parameters for ln_relu_acc from the packed image's [C][2] = (gamma, beta) rows.
+__device__ __forceinline__ void ln_pair_table(float* s_ln, const float* packed_ln, int C, int tid, int nthreads) {
+    for (int i = tid; i < 2 * C; i += nthreads) {
+        const int c = i >> 1, which = i & 1;             // packed_ln[i] = which ? beta_c : gamma_c
+        s_ln[4 * (c >> 1) + 2 * which + (c & 1)] = packed_ln[i];
+    }
+}
+
+// Streams the A operands of one dense layer through a register ring DEPTH groups deep: group g
+// (4 k-steps of one 32-row block) is consumed while groups g+1 .. g+DEPTH are in flight, so the
+// L2 / LDS latency of an operand load is hidden behind 4*DEPTH MFMAs instead of being paid per group.
+// `load(g)` returns the f32x4 of group g, `body(g, w)` issues its 4 MFMAs.  Fully unrolled.
+template <int NG, int DEPTH, class LoadFn, class BodyFn>
+__device__ __forceinline__ void stream_operands(LoadFn load, BodyFn body) {
+    f32x4 ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < NG) ring[d] = load(d);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 w = ring[g % DEPTH];
+        if (g + DEPTH < NG) ring[g % DEPTH] = load(g + DEPTH);
+        body(g, w);
+    }
+}
+
+// One dense layer on the MFMA: acc[mb] += W[32mb.., :] . act, all MB row blocks, K = 8 * TQ channels.
+// Two row blocks are advanced together so that consecutive MFMAs never touch the same accumulator
+// (a dependent v_mfma_f32_32x32x2_f32 must otherwise issue in the exact cycle its predecessor retires;
+// any instruction slipped in between -- an operand load, a wait -- idles the matrix pipe), and the A
+// operands of pair-group g + DEPTH are in flight while group g computes.
+// load(mb, tq) -> the f32x4 holding A operands of k-steps 4tq..4tq+3 of row block mb;
+// act(t) -> the B operand (activation register) of k-step t.
+template <int MB, int TQ, int DEPTH, bool ZERO_START = true, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    static_assert(MB % 2 == 0, "row blocks are processed in pairs");
+    constexpr int NG = (MB / 2) * TQ;
+    f32x4 ra[DEPTH], rb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < NG) { ra[d] = load(2 * (d / TQ), d % TQ); rb[d] = load(2 * (d / TQ) + 1, d % TQ); }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 wa = ra[g % DEPTH], wb = rb[g % DEPTH];
+        if (g + DEPTH < NG) {
+            ra[g % DEPTH] = load(2 * ((g + DEPTH) / TQ), (g + DEPTH) % TQ);
+            rb[g % DEPTH] = load(2 * ((g + DEPTH) / TQ) + 1, (g + DEPTH) % TQ);
+        }
+        const int mb = 2 * (g / TQ), tq = g % TQ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float b = act(4 * tq + j);
+            // the first k-step takes the literal 0 as its C operand: the accumulators need no zero fill (on gfx950 a
+            // v_mov costs the same FP32 ALU cycles the MFMAs need -- tools/probes/mfma_valu_overlap.hip)
+            const bool first = ZERO_START && tq == 0 && j == 0;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, first ? zero : acc[mb], 0, 0, 0);
+            acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, first ? zero : acc[mb + 1], 0, 0, 0);
+        }
+    }
+}
+
+// Mixed-precision dense layer: acc[mb] (+)= W[32mb.., :] . act with bf16 operands on v_mfma_f32_32x32x16_bf16 and fp32
+// accumulation.  One MFMA contracts 16 input channels: the 8 accumulator registers 8g..8g+7 of BOTH wave halves, i.e.
+// channels acc_chan(8g + r, h) -- the weight image (PackedLayout::w1b/w2b) is packed in exactly that order, so the
+// activations still never leave registers: 8 fp32 registers -> 4 packed bf16 registers (v_cvt_pk_bf16_f32, RNE).
+// load(mb, g) -> 16 bytes = the 8 bf16 A operands of lane (i, h) for row block mb, channel group g; act(t) -> register t.
+template <int MB, int G, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_bf16(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    f32x4 w[2][MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) w[0][mb] = load(mb, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) w[(g + 1) & 1][mb] = load(mb, g + 1);
+        }
+        bf16x8 b;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const bf16x2 pr = __builtin_convertvector(f32x2{act(8 * g + r), act(8 * g + r + 1)}, bf16x2);
+            b[r] = pr[0]; b[r + 1] = pr[1];
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[g & 1][mb]), b, g == 0 ? zero : acc[mb], 0, 0, 0);
+    }
+}
+
+// Host side: validate the descriptors of the C ABI and flatten them into CloudParams.
+int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out);
+
+}  // namespace pcrl

@@ -1,0 +1,457 @@
+// Fused PointNet encoder forward for gfx950 (MI355X), fp32.
+//
+// Replaces, per call, the reference's op sequence
+//   PointCloudBase.preprocess (pyrl/networks/backbones/pointnet.py:49-73)
+//   [RandomJitterPoints / GlobalRotScaleTrans (pyrl/utils/augmentations/pcd_aug.py:306-327, 125-227)]
+//   ConvMLP: Conv1d(k=1)+ReLU, Conv1d+LN1d+ReLU, Conv1d+LN1d+ReLU (mlp.py:43-56, nn_layer.py:207-219)
+//   feature.max(-1) (pointnet.py:151)
+// with one kernel that never materialises a [B, c, N] activation.
+//
+// Mapping to CDNA4.  One wave owns a tile of 32 points.  Output channels are MFMA rows,
+// points are MFMA columns (v_mfma_f32_32x32x2_f32, exact f32 fma chains).  The accumulator
+// layout of a layer (lane = point, register = channel) is already the B-operand layout of
+// the next layer's k-steps, so the three layers chain in registers; only the weights
+// stream, as A operands: conv2 from LDS (128 KB image, loaded once per workgroup), conv1
+// from L1/L2 in 1 KB lane-linear pieces.  Per-point LayerNorm is an in-lane sum plus one
+// v_permlane32_swap.  The symmetric max-pool is a DPP max over the 32 lanes of a half-wave
+// followed by one ds_max_u64 on a {value bits, ~point index} key per winning lane, which
+// gives torch's first-index tie rule for free and merges the 8 waves of the workgroup.
+#include "encoder_common.h"
+
+namespace pcrl {
+
+struct FwdParams {
+    CloudParams cl;
+    int S, tiles_total, tiles_per_seg;
+    float eps;
+    const float* packed;
+    float* pooled;
+    int* argmax;
+    unsigned long long* partial;   // [B][S][C3] keys when S > 1
+};
+
+// BF16: conv1 / conv2 contract bf16 operands (weights rounded once by the pack kernel, activations rounded as they are
+// fed to the next layer) with fp32 accumulation; conv0, both LayerNorms and the max-pool are unchanged fp32 code.
+template <int T0, int C1, int C2, int C3, bool BF16>
+__global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
+    constexpr PackedLayout L{T0, C1, C2, C3};
+    constexpr int MB1 = C1 / 32, MB2 = C2 / 32, MB3 = C3 / 32;
+    // LDS image: small tables first (DS instructions carry a 16-bit offset, so everything that is
+    // addressed with per-register constants must sit below 64 KB), the 128 KB conv2 image last.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_desc + PCRL_MAX_CHANNELS);
+    float* s_ln1 = reinterpret_cast<float*>(s_keys + C3);
+    float* s_ln2 = s_ln1 + 2 * C2;
+    float* s_b0 = s_ln2 + 2 * C3;
+    float* s_w0 = s_b0 + C1;
+    float* s_w2 = s_w0 + MB1 * T0 * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+
+    {   // prologue: weights -> LDS, once per workgroup
+        const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (BF16 ? L.w2b() : L.w2()));
+        f32x4* s = reinterpret_cast<f32x4*>(s_w2);
+        constexpr int N16 = BF16 ? C3 * C2 / 8 : C3 * C2 / 4;
+        if (nthreads == 512) stage_to_lds<512, N16>(s, g, tid);
+        else for (int i = tid; i < N16; i += nthreads) s[i] = g[i];
+        for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
+        for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
+        ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
+        ln_pair_table(s_ln2, p.packed + L.ln2(), C3, tid, nthreads);
+        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
+    }
+    const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
+
+    for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
+        const int b = work / p.S, seg = work - b * p.S;
+        const int t_begin = seg * p.tiles_per_seg;
+        const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
+        __syncthreads();   // previous read-out of s_keys (and the prologue) is complete
+        // {value +0.0, point 0}: what a channel that is zero everywhere (ReLU-dead) must report, so zero maxima never
+        // have to be written by anybody
+        for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0x00000000FFFFFFFFull;
+        __syncthreads();
+
+        for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
+            const int pidx = tile * 32 + l31;
+            const bool valid = pidx < p.cl.N;
+            const int pc = valid ? pidx : p.cl.N - 1;
+
+            // ---- preprocess (+ augmentation) ---------------------------------------------
+            const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
+
+            const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
+            // ---- conv0 + bias + ReLU ------------------------------------------------------
+            f32x16 a0[MB1];
+#pragma unroll
+            for (int mb = 0; mb < MB1; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const float bop = half_select(x[2 * t], x[2 * t + 1], half_mask);
+                    a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = relu_nan(a0[mb][r]);
+            }
+
+            // ---- conv1 + LN + ReLU --------------------------------------------------------
+            f32x16 a1[MB2];
+            if (BF16)
+                dense_layer_bf16<MB2, C1 / 16>(
+                    a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB2, C1 / 8, 3>(
+                    a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                    [&](int t) { return a0[t >> 4][t & 15]; });
+            ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
+
+            // ---- conv2 + LN + ReLU --------------------------------------------------------
+            f32x16 a2[MB3];
+            if (BF16)
+                dense_layer_bf16<MB3, C2 / 16>(
+                    a2, [&](int mb, int g) { return s_w2v[(mb * (C2 / 16) + g) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB3, C2 / 8, 2>(
+                    a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            const bool nan_pt = ln_relu_acc<C3, true>(a2, s_ln2, half, p.eps);
+            if (__builtin_expect(__ballot(nan_pt) != 0ull, 0)) {
+                // torch: a NaN wins the max and the first NaN's index is returned
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (nan_pt) a2[mb][r] = u2f(0xFFFFFFFFu);
+            }
+
+            // ---- symmetric max-pool with first-index argmax --------------------------------
+            // lanes past N hold a copy of point N - 1 and report that index, so no validity test is needed below
+            const unsigned inv_idx = ~(unsigned)pc;
+            if (tile == t_begin + wave) {
+                // The wave's first tile of this cloud segment: the keys hold (almost) nothing yet, so reduce across the 32
+                // lanes first and let only the winner of each half touch the key.
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb) {
+                    // 16 independent reductions advance together: each DPP step of one register fills the
+                    // wait states of the others, and the 16 conditional key updates are issued back to back.
+                    unsigned m[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = f2u(a2[mb][r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0xB1>(m[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x4E>(m[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x141>(m[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x140>(m[r]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
+                        // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.  max(.., 1):
+                        // a zero maximum matches no lane (nobody reports it: the key's initial value already says so)
+                        m[r] = umax_(umax_(sw[0], sw[1]), 1u);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned v = f2u(a2[mb][r]);
+                        if (v == m[r]) {
+                            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                            atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                        }
+                    }
+                }
+            } else {
+                // Later tiles: a point can only matter if it reaches the value already in the channel's key (which only
+                // grows, so a stale read errs on the safe side; equality passes for the first-index rule).  That is rare
+                // -- the k-th tile of a cloud holds the running maximum with probability ~1/k -- so the cross-lane
+                // reduction is skipped and the few qualifying lanes update the key themselves: one LDS read and two
+                // compares per register instead of four DPP steps, a lane swap and three more instructions.
+                const unsigned* s_key_hi = reinterpret_cast<const unsigned*>(s_keys) + 1;
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb) {
+                    unsigned cur[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[r] = s_key_hi[2 * (acc_chan(mb * 16 + r, 0) + 4 * half)];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned v = f2u(a2[mb][r]);
+                        if (v >= umax_(cur[r], 1u)) {
+                            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                            atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C3; c += nthreads) {
+            const unsigned long long key = s_keys[c];
+            if (p.S == 1) {
+                unsigned vb = (unsigned)(key >> 32);
+                if (vb > 0x7F800000u) vb = 0x7FC00000u;
+                p.pooled[(long long)b * C3 + c] = u2f(vb);
+                p.argmax[(long long)b * C3 + c] = (int)~(unsigned)key;
+            } else {
+                p.partial[((long long)b * p.S + seg) * C3 + c] = key;
+            }
+        }
+    }
+}
+
+// Second stage of the split-cloud pool: max over the S partial keys of a cloud.
+__global__ void encoder_merge_kernel(const unsigned long long* __restrict__ partial, int B, int S, int C3,
+                                     float* __restrict__ pooled, int* __restrict__ argmax) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * C3) return;
+    const int b = (int)(i / C3), c = (int)(i - (long long)b * C3);
+    unsigned long long key = 0ull;
+    for (int s = 0; s < S; ++s) {
+        const unsigned long long k = partial[((long long)b * S + s) * C3 + c];
+        key = k > key ? k : key;
+    }
+    unsigned vb = (unsigned)(key >> 32);
+    if (vb > 0x7F800000u) vb = 0x7FC00000u;
+    pooled[i] = u2f(vb);
+    argmax[i] = (int)~(unsigned)key;
+}
+
+// Weights (reference state_dict layout) -> operand order.  One thread per packed float.
+__global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __restrict__ out) {
+    const PackedLayout L{T0, w.c1, w.c2, w.c3};
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.total()) return;
+    float v = 0.0f;
+    if (i < L.b0()) {                       // conv0: [mb][t][lane], natural k order, zero padded
+        const int e = i - L.w0(), ln = e & 63, t = (e >> 6) % T0, mb = (e >> 6) / T0;
+        const int row = 32 * mb + (ln & 31), k = 2 * t + (ln >> 5);
+        v = k < w.c_in ? w.w0[row * w.c_in + k] : 0.0f;
+    } else if (i < L.b0() + w.c1) {
+        v = w.b0[i - L.b0()];
+    } else if (i >= L.w1() && i < L.ln1()) { // conv1: [mb][tq][lane][4]
+        const int e = i - L.w1(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c1 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(4 * tq + j, ln >> 5)];
+    } else if (i >= L.ln1() && i < L.ln1() + 2 * w.c2) {
+        const int e = i - L.ln1();
+        v = (e & 1) ? w.be1[e >> 1] : w.g1[e >> 1];
+    } else if (i >= L.w2() && i < L.ln2()) { // conv2: [mb][tq][lane][4]
+        const int e = i - L.w2(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(4 * tq + j, ln >> 5)];
+    } else if (i >= L.ln2() && i < L.ln2() + 2 * w.c3) {
+        const int e = i - L.ln2();
+        v = (e & 1) ? w.be2[e >> 1] : w.g2[e >> 1];
+    } else if (i >= L.w2t() && i < L.w1t()) { // conv2 transposed (dX GEMM of the backward): rows = c2, k = c3
+        const int e = i - L.w2t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c3 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w2[acc_chan(4 * tq + j, ln >> 5) * w.c2 + 32 * mb + (ln & 31)];
+    } else if (i >= L.w1t() && i < L.w1t() + w.c1 * w.c2) { // conv1 transposed: rows = c1, k = c2
+        const int e = i - L.w1t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
+        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
+        v = w.w1[acc_chan(4 * tq + j, ln >> 5) * w.c1 + 32 * mb + (ln & 31)];
+    } else if (i >= L.w1b() && i < L.w1b() + w.c1 * w.c2 / 2) {   // conv1, bf16: [mb][g][lane][8], two elements per slot
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w1b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c1 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
+        }
+        v = u2f(bits);
+    } else if (i >= L.w2b() && i < L.w2b() + w.c2 * w.c3 / 2) {   // conv2, bf16
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w2b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c2 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
+        }
+        v = u2f(bits);
+    } else if (i >= L.w2tb() && i < L.w2tb() + w.c2 * w.c3 / 2) {  // conv2 transposed, bf16: rows = c2, k = c3
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w2tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c3 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w2[acc_chan(8 * g + r, ln >> 5) * w.c2 + 32 * mb + (ln & 31)]) << (16 * k);
+        }
+        v = u2f(bits);
+    } else if (i >= L.w1tb() && i < L.w1tb() + w.c1 * w.c2 / 2) {  // conv1 transposed, bf16: rows = c1, k = c2
+        unsigned bits = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int e = 2 * (i - L.w1tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
+            const int G = w.c2 / 16, g = q % G, mb = q / G;
+            bits |= bf16_rne_bits(w.w1[acc_chan(8 * g + r, ln >> 5) * w.c1 + 32 * mb + (ln & 31)]) << (16 * k);
+        }
+        v = u2f(bits);
+    }
+    out[i] = v;
+}
+
+int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out) {
+    if (!clouds) return fail(PCRL_E_ARG, "clouds is NULL");
+    if (clouds->B < 0 || clouds->N < 1) return fail(PCRL_E_ARG, "bad cloud shape B=%d N=%d", clouds->B, clouds->N);
+    if (clouds->nseg < 1 || clouds->nseg > PCRL_MAX_SEG) return fail(PCRL_E_ARG, "nseg=%d out of range", clouds->nseg);
+    CloudParams& p = *out;
+    p = CloudParams{};
+    p.B = clouds->B; p.N = clouds->N;
+    int c = 0;
+    for (int s = 0; s < clouds->nseg; ++s) {
+        const pcrl_feat_seg& sg = clouds->seg[s];
+        if (!sg.ptr || sg.channels < 1) return fail(PCRL_E_ARG, "segment %d is empty", s);
+        if (sg.dtype != PCRL_DT_F32 && sg.dtype != PCRL_DT_U8 && sg.dtype != PCRL_DT_BOOL) return fail(PCRL_E_ARG, "segment %d: bad dtype", s);
+        const size_t esz = sg.dtype == PCRL_DT_F32 ? 4 : 1;
+        for (int k = 0; k < sg.channels; ++k, ++c) {
+            if (c >= PCRL_MAX_CHANNELS) return fail(PCRL_E_ARG, "more than %d channels", PCRL_MAX_CHANNELS);
+            p.ch[c].base = static_cast<const char*>(sg.ptr) + esz * (size_t)k * sg.stride_c;
+            p.ch[c].stride_b = sg.stride_b; p.ch[c].stride_n = sg.stride_n;
+            p.ch[c].dtype = sg.dtype; p.ch[c].div255 = sg.div255;
+        }
+    }
+    if (c != expect_channels) return fail(PCRL_E_ARG, "clouds carry %d channels, weights expect %d", c, expect_channels);
+    p.C = c;
+    if (aug && aug->flags) {
+        if ((aug->flags & (PCRL_AUG_JITTER | PCRL_AUG_AFFINE)) && (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32))
+            return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
+        if (aug->flags & PCRL_AUG_SUBSAMPLE) {
+            if (!aug->point_index || aug->n_index < 1 || aug->n_index > clouds->N)
+                return fail(PCRL_E_ARG, "SUBSAMPLE needs point_index and 1 <= n_index <= N (got %d of %d)", aug->n_index, clouds->N);
+            p.point_index = aug->point_index;
+            p.N = aug->n_index;
+        }
+        if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
+        p.aug_flags = aug->flags; p.jitter_noise = aug->jitter_noise; p.affine = aug->affine;
+        p.row_mul = aug->row_mul ? aug->row_mul : 1; p.row_add = aug->row_add;
+        p.offset_ptr = reinterpret_cast<const unsigned long long*>(aug->offset_ptr);
+        p.jitter_lo = aug->jitter_lo; p.jitter_hi = aug->jitter_hi; p.seed = aug->seed; p.offset = aug->offset;
+    }
+    return PCRL_OK;
+}
+
+static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16) {
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 +
+           sizeof(float) * ((size_t)C3 * C2 / (bf16 ? 2 : 1) + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
+}
+
+template <int T0, int C1, int C2, int C3, bool BF16>
+static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16);
+    auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16>;
+    if (!attr_set) {
+        PCRL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    PCRL_CHECK_LAUNCH("encoder_fwd_kernel");
+    return PCRL_OK;
+}
+
+static bool dims_supported(int c1, int c2, int c3) {
+    return (c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256;
+}
+
+}  // namespace pcrl
+
+using namespace pcrl;
+
+extern "C" int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes) {
+    if (!bytes) return fail(PCRL_E_ARG, "bytes is NULL");
+    if (c_in < 1 || c_in > PCRL_MAX_CHANNELS || !dims_supported(c1, c2, c3))
+        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256])", c_in, c1, c2, c3);
+    const PackedLayout L{(c_in + 1) / 2, c1, c2, c3};
+    *bytes = sizeof(float) * (size_t)L.total();
+    return PCRL_OK;
+}
+
+static void split_plan(int B, int N, int* S, int* tiles_total, int* tiles_per_seg) {
+    const int tiles = (N + 31) / 32, cus = num_cus();
+    int s = 1;
+    if (B < cus) {
+        s = cus / B;
+        const int max_s = (tiles + 7) / 8;    // keep >= 8 tiles (one per wave) per workgroup
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+    }
+    int tps = (tiles + s - 1) / s;
+    s = (tiles + tps - 1) / tps;
+    *S = s; *tiles_total = tiles; *tiles_per_seg = tps;
+}
+
+extern "C" int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3, size_t* bytes) {
+    if (!bytes || B < 1 || N < 1 || c3 < 1) return fail(PCRL_E_ARG, "bad arguments");
+    int S, tt, tps;
+    split_plan(B, N, &S, &tt, &tps);
+    *bytes = S > 1 ? (size_t)B * S * c3 * sizeof(unsigned long long) : 0;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream) {
+    if (!w || !packed) return fail(PCRL_E_ARG, "NULL argument");
+    size_t need;
+    if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
+    if (packed_bytes < need) return fail(PCRL_E_WORKSPACE, "packed buffer %zu < %zu bytes", packed_bytes, need);
+    const int T0 = (w->c_in + 1) / 2;
+    const int total = (int)(need / sizeof(float));
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *w, T0, (float*)packed);
+    PCRL_CHECK_LAUNCH("encoder_pack_kernel");
+    return PCRL_OK;
+}
+
+static int encoder_fwd_impl(bool bf16, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                            const pcrl_encoder_weights* w, const void* packed,
+                            float* pooled, int32_t* argmax,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!clouds || !w || !packed || !pooled || !argmax) return fail(PCRL_E_ARG, "NULL argument");
+    size_t need;
+    if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
+    FwdParams p{};
+    if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
+    if (p.cl.B == 0) return PCRL_OK;
+    split_plan(p.cl.B, p.cl.N, &p.S, &p.tiles_total, &p.tiles_per_seg);
+    if (p.S > 1) {
+        const size_t ws = (size_t)p.cl.B * p.S * w->c3 * sizeof(unsigned long long);
+        if (!workspace || workspace_bytes < ws) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws);
+        p.partial = static_cast<unsigned long long*>(workspace);
+    }
+    p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.pooled = pooled; p.argmax = argmax;
+
+    const int grid = min(p.cl.B * p.S, num_cus());
+    const int T0 = (p.cl.C + 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = PCRL_E_ARG;
+#define PCRL_FWD_CASE(T0_, C1_)                                                   \
+    if (T0 == T0_ && w->c1 == C1_) rc = bf16 ? launch_fwd<T0_, C1_, 128, 256, true>(p, grid, st) : launch_fwd<T0_, C1_, 128, 256, false>(p, grid, st);
+    PCRL_FWD_CASE(2, 64) PCRL_FWD_CASE(3, 64) PCRL_FWD_CASE(4, 64) PCRL_FWD_CASE(5, 64)
+    PCRL_FWD_CASE(2, 128) PCRL_FWD_CASE(3, 128) PCRL_FWD_CASE(4, 128) PCRL_FWD_CASE(5, 128)
+#undef PCRL_FWD_CASE
+    if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
+    if (rc) return rc;
+    if (p.S > 1) {
+        const long long n = (long long)p.cl.B * w->c3;
+        hipLaunchKernelGGL(encoder_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                           p.partial, p.cl.B, p.S, w->c3, pooled, argmax);
+        PCRL_CHECK_LAUNCH("encoder_merge_kernel");
+    }
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                    const pcrl_encoder_weights* w, const void* packed,
+                                    float* pooled, int32_t* argmax,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(false, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcrl_encoder_fwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                     const pcrl_encoder_weights* w, const void* packed,
+                                     float* pooled, int32_t* argmax,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_fwd_impl(true, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
+}

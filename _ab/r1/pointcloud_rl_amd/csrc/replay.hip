@@ -1,0 +1,82 @@
+// Device-resident replay sampling for gfx950: one launch gathers the sampled rows of every stored key
+// (obs/xyz, obs/rgb, next_obs/..., actions, rewards, dones, ...) into the persistent staging batch the
+// captured update step reads.  Replaces ReplayMemory.sample's numpy `take` per key plus the pageable
+// host->device copy of 2*B clouds per step (pyrl/env/replay_buffer.py:297-322; pyrl/utils/data/
+// dict_array.py:308-318; sac.py:104).  HBM-bound: row_bytes read + row_bytes written per sampled row.
+#include "common.h"
+
+namespace pcrl {
+
+constexpr int kMaxGatherSegs = 24;
+struct GatherParams {
+    const unsigned char* src[kMaxGatherSegs];
+    unsigned char* dst[kMaxGatherSegs];
+    long long row_bytes[kMaxGatherSegs];
+    const int* idx; int B; long long capacity;
+    // idx == NULL: row b is drawn in the kernel, uniform on [0, size), Philox4x32-10 keyed by seed, counter (b, draw)
+    int* idx_out; unsigned size, seed_lo, seed_hi, draw_lo, draw_hi;
+};
+
+__global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p) {
+    const int b = blockIdx.x, seg = blockIdx.y;
+    long long row;
+    if (p.idx) {
+        row = p.idx[b];
+    } else {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)b, p.draw_lo, p.draw_hi, 0x52455055u, p.seed_lo, p.seed_hi, w);
+        row = (long long)(((unsigned long long)w[0] * p.size) >> 32);       // multiply-shift: bias < size / 2^32
+        if (seg == 0 && threadIdx.x == 0 && p.idx_out) p.idx_out[b] = (int)row;
+    }
+    row = row < 0 ? 0 : (row >= p.capacity ? p.capacity - 1 : row);       // never read outside the ring
+    const long long nbytes = p.row_bytes[seg];
+    const unsigned char* src = p.src[seg] + row * nbytes;
+    unsigned char* dst = p.dst[seg] + (long long)b * nbytes;
+    if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)nbytes) & 15) == 0) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (long long i = threadIdx.x; i < nbytes / 16; i += blockDim.x) d4[i] = s4[i];
+    } else if ((((uintptr_t)src | (uintptr_t)dst | (uintptr_t)nbytes) & 3) == 0) {
+        const unsigned* s1 = reinterpret_cast<const unsigned*>(src);
+        unsigned* d1 = reinterpret_cast<unsigned*>(dst);
+        for (long long i = threadIdx.x; i < nbytes / 4; i += blockDim.x) d1[i] = s1[i];
+    } else {
+        for (long long i = threadIdx.x; i < nbytes; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+}  // namespace pcrl
+
+using namespace pcrl;
+
+static int gather_launch(const pcrl_gather_seg* segs, int32_t n_segs, GatherParams& p, void* stream) {
+    if (!segs) return fail(PCRL_E_ARG, "NULL argument");
+    if (n_segs < 0 || n_segs > kMaxGatherSegs) return fail(PCRL_E_ARG, "replay gather: at most %d keys per launch", kMaxGatherSegs);
+    if (p.B < 0 || p.capacity < 1) return fail(PCRL_E_ARG, "bad batch / capacity");
+    if (p.B == 0 || n_segs == 0) return PCRL_OK;
+    for (int i = 0; i < n_segs; ++i) {
+        if (!segs[i].src || !segs[i].dst || segs[i].row_bytes < 1) return fail(PCRL_E_ARG, "bad gather segment %d", i);
+        p.src[i] = static_cast<const unsigned char*>(segs[i].src);
+        p.dst[i] = static_cast<unsigned char*>(segs[i].dst);
+        p.row_bytes[i] = segs[i].row_bytes;
+    }
+    hipLaunchKernelGGL(replay_gather_kernel, dim3(p.B, n_segs), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("replay_gather_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t size, int64_t capacity,
+                                         uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream) {
+    if (size < 1 || size > capacity || size > 0xFFFFFFFFll) return fail(PCRL_E_ARG, "replay sample: 1 <= size <= capacity");
+    GatherParams p{};
+    p.idx = nullptr; p.B = B; p.capacity = capacity; p.idx_out = idx_out; p.size = (unsigned)size;
+    p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.draw_lo = (unsigned)draw; p.draw_hi = (unsigned)(draw >> 32);
+    return gather_launch(segs, n_segs, p, stream);
+}
+
+extern "C" int pcrl_replay_gather(const pcrl_gather_seg* segs, int32_t n_segs, const int32_t* idx, int32_t B, int64_t capacity, void* stream) {
+    if (!idx) return fail(PCRL_E_ARG, "NULL argument");
+    GatherParams p{};
+    p.idx = idx; p.B = B; p.capacity = capacity;
+    return gather_launch(segs, n_segs, p, stream);
+}

@@ -1,0 +1,415 @@
+"""Host-side launchers: torch CUDA tensors -> raw pointers -> C ABI (include/pcrl.h).
+
+PyTorch is used for device memory and the current HIP stream only; every computation here is a
+call into libpcrl_hip.so.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from ._lib import AugDesc, CloudDesc, EncoderWeights, FeatSeg, GemmDesc, check, lib
+
+_DT = {torch.float32: _lib.DT_F32, torch.uint8: _lib.DT_U8, torch.bool: _lib.DT_BOOL}
+
+
+class KernelTimer:
+    """Optional HIP-event timing of every C-ABI launch (bench.py's roofline figures).  Events are
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def span(self, name):
+        return _Span(self, name)
+
+    def summary(self):
+        """name -> (launches, mean ms); call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.spans.items() if v}
+
+
+class _Span:
+    def __init__(self, timer, name):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.start.record()
+
+    def __exit__(self, *exc):
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.timer.spans.setdefault(self.name, []).append((self.start, end))
+
+
+class _NoSpan:
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *exc):
+        pass
+
+
+TIMER = None          # set to a KernelTimer() to time launches
+
+
+def _span(name):
+    return TIMER.span(name) if TIMER is not None else _NoSpan()
+
+
+def raw_stream():
+    """hipStream_t of torch's current stream as an int (the C calls skip the torch.cuda.Stream object: ~8 us -> < 1 us)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _stream():
+    return ctypes.c_void_p(raw_stream())
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def make_cloud_desc(obs):
+    """Describe the observation dict PointCloudBase.preprocess consumes (reference
+    pyrl/networks/backbones/pointnet.py:49-73): keys xyz [B,3,N] f32, rgb [B,3,N] u8|f32,
+    pos_encoding [B,F,N], seg [B,K,N]; or a bare xyz tensor.  Returns (desc, tensors kept alive)."""
+    if torch.is_tensor(obs):
+        obs = {"xyz": obs}
+    keep, segs = [], []
+    xyz = obs["xyz"]
+    if not xyz.is_cuda:
+        raise RuntimeError(f"point clouds must live on the MI355X (got device {xyz.device}); pointcloud_rl_amd has no CPU encoder")
+    assert xyz.ndim == 3, f"xyz must be a [B,C,N] tensor, got {tuple(xyz.shape)}"
+    B, _, N = xyz.shape
+    for key in ("xyz", "rgb", "pos_encoding", "seg"):
+        if key not in obs:
+            continue
+        t = obs[key]
+        assert t.is_cuda and t.ndim == 3 and t.shape[0] == B and t.shape[2] == N, f"{key}: bad shape {tuple(t.shape)}"
+        if t.dtype not in _DT:
+            t = t.to(torch.float32)
+        div255 = 1 if (key == "rgb" and t.dtype == torch.uint8) else 0
+        s = FeatSeg(ptr=t.data_ptr(), dtype=_DT[t.dtype], channels=t.shape[1], div255=div255,
+                    stride_b=t.stride(0), stride_c=t.stride(1), stride_n=t.stride(2))
+        segs.append(s)
+        keep.append(t)
+    desc = CloudDesc(B=B, N=N, nseg=len(segs))
+    for i, s in enumerate(segs):
+        desc.seg[i] = s
+    return desc, keep
+
+
+def make_interleaved_desc(points):
+    """[B, N, C] f32 point tensor (the synthetic benchmark layout of BASELINE.json)."""
+    assert points.is_cuda and points.ndim == 3 and points.dtype == torch.float32
+    B, N, C = points.shape
+    desc = CloudDesc(B=B, N=N, nseg=1)
+    desc.seg[0] = FeatSeg(ptr=points.data_ptr(), dtype=_lib.DT_F32, channels=C, div255=0,
+                          stride_b=points.stride(0), stride_c=points.stride(2), stride_n=points.stride(1))
+    return desc, [points]
+
+
+def make_encoder_weights(w0, b0, w1, g1, be1, w2, g2, be2, eps):
+    ts = [w0, b0, w1, g1, be1, w2, g2, be2]
+    for t in ts:
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    c1, c_in = w0.shape[0], w0.shape[1]
+    c2, c3 = w1.shape[0], w2.shape[0]
+    ew = EncoderWeights(c_in=c_in, c1=c1, c2=c2, c3=c3, eps=eps,
+                        w0=w0.data_ptr(), b0=b0.data_ptr(), w1=w1.data_ptr(), g1=g1.data_ptr(), be1=be1.data_ptr(),
+                        w2=w2.data_ptr(), g2=g2.data_ptr(), be2=be2.data_ptr())
+    return ew, ts
+
+
+def encoder_packed_bytes(c_in, c1, c2, c3):
+    n = ctypes.c_size_t()
+    check(lib().pcrl_encoder_packed_bytes(c_in, c1, c2, c3, ctypes.byref(n)))
+    return n.value
+
+
+def encoder_pack_weights(ew, packed):
+    check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
+
+
+def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None,
+                  point_index=None):
+    flags = 0
+    aug = AugDesc()
+    aug.row_mul, aug.row_add = int(row_mul), int(row_add)
+    if jitter_noise is not None or jitter_range is not None:
+        flags |= _lib.AUG_JITTER
+        aug.jitter_noise = jitter_noise.data_ptr() if jitter_noise is not None else None
+        if jitter_range is not None:
+            aug.jitter_lo, aug.jitter_hi = float(jitter_range[0]), float(jitter_range[1])
+        aug.seed, aug.offset = int(seed), int(offset)
+        if offset_tensor is not None:
+            assert offset_tensor.dtype == torch.int64 and offset_tensor.is_cuda
+            aug.offset_ptr = offset_tensor.data_ptr()
+    if affine is not None:
+        flags |= _lib.AUG_AFFINE
+        aug.affine = affine.data_ptr()
+    if point_index is not None:
+        assert point_index.dtype == torch.int32 and point_index.is_cuda and point_index.is_contiguous() and point_index.ndim == 1
+        flags |= _lib.AUG_SUBSAMPLE
+        aug.point_index, aug.n_index = point_index.data_ptr(), point_index.numel()
+    aug.flags = flags
+    return aug
+
+
+def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False):
+    """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device).  bf16=True: conv1 / conv2 on
+    the bf16 matrix cores with fp32 accumulation (pcrl_encoder_fwd_bf16)."""
+    B, c3 = desc.B, ew.c3
+    dev = packed.device
+    pooled = torch.empty((B, c3), dtype=torch.float32, device=dev)
+    argmax = torch.empty((B, c3), dtype=torch.int32, device=dev)
+    need = ctypes.c_size_t()
+    if B > 0:
+        check(lib().pcrl_encoder_fwd_workspace_bytes(B, desc.N, c3, ctypes.byref(need)))
+    if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
+        workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
+    with _span("encoder_fwd"):
+        fn = lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
+        check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
+                                         ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
+                                         _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
+    return pooled, argmax
+
+
+def encoder_num_grads(ew):
+    n = ctypes.c_size_t()
+    check(lib().pcrl_encoder_num_grads(ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(n)))
+    return n.value
+
+
+def encoder_grad_views(flat, ew):
+    """Split the flat gradient into the reference's parameter order/shapes (conv weights as [out,in,1])."""
+    C, c1, c2, c3 = ew.c_in, ew.c1, ew.c2, ew.c3
+    sizes = [("conv0.weight", (c1, C, 1)), ("conv0.bias", (c1,)), ("conv1.weight", (c2, c1, 1)), ("norm1.weight", (c2,)),
+             ("norm1.bias", (c2,)), ("conv2.weight", (c3, c2, 1)), ("norm2.weight", (c3,)), ("norm2.bias", (c3,))]
+    out, o = {}, 0
+    for name, shape in sizes:
+        n = 1
+        for d in shape:
+            n *= d
+        out[name] = flat[o:o + n].view(shape)
+        o += n
+    assert o == flat.numel()
+    return out
+
+
+def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None, want_n_active=False, out=None, bf16=False, pooled=None):
+    """Flat encoder gradient [pcrl_encoder_num_grads] for d(loss)/d(pooled) = grad_pooled [B,c3]
+    (written into `out` when given: a slice of an optimizer's flat gradient buffer)."""
+    dev = packed.device
+    assert argmax.dtype == torch.int32 and argmax.is_contiguous() and grad_pooled.dtype == torch.float32
+    grad_pooled = grad_pooled.contiguous()
+    grads = out if out is not None else torch.empty(encoder_num_grads(ew), dtype=torch.float32, device=dev)
+    assert grads.numel() == encoder_num_grads(ew) and grads.is_contiguous()
+    need = ctypes.c_size_t()
+    check(lib().pcrl_encoder_bwd_workspace_bytes(desc.B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
+    if workspace is None or workspace.numel() * workspace.element_size() < need.value:
+        workspace = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)
+    n_active = torch.empty(desc.B, dtype=torch.int32, device=dev) if want_n_active else None
+    with _span("encoder_bwd"):
+        fn = lib().pcrl_encoder_bwd_bf16 if bf16 else lib().pcrl_encoder_bwd_f32
+        check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
+                                         _ptr(packed), _ptr(argmax), _ptr(grad_pooled), _ptr(pooled), _ptr(grads), _ptr(n_active),
+                                         _ptr(workspace), ctypes.c_size_t(workspace.numel()), _stream()))
+    return (grads, n_active) if want_n_active else grads
+
+
+def adam_workspace_bytes(n):
+    need = ctypes.c_size_t()
+    check(lib().pcrl_adam_workspace_bytes(ctypes.c_size_t(n), ctypes.byref(need)))
+    return need.value
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, workspace,
+              target=None, target_begin=0, target_end=0, tau=0.0, defer=False):
+    """defer=True: returns an AdamPending that must be passed to gather_scalars(..., pending=[...]) later in the step (it sums
+    the gradient norm and advances the step count); otherwise a second launch does that right away and None is returned."""
+    pending = _lib.AdamPending() if defer else None
+    with _span("adam_step"):
+        check(lib().pcrl_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
+                                       ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                       ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(grad_norm_out),
+                                       _ptr(target), ctypes.c_size_t(target_begin), ctypes.c_size_t(target_end), ctypes.c_float(tau),
+                                       _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()),
+                                       ctypes.byref(pending) if defer else None, _stream()))
+    return pending
+
+
+def polyak(target, src, tau):
+    check(lib().pcrl_polyak_f32(_ptr(target), _ptr(src), ctypes.c_size_t(target.numel()), ctypes.c_float(tau), _stream()))
+
+
+# ---- dense heads ---------------------------------------------------------------------------------
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+_SPAN_SHAPES = bool(os.environ.get("PCRL_SPAN_SHAPES"))
+
+
+def gemm_desc(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,
+              batch=1, batch_strides=(0, 0, 0, 0, 0), c_ones=None, c_ones_batch_stride=0):
+    """Descriptor of C[z] = epilogue(A[z] . B[z]); strides in elements; batch_strides = (A, B, C, bias, mask).  See include/pcrl.h."""
+    return GemmDesc(A=A.data_ptr(), B=B.data_ptr(), C=C.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                    mask=mask.data_ptr() if mask is not None else None, M=M, N=N, K=K, batch=batch,
+                    a_stride_m=a_strides[0], a_stride_k=a_strides[1], b_stride_k=b_strides[0], b_stride_n=b_strides[1], ldc=ldc, ld_mask=ld_mask,
+                    a_batch_stride=batch_strides[0], b_batch_stride=batch_strides[1], c_batch_stride=batch_strides[2],
+                    bias_batch_stride=batch_strides[3], mask_batch_stride=batch_strides[4],
+                    relu=int(relu), ones_col=ones_col, accumulate=int(accumulate),
+                    C_ones=c_ones.data_ptr() if c_ones is not None else None, c_ones_batch_stride=c_ones_batch_stride)
+
+
+def gemm_group(descs):
+    """Launch up to 4 independent GEMMs (gemm_desc results; None entries are skipped) as one kernel."""
+    descs = [d for d in descs if d is not None]
+    if not descs:
+        return
+    arr = (GemmDesc * len(descs))(*descs)
+    name = "gemm " + " | ".join(f"M{d.M} N{d.N} K{d.K} b{d.batch}" for d in descs) if _SPAN_SHAPES else "gemm"
+    with _span(name):
+        check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
+
+
+def gemm(*args, **kwargs):
+    """One GEMM launch; arguments as gemm_desc."""
+    gemm_group([gemm_desc(*args, **kwargs)])
+
+
+def layernorm_rows_fwd(x, ldx, gamma, beta, M, F, eps, dsts, xhat=None, rstd=None):
+    """dsts: list of (tensor, column offset, leading dimension)."""
+    n = len(dsts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() + 4 * off for t, off, _ in dsts])
+    lds = (ctypes.c_int64 * n)(*[ld for _, _, ld in dsts])
+    check(lib().pcrl_layernorm_rows_fwd_f32(_ptr(x), ctypes.c_int64(ldx), _ptr(gamma), _ptr(beta), M, F, _f(eps), ptrs, lds, n,
+                                            _ptr(xhat), _ptr(rstd), _stream()))
+
+
+def layernorm_rows_fwd_multi(jobs, gamma, beta, F, eps):
+    """jobs: [dict(x=, ldx=, M=, dsts=[(tensor, column offset, leading dim)], xhat=None, rstd=None,
+    cats=[(src tensor [M, n] (row stride src.stride(0)), dst tensor, dst column offset, dst leading dim)])], one launch."""
+    arr = (_lib.LnJob * len(jobs))()
+    for j, job in zip(arr, jobs):
+        j.x, j.ldx, j.M, j.n_dst = job["x"].data_ptr(), job["ldx"], job["M"], len(job["dsts"])
+        for i, (t, off, ld) in enumerate(job["dsts"]):
+            j.dst[i], j.ld_dst[i] = t.data_ptr() + 4 * off, ld
+        j.xhat = job["xhat"].data_ptr() if job.get("xhat") is not None else None
+        j.rstd = job["rstd"].data_ptr() if job.get("rstd") is not None else None
+        for c, (src, dst, off, ld) in enumerate(job.get("cats", [])):
+            assert src.dtype == torch.float32 and src.stride(-1) == 1
+            j.cat_src[c], j.cat_dst[c], j.cat_ld_src[c], j.cat_ld_dst[c], j.cat_n[c] = src.data_ptr(), dst.data_ptr() + 4 * off, src.stride(0), ld, src.shape[1]
+    check(lib().pcrl_layernorm_rows_fwd_multi_f32(arr, len(jobs), _ptr(gamma), _ptr(beta), F, _f(eps), _stream()))
+
+
+def layernorm_rows_bwd(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, dgamma, dbeta, workspace, accumulate=False):
+    check(lib().pcrl_layernorm_rows_bwd_f32(ctypes.c_void_p(dy0), ctypes.c_void_p(dy1) if dy1 else None, ctypes.c_int64(lddy), _ptr(xhat), _ptr(rstd),
+                                            _ptr(gamma), M, F, _ptr(dx), ctypes.c_int64(lddx), _ptr(dgamma), _ptr(dbeta), int(accumulate),
+                                            _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
+
+
+def tanh_gaussian_fwd(feat, ld_feat, eps, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action, neg_logp, saved=None,
+                      action2_ptr=None, ld_action2=0):
+    check(lib().pcrl_tanh_gaussian_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
+                                           _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
+                                           ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
+                                           _ptr(neg_logp), _ptr(saved), _stream()))
+
+
+def tanh_gaussian_sample_fwd(feat, ld_feat, seed, step_counter, draw_id, eps_out, scale, bias, B, A, ls_min, ls_max, epsilon, action, ld_action,
+                             neg_logp, saved=None, action2_ptr=None, ld_action2=0):
+    """tanh_gaussian_fwd with in-kernel Philox draws (written to eps_out); step_counter: device int32 tensor."""
+    check(lib().pcrl_tanh_gaussian_sample_fwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(step_counter),
+                                                  int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), B, A, _f(ls_min), _f(ls_max),
+                                                  _f(epsilon), _ptr(action), ctypes.c_int64(ld_action),
+                                                  ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
+                                                  _ptr(neg_logp), _ptr(saved), _stream()))
+
+
+def tanh_gaussian_bwd(feat, ld_feat, eps, saved, scale, B, A, ls_min, ls_max, epsilon, da0_ptr, da1_ptr, ld_da, d_neglogp, d_feat, ld_d_feat):
+    check(lib().pcrl_tanh_gaussian_bwd_f32(_ptr(feat), ctypes.c_int64(ld_feat), _ptr(eps), _ptr(saved), _ptr(scale), B, A, _f(ls_min), _f(ls_max),
+                                           _f(epsilon), ctypes.c_void_p(da0_ptr), ctypes.c_void_p(da1_ptr) if da1_ptr else None,
+                                           ctypes.c_int64(ld_da), _ptr(d_neglogp), _ptr(d_feat), ctypes.c_int64(ld_d_feat), _stream()))
+
+
+def sac_critic_loss(q_next, ld_qn, neg_logp_next, rewards, dones_u8, log_alpha, gamma, reward_scale, ignore_dones, group, q, ld_q, B, H,
+                    q_target, dq, ld_dq, stats):
+    check(lib().pcrl_sac_critic_loss_f32(_ptr(q_next), ctypes.c_int64(ld_qn), _ptr(neg_logp_next), _ptr(rewards), _ptr(dones_u8), _ptr(log_alpha),
+                                         _f(gamma), _f(reward_scale), int(ignore_dones), int(group), _ptr(q), ctypes.c_int64(ld_q), B, H,
+                                         _ptr(q_target), _ptr(dq), ctypes.c_int64(ld_dq), _ptr(stats), _stream()))
+
+
+def sac_actor_loss(q_pi, ld_q, neg_logp, log_alpha, target_entropy, B, H, dq, ld_dq, d_neglogp, alpha_grad, stats):
+    check(lib().pcrl_sac_actor_loss_f32(_ptr(q_pi), ctypes.c_int64(ld_q), _ptr(neg_logp), _ptr(log_alpha), _f(target_entropy), B, H,
+                                        _ptr(dq), ctypes.c_int64(ld_dq), _ptr(d_neglogp), _ptr(alpha_grad), _ptr(stats), _stream()))
+
+
+def gather_segments(pairs):
+    """ctypes segment table for replay_gather / replay_sample_gather (build once, reuse every step):
+    pairs = [(storage [capacity, ...], staging [B, ...])] contiguous tensors of equal row size."""
+    n = len(pairs)
+    segs = (_lib.GatherSeg * n)()
+    for i, (src, dst) in enumerate(pairs):
+        row = src[0].numel() * src.element_size()
+        assert src.is_contiguous() and dst.is_contiguous() and dst[0].numel() * dst.element_size() == row
+        segs[i].src, segs[i].dst, segs[i].row_bytes = src.data_ptr(), dst.data_ptr(), row
+    return segs
+
+
+def replay_gather(segs, idx, capacity):
+    """staging[b] = storage[idx[b]] for every key; idx int32 [B] on the device."""
+    with _span("replay_gather"):
+        check(lib().pcrl_replay_gather(segs, len(segs), _ptr(idx), idx.numel(), ctypes.c_int64(capacity), _stream()))
+
+
+def replay_sample_gather(segs, B, size, capacity, seed, draw, idx_out=None):
+    """Rows drawn in the kernel (uniform on [0, size), Philox keyed by seed / draw); idx_out int32 [B] receives them."""
+    with _span("replay_gather"):
+        check(lib().pcrl_replay_sample_gather(segs, len(segs), B, ctypes.c_int64(size), ctypes.c_int64(capacity),
+                                              ctypes.c_uint64(seed & (2 ** 64 - 1)), ctypes.c_uint64(draw), _ptr(idx_out), _stream()))
+
+
+def gather_scalars(entries, pending=()):
+    """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars;
+    pending: AdamPending objects of deferred adam_step calls, finished by the same launch before the copies."""
+    n = len(entries)
+    pend = (_lib.AdamPending * max(len(pending), 1))(*pending)
+    src = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
+    dst = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries])
+    flags = (ctypes.c_int32 * n)(*[int(bool(e[2])) for e in entries])
+    check(lib().pcrl_gather_scalars_f32(src, dst, flags, n, pend, len(pending), _stream()))
+
+
+# ---- stand-alone memory-shaped kernels --------------------------------------------------------------
+def segmax_fwd(x):
+    """x [..., N] f32 contiguous -> (max [...], argmax [...] int32), torch.max(dim=-1) semantics."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+    N, rows = x.shape[-1], x.numel() // x.shape[-1]
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    idx = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+    with _span("segmax_fwd"):
+        check(lib().pcrl_segmax_fwd_f32(_ptr(x), ctypes.c_int64(rows), N, _ptr(out), _ptr(idx), _stream()))
+    return out, idx
+
+
+def segmax_bwd(grad_out, idx, N):
+    grad_out = grad_out.contiguous()
+    dx = torch.empty(tuple(idx.shape) + (N,), dtype=torch.float32, device=idx.device)
+    with _span("segmax_bwd"):
+        check(lib().pcrl_segmax_bwd_f32(_ptr(grad_out), _ptr(idx), ctypes.c_int64(idx.numel()), N, _ptr(dx), _stream()))
+    return dx
+
+
+def augment_xyz(xyz, out=None, **aug):
+    """Materialised RandomJitterPoints / GlobalRotScaleTrans on xyz [B,3,N] (same keywords as make_aug_desc)."""
+    assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous() and xyz.shape[1] == 3
+    out = torch.empty_like(xyz) if out is None else out
+    desc = make_aug_desc(**aug)
+    with _span("augment_xyz"):
+        check(lib().pcrl_augment_xyz_f32(_ptr(xyz), _ptr(out), xyz.shape[0], xyz.shape[2], ctypes.byref(desc), _stream()))
+    return out

@@ -1,0 +1,321 @@
+"""Autograd-free execution of the SAC / DrQ update step on libpcrl_hip.so.
+
+Used by SAC/DrQ when the agent has the topology of every shipped point-cloud config (one PointNet
+shared by the actor, both Q heads and both target Q heads; 3-layer LinearMLP heads without norm;
+TanhGaussianHead; detach_actor_feature=True; plain Adam).  The step is then a fixed sequence of
+~55 launches: fused encoder forward/backward, batched fp32 MFMA GEMMs for the heads (both Q heads in
+one launch), fused squashed-Gaussian / TD-target / loss kernels and fused Adam+Polyak -- versus
+~800 ATen launches for the same step through autograd.  Semantics (reference sac.py:103-214,
+drq.py:46-165) are unchanged and checked against golden vectors in tests/test_update_step_gpu.py.
+"""
+import torch
+import torch.nn as nn
+
+from .. import hip
+from ..networks.mlp import LinearMLP
+from ..networks.heads import TanhGaussianHead
+from ..networks.pointnet import PointNet
+
+
+class PackedStats(dict):
+    """name -> device scalar (views into `packed`, one contiguous float32 tensor in the same order)."""
+    packed = None
+
+
+def ceil4(x):
+    return (x + 3) & ~3
+
+
+class MlpView:
+    """Three Linear layers of a LinearMLP located inside a flat parameter buffer (data and grad)."""
+
+    def __init__(self, flat, prefix, head_stride=0, nb=1):
+        self.flat, self.nb, self.hs = flat, nb, head_stride
+        self.off = dict(zip(flat.names, flat.offsets))
+        self.dims = []
+        for i in range(3):
+            w = flat.params[flat.names.index(f"{prefix}linear{i}.weight")]
+            self.dims.append((w.shape[1], w.shape[0]))      # (in, out)
+        self.w = [self.off[f"{prefix}linear{i}.weight"] for i in range(3)]
+        self.b = [self.off[f"{prefix}linear{i}.bias"] for i in range(3)]
+
+    def W(self, i, buf=None, base=0):
+        return (buf if buf is not None else self.flat.data)[base + self.w[i]:]
+
+    def Bv(self, i, buf=None, base=0):
+        return (buf if buf is not None else self.flat.data)[base + self.b[i]:]
+
+
+def mlp_forward_descs(mv, params, base, X, ldx, M, outs, ld_out2, out2, out2_bs, x_bs=0):
+    """GEMM descriptors, one per layer, of h1 = relu(X W0^T + b0), h2 = relu(h1 W1^T + b1), out = h2 W2^T + b2,
+    batched over mv.nb heads.  outs = (h1, h2) buffers [nb][M][H]; out2 written with leading dim ld_out2 and batch
+    stride out2_bs."""
+    (k0, h), (_, _), (_, n2) = mv.dims
+    nb, hs = mv.nb, mv.hs
+    h1, h2 = outs
+    return [hip.gemm_desc(X, mv.W(0, params, base), h1, M, h, k0, (ldx, 1), (1, k0), h, bias=mv.Bv(0, params, base), relu=True,
+                          batch=nb, batch_strides=(x_bs, hs, M * h, hs, 0)),
+            hip.gemm_desc(h1, mv.W(1, params, base), h2, M, h, h, (h, 1), (1, h), h, bias=mv.Bv(1, params, base), relu=True,
+                          batch=nb, batch_strides=(M * h, hs, M * h, hs, 0)),
+            hip.gemm_desc(h2, mv.W(2, params, base), out2, M, n2, h, (h, 1), (1, h), ld_out2, bias=mv.Bv(2, params, base),
+                          batch=nb, batch_strides=(M * h, hs, out2_bs, hs, 0))]
+
+
+def launch_layers(*mlps):
+    """Layer l of every given MLP (independent of each other) goes into one grouped launch."""
+    for layer in zip(*mlps):
+        hip.gemm_group([d for group in layer for d in (group if isinstance(group, (list, tuple)) else [group])])
+
+
+def mlp_forward(*args, **kwargs):
+    launch_layers(mlp_forward_descs(*args, **kwargs))
+
+
+def mlp_backward_descs(mv, X, ldx, M, h1, h2, dout, dout_strides, dout_bs, dh1, dh2, grad=None, dX=None, dx_cols=None, ld_dx=0, x_bs=0):
+    """Backward of mlp_forward as three stages of independent GEMMs [(dW2|db2, dh2), (dW1|db1, dh1), (dW0|db0, dX)].
+    dout[z][m][n] at dout + z*dout_bs + m*dout_strides[0] + n*dout_strides[1].
+    grad: flat gradient buffer receiving dW|db of every layer (None: data gradients only).
+    dX: receives dh1 @ W0[:, c0:c0+nc] for dx_cols = (c0, nc), shape [nb][M][ld_dx]."""
+    (k0, h), (_, _), (_, n2) = mv.dims
+    nb, hs = mv.nb, mv.hs
+    sm, sn = dout_strides
+    stages = [[], [], []]
+    if grad is not None:
+        stages[0].append(hip.gemm_desc(dout, h2, grad[mv.w[2]:], n2, h + 1, M, (sn, sm), (h, 1), h, ones_col=h, c_ones=grad[mv.b[2]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(dout_bs, M * h, hs, 0, 0)))
+    stages[0].append(hip.gemm_desc(dout, mv.W(2), dh2, M, h, n2, (sm, sn), (h, 1), h, mask=h2, ld_mask=h, batch=nb,
+                                   batch_strides=(dout_bs, hs, M * h, 0, M * h)))
+    if grad is not None:
+        stages[1].append(hip.gemm_desc(dh2, h1, grad[mv.w[1]:], h, h + 1, M, (1, h), (h, 1), h, ones_col=h, c_ones=grad[mv.b[1]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(M * h, M * h, hs, 0, 0)))
+    stages[1].append(hip.gemm_desc(dh2, mv.W(1), dh1, M, h, h, (h, 1), (h, 1), h, mask=h1, ld_mask=h, batch=nb,
+                                   batch_strides=(M * h, hs, M * h, 0, M * h)))
+    if grad is not None:
+        stages[2].append(hip.gemm_desc(dh1, X, grad[mv.w[0]:], h, k0 + 1, M, (1, h), (ldx, 1), k0, ones_col=k0, c_ones=grad[mv.b[0]:],
+                                       c_ones_batch_stride=hs, batch=nb, batch_strides=(M * h, x_bs, hs, 0, 0)))
+    if dX is not None:
+        c0, nc = dx_cols
+        stages[2].append(hip.gemm_desc(dh1, mv.W(0)[c0:], dX, M, nc, h, (h, 1), (k0, 1), ld_dx, batch=nb,
+                                       batch_strides=(M * h, hs, M * ld_dx, 0, 0)))
+    return stages
+
+
+def mlp_backward(*args, **kwargs):
+    launch_layers(mlp_backward_descs(*args, **kwargs))
+
+
+class FusedStep:
+    """Buffers + launch sequence of one update step for a fixed (rows, actor rows) geometry."""
+
+    @staticmethod
+    def supported(agent):
+        from .sac import HipAdam
+        enc = agent.encoder
+        if not isinstance(enc, PointNet) or enc.final_mlp is None or not agent._dedup or not agent.detach_actor_feature:
+            return False
+        if not all(isinstance(getattr(agent, f"{n}_optim"), HipAdam) for n in ("critic", "actor", "alpha")):
+            return False
+        if not agent.automatic_alpha_tuning or agent._target_flat is None or len(agent.critic.values) != 2:
+            return False
+        mlps = [agent.actor.backbone.final_mlp] + [v.backbone.final_mlp for v in agent.critic.values]
+        if not all(isinstance(m, LinearMLP) and len(m.linears) == 3 and all(l.bias is not None for l in m.linears) for m in mlps):
+            return False
+        if not isinstance(agent.actor.head, TanhGaussianHead) or agent.actor.final_mlp is not None:
+            return False
+        if any(v.final_mlp is not None or v.head is not None for v in agent.critic.values):
+            return False
+        return agent.actor.backbone.ac_feat is None and agent.actor.backbone.obs_feat is None
+
+    def __init__(self, agent):
+        self.a = agent
+        enc = agent.encoder
+        self.F = enc.final_mlp[0].out_features
+        self.c3 = enc.mlp_spec[-1]
+        fc, fa = agent._flat["critic"], agent._flat["actor"]
+        off = dict(zip(fc.names, fc.offsets))
+        self.off = off
+        self.n_conv = off["values.0.backbone.visual_nn.final_mlp.0.weight"]
+        q0, q1 = "values.0.backbone.final_mlp.mlp.", "values.1.backbone.final_mlp.mlp."
+        self.q = MlpView(fc, q0, head_stride=off[q1 + "linear0.weight"] - off[q0 + "linear0.weight"], nb=2)
+        self.pi = MlpView(fa, "backbone.final_mlp.mlp.")
+        self.q_base = off[q0 + "linear0.weight"]          # start of the Q heads inside the critic buffer
+        assert agent._target_range[0] == self.q_base
+        self.A = agent.actor.head.dim_output
+        self.H = self.q.dims[0][1]
+        self.Din_q, self.Din_a = self.q.dims[0][0], self.pi.dims[0][0]
+        self.S = self.Din_a - self.F
+        assert self.Din_q == self.Din_a + self.A and self.S >= 0
+        self.ldq, self.lda = ceil4(self.Din_q), ceil4(self.Din_a)
+        self.bufs = {}
+        dev = fc.data.device
+        self.stats_c = torch.zeros(4, device=dev)
+        self.stats_a = torch.zeros(3, device=dev)
+        self.d_nlp = torch.zeros(1, device=dev)
+        # policy noise stream: torch's seed (torch.manual_seed controls it), decorrelated across data-parallel ranks
+        from ..utils.dist import rank as _rank
+        self.seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (_rank() + 1)) & (2 ** 64 - 1)
+
+    def _buf(self, name, *shape, dtype=torch.float32):
+        key = (name,) + shape
+        if key not in self.bufs:
+            self.bufs[key] = torch.zeros(*shape, dtype=dtype, device=self.a._flat["critic"].data.device)
+        return self.bufs[key]
+
+    # -- pieces -------------------------------------------------------------------------------------
+    def _features(self, jobs):
+        """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
+        jobs = [(pooled, M, tag, dsts, save, cats)]; the Linear GEMMs share one launch and so do the LayerNorms, which
+        also drop the pass-through columns `cats` = [(src [M, n], dst buffer, dst column)] (robot state, replay actions:
+        Visuomotor's torch.cat, visuomotor.py:130-141) into the head inputs.  Returns [(xhat, rstd)]."""
+        fc, off, F, c3 = self.a._flat["critic"], self.off, self.F, self.c3
+        pre = "values.0.backbone.visual_nn.final_mlp."
+        ys = [self._buf(f"feat_pre_{tag}", M, F) for _, M, tag, _, _, _ in jobs]
+        hip.gemm_group([hip.gemm_desc(pooled, fc.data[off[pre + "0.weight"]:], y, M, F, c3, (c3, 1), (1, c3), F, bias=fc.data[off[pre + "0.bias"]:])
+                        for (pooled, M, _, _, _, _), y in zip(jobs, ys)])
+        out, ln_jobs = [], []
+        for (_, M, tag, dsts, save, cats), y in zip(jobs, ys):
+            xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
+            rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
+            pending = [(src if src.dtype == torch.float32 else src.float(), dst, col, dst.shape[1]) for src, dst, col in cats if src is not None]
+            while len(pending) > 2:                      # the kernel takes two pass-through blocks per job
+                src, dst, col, _ = pending.pop()
+                dst[:, col:col + src.shape[1]].copy_(src)
+            ln_jobs.append(dict(x=y, ldx=F, M=M, dsts=dsts, xhat=xhat, rstd=rstd, cats=pending))
+            out.append((xhat, rstd))
+        hip.layernorm_rows_fwd_multi(ln_jobs, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps)
+        return out
+
+    def _actor_forward(self, XA, M, tag, act_dst, ld_act, save):
+        """Actor MLP + TanhGaussianHead mode="max-entropy"; the action goes straight into the Q input."""
+        a, A, H = self.a, self.A, self.H
+        h1, h2 = self._buf(f"pi_h1_{tag}", 1, M, H), self._buf(f"pi_h2_{tag}", 1, M, H)
+        feat = self._buf(f"pi_out_{tag}", M, 2 * A)
+        mlp_forward(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
+        head = a.actor.head
+        eps = self._buf(f"pi_eps_{tag}", M, A)
+        act = self._buf(f"pi_act_{tag}", M, A)
+        nlp = self._buf(f"pi_nlp_{tag}", M)
+        saved = self._buf(f"pi_saved_{tag}", M, 2 * A) if save else None
+        if head.noise_override:          # parity tests inject the draws
+            eps = head._standard_normal(eps)
+            hip.tanh_gaussian_fwd(feat, 2 * A, eps, head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                  act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+        else:                            # drawn in the kernel; the critic optimizer's device step count advances the stream
+            hip.tanh_gaussian_sample_fwd(feat, 2 * A, self.seed, a.critic_optim.step_counter, 0 if tag == "n" else 1, eps,
+                                         head.scale, head.bias, M, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                         act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+        return feat, eps, saved, nlp, h1, h2
+
+    # -- the step -------------------------------------------------------------------------------------
+    def run(self, *args, **kwargs):
+        """Execute the step in one go; gradient exchanges (data-parallel) happen inline."""
+        a = self.a
+        gen = self.steps(*args, **kwargs)
+        exchange = next(gen)
+        try:
+            while True:
+                scale = 1.0
+                for t in exchange:
+                    scale = a._allreduce(t)
+                exchange = gen.send(scale)
+        except StopIteration as done:
+            return done.value
+
+    def steps(self, obs, next_obs, actions, rewards, dones, do_actor, polyak, group=1, actor_obs=None):
+        """Generator form of the step: yields the flat gradient buffers that have to be all-reduced at
+        that point (empty list when single-process semantics suffice) and receives the factor 1/world
+        to fold into the optimizer pass.  Between two yields no cross-rank communication happens, so
+        every stretch can be captured as its own hipGraph while the collectives stay eager."""
+        a = self.a
+        enc, F, S, A, H = a.encoder, self.F, self.S, self.A, self.H
+        ldq, lda = self.ldq, self.lda
+        fc, fa = a._flat["critic"], a._flat["actor"]
+        split = type(a.actor.backbone).split_obs
+        M = actions.shape[0]
+        stats = {}
+
+        # ---- target y = r + (1-d) gamma (min_h Q'(s', a') + alpha * (-log pi(a'|s')))  (sac.py:110-134) and q = Q(s, a)
+        # (sac.py:136).  Both encoder passes first, then the head GEMMs of the two independent branches pairwise in
+        # one launch each (feature Linear of s' and s; target Q heads on s' and online Q heads on s).
+        vis_n, state_n = split(next_obs)
+        pooled_n, _, _ = enc.encode_raw(vis_n)
+        vis_o, state_o = split(obs)
+        pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
+        XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
+        (_, _), (xhat, rstd) = self._features([
+            (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F), (state_n, XQ_n, F)]),
+            (pooled_o, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F), (actions, XQ_o, F + S)])])
+        _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
+        qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
+        q_next = self._buf("q_next", M, 2)
+        tgt = a._target_flat.data
+        q_h1, q_h2 = self._buf("q_h1", 2, M, H), self._buf("q_h2", 2, M, H)
+        q = self._buf("q", M, 2)
+        launch_layers(mlp_forward_descs(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1),
+                      mlp_forward_descs(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1))
+
+        # ---- critic loss, backward through heads, feature head and encoder (sac.py:137-148) ----
+        q_target, dq = self._buf("q_target", M), self._buf("dq", M, 2)
+        dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
+        hip.sac_critic_loss(q_next, 2, nlp_n, rewards, dones_u8, a.log_alpha, a.gamma,
+                            a.reward_scale if a.metric_prefix == "sac" else 1.0, a.ignore_dones, group, q, 2, M, 2,
+                            q_target, dq, 2, self.stats_c)
+        dh1, dh2 = self._buf("q_dh1", 2, M, H), self._buf("q_dh2", 2, M, H)
+        dX0 = self._buf("q_dX0", 2, M, ceil4(F))
+        mlp_backward(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F), ld_dx=ceil4(F))
+        off, pre = self.off, "values.0.backbone.visual_nn.final_mlp."
+        dy = self._buf("feat_dy", M, F)
+        ws = self._buf("ln_ws", ((M + 3) // 4) * 2 * F)
+        hip.layernorm_rows_bwd(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd, fc.data[off[pre + "1.weight"]:], M, F,
+                               dy, F, fc.grad[off[pre + "1.weight"]:], fc.grad[off[pre + "1.bias"]:], ws)
+        c3 = self.c3
+        dpooled = self._buf("dpooled", M, c3)
+        hip.gemm_group([hip.gemm_desc(dy, pooled_o, fc.grad[off[pre + "0.weight"]:], F, c3 + 1, M, (1, F), (c3, 1), c3, ones_col=c3,
+                                      c_ones=fc.grad[off[pre + "0.bias"]:]),
+                        hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
+        enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
+        scale = yield [fc.grad]
+        pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
+        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)
+        enc.invalidate_packed()
+        stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
+
+        # ---- actor + temperature (sac.py:161-205) --------------------------------------------------------
+        if do_actor:
+            a_obs = obs if actor_obs is None else actor_obs
+            vis_a, state_a = split(a_obs)
+            Ma = M if actor_obs is None else vis_a["xyz"].shape[0]
+            pooled_a, _, _ = enc.encode_raw(vis_a)                    # updated encoder weights, no gradient
+            XA_a, XQ_a = self._buf("XA_a", Ma, lda), self._buf("XQ_a", Ma, ldq)
+            self._features([(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False, [(state_a, XA_a, F), (state_a, XQ_a, F)])])
+            feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
+            qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)
+            q_pi = self._buf("q_pi", Ma, 2)
+            mlp_forward(self.q, None, 0, XQ_a, ldq, Ma, (qa_h1, qa_h2), 2, q_pi, 1)
+            dq_pi = self._buf("dq_pi", Ma, 2)
+            fal = a._flat["alpha"]
+            hip.sac_actor_loss(q_pi, 2, nlp, a.log_alpha, a.target_entropy, Ma, 2, dq_pi, 2, self.d_nlp, fal.grad, self.stats_a)
+            da_h1, da_h2 = self._buf("qa_dh1", 2, Ma, H), self._buf("qa_dh2", 2, Ma, H)
+            d_act = self._buf("d_act", 2, Ma, ceil4(A))
+            mlp_backward(self.q, XQ_a, ldq, Ma, qa_h1, qa_h2, dq_pi, (2, 1), 1, da_h1, da_h2, grad=None, dX=d_act,
+                         dx_cols=(F + S, A), ld_dx=ceil4(A))
+            head = a.actor.head
+            dfeat = self._buf("pi_dfeat", Ma, 2 * A)
+            hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, head.scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                  d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
+            dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
+            mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
+            scale = yield ([fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
+            stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
+            a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
+            stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
+        # one launch gathers every reported scalar (and alpha = exp(log_alpha), sac.py:196) into one array
+        names = list(stats.keys())
+        out = self._buf("stats_out", 16)
+        entries = [(a.log_alpha, out[i:], True) if k == "new_alpha" else (stats[k], out[i:], False) for i, k in enumerate(names)]
+        if "new_alpha" in stats:
+            entries.append((a.log_alpha, a._alpha_t, True))
+        hip.gather_scalars(entries, pending=pending)
+        packed = PackedStats((k, out[i]) for i, k in enumerate(names))
+        packed.packed = out[:len(names)]
+        return packed

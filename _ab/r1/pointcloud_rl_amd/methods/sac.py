@@ -1,0 +1,493 @@
+"""SAC agent on the MI355X hot path.
+
+Constructor keywords, `update_parameters(memory, updates) -> dict[str, float]` and the returned
+metric keys follow the reference's pyrl/methods/mfrl/sac.py:26-214.  What differs is how the step
+is executed:
+  * the shared PointNet is evaluated once per distinct (weights, input) pair -- next_obs once
+    (the reference: 3x), obs once with the gradients of both Q heads summed (2x), and once more for
+    the actor after the critic step -- instead of once per head;
+  * parameters and gradients of each optimizer live in one flat buffer (one RCCL all-reduce per
+    backward when data-parallel);
+  * all returned metrics come from one device->host copy at the end of the step.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hip
+from ..augmentations import build_data_augmentations
+from ..networks import build_actor_critic, build_target_network
+from ..utils.dist import allreduce_sum_, world_size
+from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
+from .builder import MFRL
+
+
+class FlatBuffer:
+    """Re-homes a list of parameters into one contiguous buffer (data and grad as views).  Every
+    tensor starts on a 16-byte boundary so that the GEMM kernels can use 16-byte operand loads; the
+    padding floats stay zero (zero gradient -> Adam leaves them at zero)."""
+
+    ALIGN = 4    # floats
+
+    def __init__(self, named_params, with_grad=True):
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        dev = self.params[0].device
+        self.offsets, o = [], 0
+        for p in self.params:
+            self.offsets.append(o)
+            o += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = o
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev) if with_grad else None
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            if with_grad:
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def offset_of(self, name):
+        return self.offsets[self.names.index(name)]
+
+    def views(self, flat_tensor):
+        return [flat_tensor[o:o + p.numel()].view(p.shape) for p, o in zip(self.params, self.offsets)]
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, g in zip(self.params, self.views(self.grad)):   # re-attach in case something set .grad to None
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+    def grad_norm_sq(self):
+        return (self.grad * self.grad).sum()
+
+
+class HipAdam:
+    """torch.optim.Adam-compatible facade over the fused flat-buffer kernel (pcrl_adam_step_f32).
+
+    Keeps what the reference's drivers touch: `param_groups` (one group per tensor, as
+    build_optimizer makes them), `state_dict()/load_state_dict()` in torch's format (checkpoints store
+    the optimizers under their attribute names, checkpoint_utils.py:215-237), `zero_grad()`, `step()`.
+    """
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **unused):
+        self.flat = flat
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False)
+        self.param_groups = [dict(self.defaults, params=[p]) for p in flat.params]
+        dev = flat.data.device
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.workspace = torch.empty(hip.adam_workspace_bytes(flat.data.numel()), dtype=torch.uint8, device=dev)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False):
+        """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...)."""
+        g = self.param_groups[0]
+        return hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
+                             g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
+                             target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer)
+
+    def _views(self, flat_tensor):
+        return self.flat.views(flat_tensor)
+
+    def state_dict(self):
+        step = self.step_counter.to(torch.float32).reshape(())
+        state = {i: dict(step=step.clone(), exp_avg=m, exp_avg_sq=v)
+                 for i, (m, v) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq)))} if int(self.step_counter.item()) > 0 else {}
+        groups = [dict({k: v for k, v in g.items() if k != "params"}, params=[i]) for i, g in enumerate(self.param_groups)]
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        for i, st in sd.get("state", {}).items():
+            i = int(i)
+            self._views(self.exp_avg)[i].copy_(st["exp_avg"])
+            self._views(self.exp_avg_sq)[i].copy_(st["exp_avg_sq"])
+            self.step_counter.fill_(int(st["step"]))
+        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in src.items() if k != "params"})
+
+
+def _plain_adam(optim):
+    if type(optim) is not torch.optim.Adam:
+        return None
+    d = optim.defaults
+    if d.get("amsgrad") or d.get("weight_decay") or d.get("maximize"):
+        return None
+    return dict(lr=d["lr"], betas=d["betas"], eps=d["eps"])
+
+
+@MFRL.register_module()
+class SAC(BaseAgent):
+    metric_prefix = "sac"
+
+    def __init__(self, actor_cfg, critic_cfg, env_params, batch_size=128, gamma=0.99, reward_scale=1, update_coeff=0.005,
+                 alpha=0.2, alpha_optim_cfg=None, automatic_alpha_tuning=True, target_entropy=None, ignore_dones=False,
+                 use_episode_dones=False, target_update_interval=1, actor_update_interval=1, shared_backbone=False,
+                 shared_target_backbone=None, detach_actor_feature=False, target_smooth=0.90, pre_process=None):
+        super().__init__()
+        self.is_discrete = env_params["is_discrete"]
+        if self.is_discrete:
+            raise NotImplementedError("discrete SAC is outside the point-cloud hot path")
+        self.gamma, self.update_coeff, self.alpha, self.reward_scale = gamma, update_coeff, alpha, reward_scale
+        self.ignore_dones, self.batch_size = ignore_dones, batch_size
+        self.target_update_interval, self.actor_update_interval = target_update_interval, actor_update_interval
+        self.automatic_alpha_tuning, self.shared_backbone = automatic_alpha_tuning, shared_backbone
+        self.detach_actor_feature, self.use_episode_dones = detach_actor_feature, use_episode_dones
+
+        self.obs_processor = build_data_augmentations(pre_process)
+        actor_cfg, critic_cfg = deepcopy([actor_cfg, critic_cfg])
+        actor_optim_cfg, critic_optim_cfg = actor_cfg.pop("optim_cfg"), critic_cfg.pop("optim_cfg")
+        actor_cfg.update(env_params)
+        critic_cfg.update(env_params)
+        self.actor, self.critic = build_actor_critic(actor_cfg, critic_cfg, shared_backbone)
+        self._actor_optim_cfg, self._critic_optim_cfg = actor_optim_cfg, critic_optim_cfg
+        self.actor_optim = build_optimizer(self.actor, actor_optim_cfg)
+        self.critic_optim = build_optimizer(self.critic, critic_optim_cfg)
+        shared_target_backbone = shared_backbone if shared_target_backbone is None else shared_target_backbone
+        self.target_critic = build_target_network(critic_cfg, self.critic, self.actor, shared_target_backbone)
+        self.is_recurrent = False
+
+        self.log_alpha = nn.Parameter(torch.ones(1, requires_grad=True))
+        self.log_alpha.data *= float(np.log(np.float32(alpha)))
+        self.target_entropy = -float(np.prod(env_params["action_shape"])) if target_entropy is None else target_entropy
+        if self.automatic_alpha_tuning:
+            self.alpha = self.log_alpha.exp().item()
+        self.alpha_optim = build_optimizer(self.log_alpha, alpha_optim_cfg)
+        self._flat = None
+        self.use_fused_step = True   # autograd-free launch sequence (methods/fused.py) when the topology allows
+        self.sync_alpha = True     # data-parallel: all-reduce log_alpha's gradient too (the reference does not)
+
+    # ---------------------------------------------------------------------------------------------
+    @property
+    def encoder(self):
+        return getattr(self.actor.backbone, "visual_nn", None)
+
+    def _encoder_is_shared(self):
+        enc = self.encoder
+        if enc is None:
+            return False
+        heads = list(self.critic.values) + list(self.target_critic.values)
+        return all(getattr(h.backbone, "visual_nn", None) is enc for h in heads)
+
+    def _prepare(self):
+        """Lazily (after .to(device)) move every optimizer's parameters into flat buffers."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("pointcloud_rl_amd agents update on MI355X only (agent.to('cuda') first); there is no CPU path")
+        self._flat = {
+            "critic": FlatBuffer(select_optimizer_params(self.critic, self._critic_optim_cfg.get("param_cfg"))),
+            "actor": FlatBuffer(select_optimizer_params(self.actor, self._actor_optim_cfg.get("param_cfg"))),
+        }
+        self._flat["alpha"] = FlatBuffer([("log_alpha", self.log_alpha)])
+        for name in ("critic", "actor", "alpha"):      # torch.optim.Adam (one group per tensor) -> one fused launch
+            old = getattr(self, f"{name}_optim")
+            hp = _plain_adam(old)
+            if hp is not None:
+                fused = HipAdam(self._flat[name], **hp)
+                if old.state:                          # a checkpoint was loaded before the first update: keep moments and step
+                    fused.load_state_dict(old.state_dict())
+                setattr(self, f"{name}_optim", fused)
+        # Polyak: the target's own (non-shared) parameters mirror a tail range of the critic buffer
+        online = {id(p) for p in self.critic.parameters()}
+        tgt = [(n, p) for n, p in self.target_critic.named_parameters() if id(p) not in online]
+        self._target_flat, self._target_range, self._target_tau = None, (0, 0), None
+        own = [(n, p) for n, p in zip(self._flat["critic"].names, self._flat["critic"].params)
+               if n in {tn for tn, _ in tgt}]
+        taus = {self._tau_for(n) for n, _ in own}
+        if tgt and len(own) == len(tgt) and len(taus) == 1 and [n for n, _ in own] == [n for n, _ in tgt]:
+            fc = self._flat["critic"]
+            first = fc.names.index(own[0][0])
+            if first + len(own) == len(fc.params):
+                target_flat = FlatBuffer(tgt, with_grad=False)
+                begin = fc.offsets[first]
+                if target_flat.total == fc.total - begin:      # same relative layout (identical padding)
+                    self._target_flat, self._target_range, self._target_tau = target_flat, (begin, fc.total), taus.pop()
+        self._alpha_t = self.log_alpha.detach().exp()
+        self._dedup = self._encoder_is_shared()
+        from .fused import FusedStep
+        self._fused = FusedStep(self) if (self.use_fused_step and FusedStep.supported(self)) else None
+        self._world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+
+    def _tau_for(self, name):
+        """soft_update's regex -> tau rule (pyrl/utils/torch/ops.py:66-90)."""
+        if not isinstance(self.update_coeff, dict):
+            return float(self.update_coeff)
+        for pattern, value in self.update_coeff.items():
+            if pattern != "default" and regex_match(name, pattern):
+                return float(value)
+        return float(self.update_coeff["default"])
+
+    def _allreduce(self, tensor):
+        """Sum the flat gradient over the ranks (RCCL); the 1/world factor is applied by the optimizer kernel."""
+        return allreduce_sum_(tensor, enabled=self._be_data_parallel)
+
+    def _optim_step(self, name, scale, polyak=False, pending=None):
+        """pending: a list -> the optimizer's second half (gradient norm, step count) is deferred and appended to it."""
+        opt = getattr(self, f"{name}_optim")
+        fb = self._flat[name]
+        if isinstance(opt, HipAdam):
+            defer = pending is not None
+            if polyak and self._target_flat is not None:
+                pend = opt.step(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau, defer=defer)
+            else:
+                pend = opt.step(scale, defer=defer)
+            if defer:
+                pending.append(pend)
+            return opt.grad_norm.reshape(())
+        if scale != 1.0:
+            fb.grad.mul_(scale)
+        opt.step()
+        return fb.grad_norm_sq().sqrt()
+
+    def _encode(self, module_for_fallback, obs):
+        """Visual feature of `obs` when the encoder is shared (else None: the module encodes itself)."""
+        if not self._dedup:
+            return None
+        visual, _ = type(self.actor.backbone).split_obs(obs)
+        return self.encoder(visual)
+
+    # ---------------------------------------------------------------------------------------------
+    def _q_target(self, next_obs, rewards, dones, n_groups=None):
+        with torch.no_grad():
+            vis = self._encode(self.actor, next_obs)
+            kw = {} if vis is None else dict(visual_feature=vis)
+            next_actions, neg_logp = self.actor(next_obs, mode="max-entropy", **kw)
+            q_next = self.target_critic(next_obs, actions=next_actions, **kw)
+            min_q = torch.min(q_next, dim=-1, keepdim=True).values + self._alpha_t * neg_logp
+            r = rewards * self.reward_scale if self.metric_prefix == "sac" else rewards
+            q_target = r + self.gamma * min_q if self.ignore_dones else r + (1 - dones.float()) * self.gamma * min_q
+            if n_groups is not None:      # DrQ: average the target over the augmentations of a sample (drq.py:83-86)
+                q_target = q_target.reshape(n_groups, -1).mean(1, keepdim=True)
+                q_target = torch.repeat_interleave(q_target, q_next.shape[0] // n_groups, dim=0)
+            return q_target.repeat(1, q_next.shape[-1])
+
+    def _critic_step(self, obs, actions, q_target, stats, polyak=False):
+        fb = self._flat["critic"]
+        vis = self._encode(self.critic, obs)
+        q = self.critic(obs, actions, **({} if vis is None else dict(visual_feature=vis)))
+        critic_loss = F.mse_loss(q, q_target) * q_target.shape[-1]
+        fb.zero_grad()
+        critic_loss.backward()
+        scale = self._allreduce(fb.grad)
+        grad_norm = self._optim_step("critic", scale, polyak=polyak)
+        if self.encoder is not None:
+            self.encoder.invalidate_packed()
+        with torch.no_grad():
+            stats["critic_loss"] = critic_loss.detach()
+            stats["max_critic_abs_err"] = torch.abs(q - q_target).max()
+            stats["q"] = torch.min(q, dim=-1).values.mean()
+            stats["q_target"] = q_target.mean()
+            # 2-norm over all critic parameters == norm of the per-tensor norms (module_utils.py:40-45)
+            stats["critic_grad"] = grad_norm
+
+    def _actor_step(self, obs, stats):
+        fb = self._flat["actor"]
+        kw = {}
+        if self._dedup:
+            visual, _ = type(self.actor.backbone).split_obs(obs)
+            if self.detach_actor_feature:
+                with torch.no_grad():
+                    kw["visual_feature"] = self.encoder(visual)
+            else:
+                kw["visual_feature"] = self.encoder(visual)
+        pi, neg_logp = self.actor(obs, mode="max-entropy", save_feature=self.shared_backbone,
+                                  detach_visual=self.detach_actor_feature, **kw)[:2]
+        entropy_term = neg_logp.mean()
+        visual_feature = self.actor.backbone.pop_attr("saved_visual_feature")
+        if visual_feature is not None:
+            visual_feature = visual_feature.detach()
+        # Only d(q)/d(pi) is needed from the Q heads here: the reference also accumulates (and later
+        # discards, sac.py:141/148) their weight gradients; skip computing them.
+        critic_params = [p for p in self.critic.parameters() if p.requires_grad]
+        for p in critic_params:
+            p.requires_grad_(False)
+        try:
+            q_pi = self.critic(obs, actions=pi, visual_feature=visual_feature)
+        finally:
+            for p in critic_params:
+                p.requires_grad_(True)
+        q_pi = torch.min(q_pi, dim=-1, keepdim=True).values
+        actor_loss = -(q_pi.mean() + self._alpha_t * entropy_term)
+        fb.zero_grad()
+        actor_loss.backward()
+        stats["actor_grad"] = self._optim_step("actor", self._allreduce(fb.grad))
+        stats["actor_loss"] = actor_loss.detach()
+        stats["entropy"] = entropy_term.detach()
+        if self.automatic_alpha_tuning:
+            alpha_loss = self.log_alpha.exp() * (entropy_term - self.target_entropy).detach()
+            self._flat["alpha"].zero_grad()
+            alpha_loss.backward()
+            self._optim_step("alpha", self._allreduce(self._flat["alpha"].grad) if self.sync_alpha else 1.0)
+            self._alpha_t.copy_(self.log_alpha.detach().exp())     # in place: captured graphs read this tensor
+            stats["alpha_loss"] = alpha_loss.detach().reshape(())
+        else:
+            stats["alpha_loss"] = torch.zeros((), device=self.device)
+        stats["new_alpha"] = self._alpha_t.reshape(()).clone()
+
+    def _finish(self, stats, updates, host_values=None):
+        """One device->host copy for every metric the reference reads with .item() (sac.py:140-203)."""
+        keys = list(stats.keys())
+        if host_values is not None:
+            vals = host_values
+        elif getattr(stats, "packed", None) is not None:
+            vals = stats.packed.tolist()
+        else:
+            vals = torch.stack([stats[k].reshape(()).float() for k in keys]).tolist()
+        got = dict(zip(keys, vals))
+        pre = self.metric_prefix
+        ret = {f"{pre}/critic_loss": got["critic_loss"], f"{pre}/max_critic_abs_err": got["max_critic_abs_err"],
+               f"{pre}/alpha": self.alpha, f"{pre}/q": got["q"], f"{pre}/q_target": got["q_target"],
+               f"{pre}/target_entropy": self.target_entropy, f"{pre}/critic_grad": got["critic_grad"], f"{pre}/grad_steps": 1}
+        if "actor_loss" in got:
+            ret.update({f"{pre}/actor_loss": got["actor_loss"], f"{pre}/alpha_loss": got["alpha_loss"],
+                        f"{pre}/entropy": got["entropy"], f"{pre}/actor_grad": got["actor_grad"]})
+            if self.automatic_alpha_tuning:
+                self.alpha = got["new_alpha"]
+        return ret
+
+    def _polyak_now(self, updates):
+        """True when this step's target update is fused into the critic's optimizer pass.  The critic's
+        weights do not change between its optimizer step and the reference's soft_update call at the end
+        of the step (sac.py:207-208), so updating the target right after the step is equivalent."""
+        return updates % self.target_update_interval == 0 and self._target_flat is not None and isinstance(self.critic_optim, HipAdam)
+
+    def _soft_update(self, updates):
+        if updates % self.target_update_interval == 0 and not self._polyak_now(updates):
+            soft_update(self.target_critic, self.critic, self.update_coeff)
+
+    # -- step execution: eager, or replayed from a hipGraph --------------------------------------
+    def _step_body(self, batch, do_actor, polyak):
+        """SAC step on a device-resident batch; returns the dict of device scalars for the metrics."""
+        if self._fused is not None:
+            return self._fused.run(batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak)
+        stats = {}
+        q_target = self._q_target(batch["next_obs"], batch["rewards"], batch["dones"])
+        self._critic_step(batch["obs"], batch["actions"], q_target, stats, polyak=polyak)
+        if do_actor:
+            self._actor_step(batch["obs"], stats)
+        return stats
+
+    def enable_graphs(self, enabled=True, warmup=2):
+        """Capture the whole update step in a hipGraph (one graph per (actor-update?, target-update?)
+        combination) and replay it: per-step host work drops to copying the batch into static buffers,
+        one graph launch and one device->host copy.  Requires device-resident state only, which is why
+        alpha, the Adam step counts and the Philox offsets live in device memory."""
+        self._use_graphs, self._graph_warmup = enabled, warmup
+        self._graphs, self._graph_seen, self._static_batch = {}, {}, None
+
+    def _to_static(self, batch):
+        """Copy `batch` into buffers whose addresses the captured graphs refer to."""
+        keys = ("obs", "next_obs", "actions", "rewards", "dones")
+        if self._static_batch is None:
+            # a device replay hands out long-lived staging tensors: read them in place instead of cloning
+            keep = (lambda t: t) if getattr(batch, "persistent", False) else (lambda t: t.clone())
+            self._static_batch = {k: ({kk: keep(vv) for kk, vv in batch[k].items()} if isinstance(batch[k], dict) else keep(batch[k]))
+                                  for k in keys}
+            return self._static_batch
+        for k in keys:
+            src, dst = batch[k], self._static_batch[k]
+            for kk in (src if isinstance(src, dict) else [None]):
+                s_, d_ = (src[kk], dst[kk]) if kk is not None else (src, dst)
+                if s_.data_ptr() != d_.data_ptr():
+                    d_.copy_(s_, non_blocking=True)
+        return self._static_batch
+
+    def _fused_args(self, batch, do_actor, polyak):
+        return (batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), {}
+
+    def _run_step(self, batch, updates):
+        do_actor = updates % self.actor_update_interval == 0
+        polyak = self._polyak_now(updates)
+        exchanging = self._be_data_parallel and world_size() > 1
+        graphable = getattr(self, "_use_graphs", False) and (not (updates % self.target_update_interval == 0) or polyak) \
+            and (not exchanging or self._fused is not None)
+        if not graphable:
+            stats = self._step_body(batch, do_actor, polyak)
+            self._soft_update(updates)
+            return self._finish({k: v for k, v in stats.items()}, updates)
+        batch = self._to_static(batch)
+        key = (do_actor, polyak)
+        if key not in self._graphs:
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen < self._graph_warmup:          # eager warm-up: lazy initialisation must not be captured
+                return self._finish(self._step_body(batch, do_actor, polyak), updates)
+            if self.encoder is not None:
+                self.encoder.invalidate_packed()   # every replay starts by re-packing the (updated) weights
+            torch.cuda.synchronize()
+            self._graphs[key] = self._capture_segments(batch, do_actor, polyak) if exchanging else self._capture_whole(batch, do_actor, polyak)
+            if exchanging:                          # capturing a segmented step also executed it
+                segments, names, out = self._graphs[key]
+                return self._finish(dict(zip(names, out.unbind(0))), updates)
+        segments, names, out = self._graphs[key]
+        for graph, exchange in segments:
+            graph.replay()
+            for t in exchange:
+                allreduce_sum_(t)
+        if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
+            stream = self.__dict__.get("_sync_stream")
+            if stream is None or stream.cuda_stream != hip.raw_stream():
+                stream = self.__dict__["_sync_stream"] = torch.cuda.current_stream()
+            stream.synchronize()
+            return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
+        return self._finish(dict(zip(names, out.unbind(0))), updates)
+
+    def _capture_whole(self, batch, do_actor, polyak):
+        graph = torch.cuda.CUDAGraph()
+        host = None
+        pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
+        with torch.cuda.graph(graph):
+            stats = self._step_body(batch, do_actor, polyak)
+            names = list(stats.keys())
+            packed = getattr(stats, "packed", None)
+            out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
+            if packed is not None:          # the metrics land in pinned host memory as the graph's last node
+                host = pinned[:len(names)]
+                host.copy_(out, non_blocking=True)
+        return [(graph, [])], names, (host if host is not None else out)
+
+    def _capture_segments(self, batch, do_actor, polyak):
+        """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay
+        eager between the graph launches (no collective is ever captured).  Capturing records without
+        executing, so each segment is replayed right after its capture to carry the step forward."""
+        pool = torch.cuda.graph_pool_handle()
+        scale = 1.0 / world_size()
+        segments, names, out, gen = [], None, None, None
+        while names is None:
+            graph = torch.cuda.CUDAGraph()
+            exchange = []
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                try:
+                    if gen is None:     # batch preparation (DrQ: repeat + augmentation draws) belongs to the first segment
+                        args, kwargs = self._fused_args(batch, do_actor, polyak)
+                        gen = self._fused.steps(*args, **kwargs)
+                        exchange = next(gen)
+                    else:
+                        exchange = gen.send(scale)
+                except StopIteration as done:
+                    stats = done.value
+                    names = list(stats.keys())
+                    out = torch.stack([stats[k].reshape(()).float() for k in names])
+            graph.replay()
+            for t in exchange:
+                allreduce_sum_(t)
+            segments.append((graph, list(exchange)))
+        return segments, names, out
+
+    def update_parameters(self, memory, updates):
+        if self._flat is None:
+            self._prepare()
+        sampled_batch = memory.sample(self.batch_size).to_torch(device=self.device, non_blocking=True)
+        sampled_batch = self.process_obs(sampled_batch)
+        if self.use_episode_dones:
+            sampled_batch["dones"] = sampled_batch["episode_dones"]
+        return self._run_step(sampled_batch, updates)

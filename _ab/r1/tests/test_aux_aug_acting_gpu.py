@@ -1,0 +1,381 @@
+"""GPU tests: stand-alone segmented max / augmentation kernels, the fused augmentations of the encoder
+(explicit noise, affine, in-kernel Philox statistics) and the acting path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_encoder_weights, make_obs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_segmax_matches_oracle_and_torch(cuda):
+    from oracle import c_oracle
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(0)
+    for B, c, N in [(3, 7, 1000), (2, 5, 33), (4, 16, 1024)]:
+        x = g.randn(B, c, N).astype(np.float32)
+        x[0, 0, :] = 0.0                         # all-equal row -> index 0
+        x[0, 1, 5] = x[0, 1, 9] = 9.0            # exact tie -> first index
+        x[1, 2, 7] = np.nan                      # NaN wins
+        x[1, 2, 3] = np.inf
+        ref_v, ref_i = c_oracle.segmax(x)
+        tv, ti = torch.from_numpy(x).max(-1)
+        assert np.array_equal(ref_i, ti.numpy().astype(np.int32))
+        v, i = hip.segmax_fwd(torch.from_numpy(x).to(cuda))
+        assert np.array_equal(i.cpu().numpy(), ref_i)
+        assert np.array_equal(np.isnan(v.cpu().numpy()), np.isnan(ref_v))
+        m = ~np.isnan(ref_v)
+        assert np.array_equal(v.cpu().numpy()[m], ref_v[m])
+        go = g.randn(B, c).astype(np.float32)
+        dx = hip.segmax_bwd(torch.from_numpy(go).to(cuda), i, N).cpu().numpy()
+        want = np.zeros_like(x)
+        np.put_along_axis(want, ref_i[..., None].astype(np.int64), go[..., None], axis=-1)
+        assert np.array_equal(dx, want)
+
+
+def test_augment_xyz_kernel_and_fused_affine_jitter(cuda):
+    """GlobalRotScaleTrans (rot + per-axis scale + translation) followed by explicit jitter: the stand-alone
+    kernel, the fused encoder load and the reference formula (apply_rot_trans: R x + t) agree."""
+    from oracle import c_oracle
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.augmentations import GlobalRotScaleTrans
+    B, N = 5, 150
+    obs = make_obs(B, N, seed=21)
+    torch.manual_seed(3)
+    t = GlobalRotScaleTrans(main_key="xyz", req_keys=["xyz"], rot_range=[-0.5, 0.5], rot_axis="y",
+                            scale_ratio_range=[0.8, 1.2], translation_range=[0.1, 0.2, 0.3], shift_height=True)
+    mat = t.sample_matrix(B, cuda)
+    noise = torch.from_numpy(np.random.RandomState(1).uniform(-0.01, 0.01, (B, 3, N)).astype(np.float32)).to(cuda)
+    xyz = torch.from_numpy(obs["xyz"]).to(cuda)
+    out = hip.augment_xyz(xyz, affine=mat, jitter_noise=noise)
+    m = mat.cpu()
+    want = torch.einsum("bin,bji->bjn", torch.from_numpy(obs["xyz"]), m[:, :, :3]) + m[:, :, 3:] + noise.cpu()
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), atol=1e-6)
+    # fused into the encoder: encode(raw obs + aug desc) == encode(materialised augmented obs), bit for bit
+    w = make_encoder_weights(6, 64, 128, 256, seed=2)
+    wt = {k: torch.from_numpy(v).to(cuda) for k, v in w.items()}
+    ew, _ = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(6, 64, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    rgb = torch.from_numpy(obs["rgb"]).to(cuda)
+    d1, k1 = hip.make_cloud_desc({"xyz": xyz, "rgb": rgb})
+    p_fused, a_fused = hip.encoder_fwd(d1, ew, packed, aug=hip.make_aug_desc(affine=mat, jitter_noise=noise))
+    d2, k2 = hip.make_cloud_desc({"xyz": out, "rgb": rgb})
+    p_mat, a_mat = hip.encoder_fwd(d2, ew, packed)
+    assert torch.equal(p_fused, p_mat) and torch.equal(a_fused, a_mat)
+    pooled_ref, arg_ref = c_oracle.encoder_fwd(c_oracle.preprocess({"xyz": out.cpu().numpy(), "rgb": obs["rgb"]}), w)
+    assert np.array_equal(a_mat.cpu().numpy(), arg_ref) and np.array_equal(p_mat.cpu().numpy().view(np.uint32), pooled_ref.view(np.uint32))
+
+
+def test_philox_jitter_statistics_and_streams(cuda):
+    """In-kernel Philox4x32-10 jitter: range, first two moments, independence across calls / axes / clouds,
+    reproducibility for a fixed (seed, offset), and row remapping for strided sub-batches."""
+    from pointcloud_rl_amd import hip
+    B, N = 64, 2048
+    xyz = torch.zeros(B, 3, N, device=cuda)
+    a = hip.augment_xyz(xyz, jitter_range=[-0.01, 0.01], seed=11, offset=0)
+    a2 = hip.augment_xyz(xyz, jitter_range=[-0.01, 0.01], seed=11, offset=0)
+    b = hip.augment_xyz(xyz, jitter_range=[-0.01, 0.01], seed=11, offset=1)
+    c = hip.augment_xyz(xyz, jitter_range=[-0.01, 0.01], seed=12, offset=0)
+    assert torch.equal(a, a2) and not torch.equal(a, b) and not torch.equal(a, c)
+    v = a.cpu().numpy().astype(np.float64)
+    assert v.min() >= -0.01 and v.max() < 0.01
+    n = v.size
+    assert abs(v.mean()) < 4 * (0.02 / np.sqrt(12)) / np.sqrt(n)
+    assert abs(v.var() - 0.02 ** 2 / 12) < 0.02 * 0.02 ** 2 / 12
+    u = (v + 0.01) / 0.02
+    hist = np.histogram(u, bins=32, range=(0, 1))[0]
+    assert np.abs(hist - n / 32).max() < 6 * np.sqrt(n / 32)
+    corr = lambda p, q: abs(np.corrcoef(p.ravel(), q.ravel())[0, 1])
+    assert corr(v[:, 0], v[:, 1]) < 0.01 and corr(v[:-1], v[1:]) < 0.01 and corr(v[:, :, :-1], v[:, :, 1:]) < 0.01
+    assert corr(v, b.cpu().numpy()) < 0.01
+    # the device-side offset slot is what a hipGraph replay reads
+    off = torch.tensor([1], dtype=torch.int64, device=cuda)
+    assert torch.equal(hip.augment_xyz(xyz, jitter_range=[-0.01, 0.01], seed=11, offset=0, offset_tensor=off), b)
+    # cloud b of a strided sub-batch (every 2nd cloud) sees the noise row 2b of the full batch
+    sub = hip.augment_xyz(torch.zeros(B // 2, 3, N, device=cuda), jitter_range=[-0.01, 0.01], seed=11, offset=0, row_mul=2, row_add=0)
+    assert torch.equal(sub, a[::2])
+
+
+def test_drq_eager_philox_step_runs_and_differs_between_calls(cuda):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    cfg = configs.drq_dmc(6, 6, 8, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 128], "rgb": [3, 128]}, 6)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    agent.enable_graphs(warmup=1)
+    mem = SyntheticReplay(8, 128, 6, seed=2, device=cuda)
+    rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    assert len(agent._graphs) == 2 and agent._fused is not None
+    # same batch every step, so identical consecutive critic losses would mean the replayed graph re-used its noise
+    losses = [r["drq/critic_loss"] for r in rets]
+    assert len(set(np.round(losses, 7))) == len(losses)
+
+
+def test_acting_path(cuda):
+    """BaseAgent.forward (reference module_utils.py:147-159): numpy obs in, actions out; (actions, None) for
+    rnn_mode="with_states" as Rollout/Evaluation call it (rollout.py:91-97, evaluation.py:167-168)."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    cfg = configs.sac_maniskill(7, 8, 10, 4, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 90], "rgb": [3, 90]}, 8)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda).eval()
+    obs = make_obs(2, 90, seed=4, seg=1)
+    obs["agent"] = np.random.RandomState(0).randn(2, 10).astype(np.float32)
+    with agent.no_sync(mode="actor"):
+        actions, states = agent(obs, rnn_mode="with_states")
+    assert states is None and actions.shape == (2, 8) and actions.abs().max() <= 1.0
+    mean_a = agent(obs, mode="eval")
+    assert torch.equal(mean_a, agent(obs, mode="eval"))                 # deterministic evaluation mode
+    # against the oracle's restatement of the same modules
+    from oracle import torch_ref
+    P = {n: p.detach().cpu() for n, p in agent.named_parameters()}
+    tobs = {k: torch.from_numpy(v) for k, v in obs.items()}
+    feat, _ = torch_ref.visuomotor(P, "actor.backbone.final_mlp.mlp.", tobs)
+    want = torch.tanh(feat[:, :8]) * P["actor.head.scale"] + P["actor.head.bias"]
+    np.testing.assert_allclose(mean_a.cpu().numpy(), want.numpy(), atol=1e-5)
+
+
+def test_device_replay_sampling_matches_numpy_take(cuda):
+    """push_batch (with wrap-around) + sample == the reference's numpy ring + take with the same RandomState."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A = 40, 33, 5
+    mem = DeviceReplay(cap, device=cuda, seed=7, host_rng=True)
+    ring = None
+    pos = count = 0
+    for i, n in enumerate((16, 16, 16)):                 # third push wraps
+        items = make_batch_np(n, N, A, seed=i, seg=1, agent=3)
+        mem.push_batch(items)
+        flat = {"obs/" + k: v for k, v in items["obs"].items()} | {"next_obs/" + k: v for k, v in items["next_obs"].items()} | \
+               {k: v for k, v in items.items() if not isinstance(v, dict)}
+        if ring is None:
+            ring = {k: np.zeros((cap,) + v.shape[1:], v.dtype) for k, v in flat.items()}
+        for j in range(n):
+            for k, v in flat.items():
+                ring[k][(pos + j) % cap] = v[j]
+        pos, count = (pos + n) % cap, count + n
+    assert len(mem) == cap
+    rs = np.random.RandomState(7)
+    first_ptrs = None
+    for _ in range(3):
+        batch = mem.sample(12).to_torch(device=cuda)
+        idx = rs.randint(0, cap, 12)
+        assert batch.persistent
+        ptrs = (batch["obs"]["xyz"].data_ptr(), batch["rewards"].data_ptr())
+        first_ptrs = first_ptrs or ptrs
+        assert ptrs == first_ptrs                         # staging keeps its addresses
+        for k, v in ring.items():
+            node = batch
+            for part in k.split("/"):
+                node = node[part]
+            np.testing.assert_array_equal(node.cpu().numpy(), v[idx], err_msg=k)
+        assert batch["is_valid"].all() and batch["worker_indices"].shape == (12, 1)
+    # rows drawn in the kernel: in range, uniform, different on every call, and the gathered data are those rows
+    dev = DeviceReplay(cap, device=cuda, seed=11)
+    dev.push_batch(make_batch_np(25, N, A, seed=3, seg=1, agent=3))        # partially filled ring: only rows [0, 25)
+    seen, prev = np.zeros(25), None
+    for _ in range(40):
+        batch = dev.sample(64).to_torch(device=cuda)
+        idx = dev.last_indices(64).cpu().numpy()
+        assert idx.min() >= 0 and idx.max() < 25 and (prev is None or (idx != prev).any())
+        np.testing.assert_array_equal(batch["obs"]["xyz"].cpu().numpy(), dev.storage["obs/xyz"].cpu().numpy()[idx])
+        np.testing.assert_array_equal(batch["actions"].cpu().numpy(), dev.storage["actions"].cpu().numpy()[idx])
+        seen += np.bincount(idx, minlength=25)
+        prev = idx
+    assert seen.min() > 0.6 * seen.mean() and seen.max() < 1.4 * seen.mean()      # 2560 draws over 25 rows
+    with pytest.raises(RuntimeError):
+        DeviceReplay(8, device="cpu")
+
+
+def test_update_from_device_replay_reads_staging_in_place(cuda):
+    """With graphs on, the agent adopts the replay's staging tensors as graph inputs (no copies) and every replay sees the new sample."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 8, 64, 4
+    cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    mem = DeviceReplay(64, device=cuda, seed=3)
+    mem.push_batch(make_batch_np(64, N, A, seed=5))
+    agent.enable_graphs(warmup=1)
+    rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+    assert agent._graphs and agent._static_batch["obs"]["xyz"].data_ptr() == mem._staging[B][0]["obs/xyz"].data_ptr()
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    assert len({round(r["sac/q_target"], 6) for r in rets[4:]}) > 1      # different samples -> different statistics
+
+
+def test_policy_noise_in_kernel_is_standard_normal_and_advances(cuda):
+    from pointcloud_rl_amd import hip
+    B, A = 4096, 6
+    feat = torch.zeros(B, 2 * A, device=cuda)            # mean 0, log_std 0 -> u = eps
+    scale, bias = torch.ones(A, device=cuda), torch.zeros(A, device=cuda)
+    step = torch.zeros(1, dtype=torch.int32, device=cuda)
+    draws = []
+    for s, d in ((0, 0), (0, 1), (1, 0)):
+        step.fill_(s)
+        eps, act, nlp = torch.empty(B, A, device=cuda), torch.empty(B, A, device=cuda), torch.empty(B, device=cuda)
+        hip.tanh_gaussian_sample_fwd(feat, 2 * A, 1234, step, d, eps, scale, bias, B, A, -10.0, 2.0, 1e-6, act, A, nlp)
+        np.testing.assert_allclose(act.cpu().numpy(), np.tanh(eps.cpu().numpy()), atol=1e-6)
+        draws.append(eps.cpu().numpy().ravel())
+    for e in draws:
+        assert abs(e.mean()) < 0.03 and abs(e.std() - 1) < 0.03 and abs((e ** 3).mean()) < 0.08 and abs((e ** 4).mean() - 3) < 0.25
+    assert abs(np.corrcoef(draws[0], draws[1])[0, 1]) < 0.03 and abs(np.corrcoef(draws[0], draws[2])[0, 1]) < 0.03
+
+
+def test_random_downsample_is_an_index_on_the_point_load(cuda):
+    """RandomDownSample (pcd_aug.py:231-268): encoding the stored cloud through the shared index equals encoding the
+    sliced tensors the reference would build -- forward bit for bit (argmax counts subsampled positions), backward too."""
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.augmentations import RandomDownSample
+    from pointcloud_rl_amd.networks.pointnet import materialize
+    B, N = 6, 300
+    obs = make_obs(B, N, seed=8, seg=1)
+    dobs = {k: torch.from_numpy(v).to(cuda) for k, v in obs.items()}
+    torch.manual_seed(5)
+    aug = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=True)
+    out = aug(dobs)
+    index = out.aug["point_index"]
+    assert index.dtype == torch.int32 and index.numel() == N - int(N * 0.3) and index.unique().numel() == index.numel()
+    sliced = materialize(out)
+    assert sliced["xyz"].shape == (B, 3, index.numel()) and torch.equal(sliced["rgb"], dobs["rgb"][..., index.long()])
+    w = make_encoder_weights(7, 128, 128, 256, seed=4)
+    wt = {k: torch.from_numpy(v).to(cuda) for k, v in w.items()}
+    ew, _ = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(7, 128, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    d1, k1 = hip.make_cloud_desc(dobs)
+    a1 = hip.make_aug_desc(**out.aug)
+    p1, i1 = hip.encoder_fwd(d1, ew, packed, aug=a1)
+    d2, k2 = hip.make_cloud_desc({k: v.contiguous() for k, v in sliced.items()})
+    p2, i2 = hip.encoder_fwd(d2, ew, packed)
+    assert torch.equal(p1, p2) and torch.equal(i1, i2) and int(i1.max()) < index.numel()
+    g = torch.randn_like(p1)
+    assert torch.equal(hip.encoder_bwd(d1, ew, packed, i1, g, aug=a1), hip.encoder_bwd(d2, ew, packed, i2, g))
+    # random drop count (fixed_ratio=False) and max_num_points variants
+    np.random.seed(0)
+    k_var = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=False)(dobs).aug["point_index"].numel()
+    assert N - int(N * 0.3) < k_var <= N
+    assert RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], max_num_points=100)(dobs).aug["point_index"].numel() == 100
+    with pytest.raises(NotImplementedError):
+        RandomDownSample(main_key="xyz", req_keys=["xyz"], max_num_points=100)(dobs)       # rgb / seg would keep all points
+    with pytest.raises(RuntimeError):
+        hip.encoder_fwd(d1, ew, packed, aug=hip.make_aug_desc(point_index=torch.zeros(N + 1, dtype=torch.int32, device=cuda)))
+
+
+def test_drq_step_with_random_downsample(cuda):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    cfg = configs.drq_dmc(6, 6, 8, head_hidden=64, obs_aug=dict(type="RandomDownSample", main_key="xyz", req_keys=["xyz", "rgb"],
+                                                                   drop_ratio=0.3, fixed_ratio=True))
+    cfg["env_params"] = configs.env_params({"xyz": [3, 128], "rgb": [3, 128]}, 6)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    agent.enable_graphs(warmup=1)
+    mem = SyntheticReplay(8, 128, 6, seed=2, device=cuda)
+    rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    assert agent._graphs and agent._fused is not None
+    losses = [r["drq/critic_loss"] for r in rets[4:]]
+    assert len(set(np.round(losses, 7))) == len(losses)        # every replay draws a new subset
+
+
+def test_device_replay_without_replacement_walks_the_reference_epoch_order(cuda):
+    """with_replacement=False: the index stream equals SamplingStrategy.get_index's (sampling_strategy.py:32-48) for the same
+    seed -- shuffled epoch order, re-shuffled when exhausted, re-drawn after a push -- and every epoch visits each row once."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A, B = 24, 16, 3, 5
+    mem = DeviceReplay(cap, device=cuda, seed=3, with_replacement=False)
+    mem.push_batch(make_batch_np(cap, N, A, seed=1))
+    rs = np.random.RandomState(3)
+    items = np.arange(cap); rs.shuffle(items); pos = 0
+    seen = []
+    for _ in range(9):                      # 4 batches per epoch (drop_last), then a re-shuffle
+        if pos + B > cap:
+            rs.shuffle(items); pos = 0
+        want = items[pos:pos + B]; pos += B
+        batch = mem.sample(B).to_torch(device=cuda)
+        np.testing.assert_array_equal(mem.last_indices(B).cpu().numpy(), want)
+        np.testing.assert_array_equal(batch["rewards"].cpu().numpy(), mem.storage["rewards"].cpu().numpy()[want])
+        seen.append(want)
+    assert len(np.unique(np.concatenate(seen[:4]))) == 4 * B
+    assert mem.sample(cap + 1, auto_restart=False) is None      # cannot be served without a restart
+
+
+@pytest.mark.parametrize("mode", ["with", "without"])
+def test_device_replay_reproduces_the_reference_replay_memory(cuda, mode):
+    """tests/golden/ref_replay.npz was produced by the reference's ReplayMemory + OneStepTransition (tools/gen_golden_replay.py):
+    the same pushes (the third wraps around the ring) and the same seed give the same ten sampled batches, key by key."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_replay.npz"))
+    mem = DeviceReplay(40, device=cuda, seed=7, with_replacement=(mode == "with"), host_rng=True)
+    for i in range(3):
+        items = {}
+        for k in z.files:
+            if k.startswith(f"push{i}/"):
+                node, parts = items, k.split("/")[1:]
+                for part in parts[:-1]:
+                    node = node.setdefault(part, {})
+                node[parts[-1]] = z[k]
+        mem.push_batch(items)
+    assert [len(mem), mem.position] == z[f"{mode}/len_position"].tolist()
+    for s in range(10):
+        batch = mem.sample(6).to_torch(device=cuda)
+        keys = [k for k in z.files if k.startswith(f"{mode}/sample{s}/")]
+        assert keys
+        for k in keys:
+            node = batch
+            for part in k.split("/")[2:]:
+                node = node[part]
+            np.testing.assert_array_equal(node.cpu().numpy(), z[k], err_msg=k)
+
+
+@pytest.mark.parametrize("tag,kw", [("ratio", dict(drop_ratio=0.3, fixed_ratio=True)), ("maxpts", dict(max_num_points=17))])
+def test_random_downsample_matches_the_reference_class(cuda, tag, kw):
+    """tests/golden/ref_downsample.npz: what the reference's RandomDownSample returned (tools/gen_golden_downsample.py).  With the
+    reference's index injected, this class keeps the same number of points and `materialize` yields the same tensors for every key."""
+    from pointcloud_rl_amd.augmentations import RandomDownSample
+    from pointcloud_rl_amd.networks.pointnet import materialize
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_downsample.npz"))
+    obs = {k: torch.from_numpy(z[f"in/{k}"]).to(cuda) for k in ("xyz", "rgb", "seg")}
+    aug = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], **kw)
+    torch.manual_seed(0)
+    assert aug(obs).aug["point_index"].numel() == int(z[f"{tag}/n"])          # same count from the same keywords
+    aug.index_override = [torch.from_numpy(z[f"{tag}/index"])]
+    got = materialize(aug(obs))
+    for k in ("xyz", "rgb", "seg"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), z[f"{tag}/out/{k}"], err_msg=k)
+
+
+def test_acting_matches_the_reference_agent_loaded_from_its_checkpoint(cuda):
+    """The reference agent that wrote tests/golden/ref_sac_dmc_small.ckpt also acted on a small observation
+    (tools/gen_golden_checkpoint.py -> ref_sac_dmc_small_acting.npz).  Loading its checkpoint here and acting on the same
+    observation gives the same actions (1e-5) in the deterministic modes."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.utils.checkpoint import load_checkpoint
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    cfg = configs.sac_dmc(6, 6, 8, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 64], "rgb": [3, 64]}, 6)
+    agent = build_agent(cfg)
+    load_checkpoint(agent, os.path.join(gold, "ref_sac_dmc_small.ckpt"), map_location="cpu", strict=True)
+    agent = agent.to(cuda).eval()
+    z = np.load(os.path.join(gold, "ref_sac_dmc_small_acting.npz"))
+    obs = {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith("obs/")}
+    for mode in ("eval", "mean"):
+        got = agent(obs, mode=mode)
+        np.testing.assert_allclose(got.cpu().numpy(), z[mode], atol=1e-5, rtol=0, err_msg=mode)
+    acts, states = agent(obs, mode="eval", rnn_mode="with_states")
+    assert states is None and torch.equal(acts, agent(obs, mode="eval"))

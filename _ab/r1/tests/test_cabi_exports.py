@@ -1,0 +1,68 @@
+"""The C-ABI shared object loads on a machine without a GPU and exports every symbol include/pcrl.h
+declares; argument validation that happens before any HIP call reports errors through the ABI."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pcrl.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcrl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_symbols()
+    for required in ("pcrl_encoder_fwd_f32", "pcrl_encoder_bwd_f32", "pcrl_encoder_pack_weights_f32", "pcrl_gemm_f32", "pcrl_gemm_group_f32",
+                     "pcrl_tanh_gaussian_fwd_f32", "pcrl_tanh_gaussian_bwd_f32", "pcrl_sac_critic_loss_f32",
+                     "pcrl_sac_actor_loss_f32", "pcrl_adam_step_f32", "pcrl_polyak_f32", "pcrl_last_error", "pcrl_version"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol():
+    from pointcloud_rl_amd import _lib
+    lib = _lib.lib()
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/pcrl.h but not exported by libpcrl_hip.so"
+    assert lib.pcrl_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from pointcloud_rl_amd import _lib
+    lib = _lib.lib()
+    n = ctypes.c_size_t()
+    assert lib.pcrl_encoder_packed_bytes(6, 64, 128, 256, ctypes.byref(n)) == 0 and n.value > 4 * (64 * 6 + 128 * 64 + 256 * 128)
+    rc = lib.pcrl_encoder_packed_bytes(6, 64, 128, 1024, ctypes.byref(n))      # c3 = 1024: not supported by the fused kernel
+    assert rc == -1 and b"unsupported encoder dims" in lib.pcrl_last_error()
+    assert lib.pcrl_encoder_packed_bytes(17, 64, 128, 256, ctypes.byref(n)) == -1            # more than 16 channels
+    assert lib.pcrl_encoder_fwd_f32(None, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1
+    assert lib.pcrl_gemm_f32(None, None) == -1
+    with pytest.raises(_lib.PcrlError):
+        _lib.check(-1)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/pcrl.h as gcc lays it out == the ctypes mirror in _lib.py."""
+    import subprocess
+    from pointcloud_rl_amd import _lib
+    pairs = [("pcrl_feat_seg", _lib.FeatSeg), ("pcrl_cloud_desc", _lib.CloudDesc), ("pcrl_aug_desc", _lib.AugDesc),
+             ("pcrl_encoder_weights", _lib.EncoderWeights), ("pcrl_gemm_desc", _lib.GemmDesc), ("pcrl_ln_job", _lib.LnJob),
+             ("pcrl_gather_seg", _lib.GatherSeg), ("pcrl_adam_pending", _lib.AdamPending)]
+    lines = []
+    for cname, cls in pairs:
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pcrl.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"

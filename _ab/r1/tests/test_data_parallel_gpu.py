@@ -1,0 +1,119 @@
+"""GPU test of the data-parallel update: two ranks (sharing the one GPU of the test box, `gloo` for the
+exchange -- RCCL refuses two ranks on one device) each own half of the batch.  With the same injected
+noise the sharded update must equal the single-process update on the whole batch, and the replicas must
+stay identical, both eagerly and when the step is replayed from per-segment hipGraphs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+B, N, A, STEPS = 16, 96, 6, 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _agent(batch_size):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    cfg = configs.sac_dmc(6, A, batch_size, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    return build_agent(cfg).to("cuda:0")
+
+
+def _eps(u):
+    g = torch.Generator().manual_seed(1000 + u)
+    return [torch.randn(B, A, generator=g) for _ in range(2)]
+
+
+def _memory(sl):
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    from pointcloud_rl_amd.utils.torch_utils import to_torch
+    full = SyntheticReplay(B, N, A, seed=9)
+    shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
+    mem = SyntheticReplay.__new__(SyntheticReplay)
+    mem.batch_np, mem.batch = shard, to_torch(shard, device="cuda:0")
+    return mem
+
+
+def _worker(rank, world, port, graphs, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pointcloud_rl_amd.utils.dist import broadcast_parameters_, shard_slice
+    sl = shard_slice(B, rank, world)
+    agent = _agent(B // world)
+    broadcast_parameters_(agent)
+    agent.to_ddp(device_ids=["cuda"])
+    if graphs:
+        agent.enable_graphs(warmup=1)
+    mem = _memory(sl)
+    for u in range(1, STEPS + 1 + (4 if graphs else 0)):
+        if not graphs:
+            agent.actor.head.noise_override = [e[sl].to("cuda:0") for e in _eps(u)][:2 if u % 2 == 0 else 1]
+        ret = agent.update_parameters(mem, u)
+        assert np.isfinite(list(ret.values())).all()
+    if graphs:
+        assert all(len(segs) >= 2 for segs, _, _ in agent._graphs.values())      # cut at every exchange
+    torch.save({n: p.detach().cpu() for n, p in agent.named_parameters()}, os.path.join(out, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _run(graphs):
+    import tempfile
+    with tempfile.TemporaryDirectory() as out:          # results come back through files (no manager process to lose)
+        mp.spawn(_worker, args=(2, _free_port(), graphs, out), nprocs=2, join=True)
+        return tuple(torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2))
+
+
+def test_sharded_update_equals_whole_batch_update(cuda):
+    p0, p1 = _run(graphs=False)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n                    # replicas identical
+    agent = _agent(B)
+    mem = _memory(slice(0, B))
+    for u in range(1, STEPS + 1):
+        agent.actor.head.noise_override = [e.to("cuda:0") for e in _eps(u)][:2 if u % 2 == 0 else 1]
+        agent.update_parameters(mem, u)
+    for n, p in agent.named_parameters():
+        err = (p.detach().cpu() - p0[n]).abs()
+        assert (err <= 1e-5).float().mean() >= 0.999 and err.max() <= 2e-4, (n, float(err.max()))
+
+
+def test_segmented_graph_replay_keeps_replicas_identical(cuda):
+    p0, p1 = _run(graphs=True)
+    for n in p0:
+        assert torch.equal(p0[n], p1[n]), n
+        assert torch.isfinite(p0[n]).all()
+
+
+def test_bench_two_ranks_prints_the_contract_line(cuda):
+    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, one rank per GPU), here with two ranks sharing the
+    test box's GPU over gloo: rank 0 prints exactly one JSON line with the contract's keys, strong scaling at global B=256."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
+           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--replay-capacity", "512"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 128
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3 * 1e3
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}

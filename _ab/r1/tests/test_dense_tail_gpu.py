@@ -1,0 +1,229 @@
+"""GPU parity of the dense-head and update-tail kernels (C ABI) vs the same math in PyTorch on the CPU."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(256, 56, 1024, True), (256, 1024, 1024, True), (256, 1024, 12, False), (37, 50, 70, True), (5, 3, 1, False)])
+def test_linear_forward(cuda, M, K, N, relu):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(M + K + N)
+    x, w, b = g.randn(M, K).astype(np.float32), (g.randn(N, K) / np.sqrt(K)).astype(np.float32), g.randn(N).astype(np.float32)
+    X, W, Bv = T(x, cuda), T(w, cuda), T(b, cuda)
+    Y = torch.empty(M, N, device=cuda)
+    hip.gemm(X, W, Y, M, N, K, (K, 1), (1, K), N, bias=Bv, relu=relu)
+    ref = F.linear(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b))
+    ref = F.relu(ref) if relu else ref
+    np.testing.assert_allclose(Y.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_linear_backward_and_batched(cuda):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(0)
+    H, M, K, N = 2, 256, 56, 1024
+    x = g.randn(H, M, K).astype(np.float32)
+    act = np.maximum(g.randn(H, M, K), 0).astype(np.float32)           # the layer input as a ReLU output (mask)
+    w = (g.randn(H, N, K) / np.sqrt(K)).astype(np.float32)
+    dy = g.randn(H, M, N).astype(np.float32)
+    X, ACT, W, DY = T(x, cuda), T(act, cuda), T(w, cuda), T(dy, cuda)
+    # data gradient with the ReLU mask of the layer input, both heads in one launch
+    DX = torch.empty(H, M, K, device=cuda)
+    hip.gemm(DY, W, DX, M, K, N, (N, 1), (K, 1), K, mask=ACT, ld_mask=K, batch=H, batch_strides=(M * N, N * K, M * K, 0, M * K))
+    ref_dx = torch.einsum("hmn,hnk->hmk", torch.from_numpy(dy), torch.from_numpy(w)) * (torch.from_numpy(act) > 0)
+    np.testing.assert_allclose(DX.cpu().numpy(), ref_dx.numpy(), atol=1e-4, rtol=1e-5)
+    # weight + bias gradient: dW|db = dy^T [x | 1]
+    DWB = torch.empty(H, N, K + 1, device=cuda)
+    hip.gemm(DY, X, DWB, N, K + 1, M, (1, N), (K, 1), K + 1, ones_col=K, batch=H, batch_strides=(M * N, M * K, N * (K + 1), 0, 0))
+    ref_dw = torch.einsum("hmn,hmk->hnk", torch.from_numpy(dy), torch.from_numpy(x))
+    ref_db = torch.from_numpy(dy).sum(1)
+    np.testing.assert_allclose(DWB[:, :, :K].cpu().numpy(), ref_dw.numpy(), atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(DWB[:, :, K].cpu().numpy(), ref_db.numpy(), atol=2e-4, rtol=1e-5)
+
+
+def test_layernorm_rows(cuda):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(1)
+    M, Fd = 77, 50
+    x, gam, bet = g.randn(M, Fd).astype(np.float32), g.uniform(0.5, 1.5, Fd).astype(np.float32), g.randn(Fd).astype(np.float32)
+    dy0, dy1 = g.randn(M, 64).astype(np.float32), g.randn(M, 64).astype(np.float32)
+    X, G, Bt = T(x, cuda), T(gam, cuda), T(bet, cuda)
+    out_a, out_b = torch.zeros(M, 56, device=cuda), torch.zeros(M, 64, device=cuda)
+    xhat, rstd = torch.empty(M, Fd, device=cuda), torch.empty(M, device=cuda)
+    hip.layernorm_rows_fwd(X, Fd, G, Bt, M, Fd, 1e-5, [(out_a, 0, 56), (out_b, 0, 64)], xhat, rstd)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    gt, bt = torch.from_numpy(gam).requires_grad_(True), torch.from_numpy(bet).requires_grad_(True)
+    ref = F.layer_norm(xt, (Fd,), gt, bt, 1e-5)
+    np.testing.assert_allclose(out_a[:, :Fd].cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(out_b[:, :Fd].cpu().numpy(), ref.detach().numpy(), atol=2e-6)
+    assert (out_a[:, Fd:] == 0).all()
+    D0, D1 = T(dy0, cuda), T(dy1, cuda)
+    dx, dg, db = torch.empty(M, Fd, device=cuda), torch.empty(Fd, device=cuda), torch.empty(Fd, device=cuda)
+    ws = torch.empty(((M + 3) // 4) * 2 * Fd * 4, dtype=torch.uint8, device=cuda)
+    hip.layernorm_rows_bwd(D0.data_ptr(), D1.data_ptr(), 64, xhat, rstd, G, M, Fd, dx, Fd, dg, db, ws)
+    ref.backward(torch.from_numpy(dy0[:, :Fd] + dy1[:, :Fd]))
+    np.testing.assert_allclose(dx.cpu().numpy(), xt.grad.numpy(), atol=1e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), gt.grad.numpy(), atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bt.grad.numpy(), atol=1e-4)
+
+
+def test_tanh_gaussian_forward_backward(cuda):
+    from oracle import torch_ref
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(2)
+    B, A = 130, 6
+    feat = (g.randn(B, 2 * A) * 1.5).astype(np.float32)
+    feat[0, A] = -30.0          # below the clamp: zero gradient to log_std
+    feat[1, A + 1] = 5.0        # above the clamp
+    eps = g.randn(B, A).astype(np.float32)
+    scale, bias = g.uniform(0.5, 2.0, A).astype(np.float32), g.randn(A).astype(np.float32)
+    da = g.randn(B, A).astype(np.float32)
+    d_nlp = np.float32(-0.013)
+    ft = torch.from_numpy(feat).requires_grad_(True)
+    a_ref, nlp_ref = torch_ref.tanh_gaussian(ft, torch.from_numpy(eps), torch.from_numpy(scale), torch.from_numpy(bias))
+    ((a_ref * torch.from_numpy(da)).sum() + (nlp_ref * float(d_nlp)).sum()).backward()
+    Fd, E, S, Bi = T(feat, cuda), T(eps, cuda), T(scale, cuda), T(bias, cuda)
+    act, act2 = torch.empty(B, A, device=cuda), torch.zeros(B, 20, device=cuda)
+    nlp, saved = torch.empty(B, device=cuda), torch.empty(B, 2 * A, device=cuda)
+    hip.tanh_gaussian_fwd(Fd, 2 * A, E, S, Bi, B, A, -10.0, 2.0, 1e-6, act, A, nlp, saved, action2_ptr=act2.data_ptr() + 4 * 14, ld_action2=20)
+    np.testing.assert_allclose(act.cpu().numpy(), a_ref.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(act2[:, 14:].cpu().numpy(), a_ref.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(nlp.cpu().numpy(), nlp_ref.detach().numpy()[:, 0], atol=2e-5, rtol=1e-5)
+    dfeat = torch.empty(B, 2 * A, device=cuda)
+    DA, DN = T(da, cuda), torch.tensor([d_nlp], device=cuda)     # raw pointers below: keep the tensors alive
+    hip.tanh_gaussian_bwd(Fd, 2 * A, E, saved, S, B, A, -10.0, 2.0, 1e-6, DA.data_ptr(), None, A, DN, dfeat, 2 * A)
+    torch.cuda.synchronize()
+    got, want = dfeat.cpu().numpy(), ft.grad.numpy()
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=2e-4)
+    assert got[0, A] == 0.0 and got[1, A + 1] == 0.0
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_critic_and_actor_loss(cuda, group):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(3)
+    B, H = 256 * group, 2
+    qn, q = g.randn(B, H).astype(np.float32), g.randn(B, H).astype(np.float32)
+    nlp, r = g.randn(B).astype(np.float32), g.randn(B).astype(np.float32)
+    done = g.rand(B) < 0.2
+    log_alpha = np.float32(math.log(0.1))
+    gamma, rs = 0.99, 1.0 if group > 1 else 0.7
+    qt = torch.from_numpy(q).requires_grad_(True)
+    alpha = float(torch.tensor(log_alpha).exp())
+    y = torch.from_numpy(r)[:, None] * rs + (1 - torch.from_numpy(done).float()[:, None]) * gamma * (
+        torch.from_numpy(qn).min(-1, keepdim=True).values + alpha * torch.from_numpy(nlp)[:, None])
+    if group > 1:
+        y = y.reshape(B // group, group).mean(1, keepdim=True).repeat_interleave(group, 0)
+    yy = y.repeat(1, H)
+    loss = F.mse_loss(qt, yy) * H
+    loss.backward()
+    out_y, dq, stats = torch.empty(B, device=cuda), torch.empty(B, H, device=cuda), torch.empty(4, device=cuda)
+    hip.sac_critic_loss(T(qn, cuda), H, T(nlp, cuda), T(r, cuda), T(done.astype(np.uint8), cuda), torch.tensor([log_alpha], device=cuda),
+                        gamma, rs, False, group, T(q, cuda), H, B, H, out_y, dq, H, stats)
+    np.testing.assert_allclose(out_y.cpu().numpy(), y[:, 0].numpy(), atol=2e-6)
+    np.testing.assert_allclose(dq.cpu().numpy(), qt.grad.numpy(), atol=1e-7, rtol=1e-5)
+    want = [loss.item(), (qt - yy).abs().max().item(), qt.min(-1).values.mean().item(), yy.mean().item()]
+    np.testing.assert_allclose(stats.cpu().numpy(), want, rtol=2e-5, atol=1e-6)
+    # actor / alpha loss
+    qp = torch.from_numpy(q).requires_grad_(True)
+    nl = torch.from_numpy(nlp).requires_grad_(True)
+    ent = nl.mean()
+    aloss = -(qp.min(-1, keepdim=True).values.mean() + alpha * ent)
+    aloss.backward()
+    la = torch.tensor([log_alpha], requires_grad=True)
+    alpha_loss = la.exp() * (ent.detach() - (-6.0))
+    alpha_loss.backward()
+    dq2, dn, ag, st = torch.empty(B, H, device=cuda), torch.empty(1, device=cuda), torch.empty(1, device=cuda), torch.empty(3, device=cuda)
+    hip.sac_actor_loss(T(q, cuda), H, T(nlp, cuda), torch.tensor([log_alpha], device=cuda), -6.0, B, H, dq2, H, dn, ag, st)
+    np.testing.assert_allclose(dq2.cpu().numpy(), qp.grad.numpy(), atol=1e-9)
+    np.testing.assert_allclose(dn.item(), nl.grad[0].item(), rtol=1e-6)
+    np.testing.assert_allclose(ag.item(), la.grad.item(), rtol=1e-5)
+    np.testing.assert_allclose(st.cpu().numpy(), [aloss.item(), ent.item(), alpha_loss.item()], rtol=2e-5, atol=1e-6)
+
+
+def test_gemm_group_matches_single_launches(cuda):
+    """dW|db, dx and two unrelated shapes in one launch give the same bits as separate launches."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(5)
+    M, K, N = 256, 1024, 1024
+    dy, x, w = g.randn(M, N).astype(np.float32), g.randn(M, K).astype(np.float32), (g.randn(N, K) / 32).astype(np.float32)
+    x2, w2 = g.randn(70, 50).astype(np.float32), g.randn(33, 50).astype(np.float32)
+    DY, X, W, X2, W2 = T(dy, cuda), T(x, cuda), T(w, cuda), T(x2, cuda), T(w2, cuda)
+
+    def descs(dwb, dx, y2, y3):
+        return [hip.gemm_desc(DY, X, dwb, N, K + 1, M, (1, N), (K, 1), K + 1, ones_col=K),
+                hip.gemm_desc(DY, W, dx, M, K, N, (N, 1), (K, 1), K),
+                hip.gemm_desc(X2, W2, y2, 70, 33, 50, (50, 1), (1, 50), 33, relu=True),
+                hip.gemm_desc(X, W, y3, M, N, K, (K, 1), (1, K), N)]
+    outs_a = [torch.zeros(N, K + 1, device=cuda), torch.zeros(M, K, device=cuda), torch.zeros(70, 33, device=cuda), torch.zeros(M, N, device=cuda)]
+    outs_b = [torch.zeros_like(o) for o in outs_a]
+    hip.gemm_group(descs(*outs_a))
+    for d in descs(*outs_b):
+        hip.gemm_group([d])
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(outs_a[0][:, :K].cpu().numpy(), dy.T @ x, atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[0][:, K].cpu().numpy(), dy.sum(0), atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[1].cpu().numpy(), dy @ w, atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[2].cpu().numpy(), np.maximum(x2 @ w2.T, 0), atol=2e-5, rtol=1e-5)
+    with pytest.raises(RuntimeError):
+        hip.gemm_group(descs(*outs_a) + descs(*outs_a)[:1])          # more than 4 problems
+
+
+def test_layernorm_rows_multi_job_with_pass_through_columns(cuda):
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(3)
+    Fd = 50
+    G, Bt = T(g.randn(Fd).astype(np.float32), cuda), T(g.randn(Fd).astype(np.float32), cuda)
+    jobs, wants = [], []
+    for M in (37, 256):
+        x, st, ac = g.randn(M, Fd).astype(np.float32), g.randn(M, 5).astype(np.float32), g.randn(M, 6).astype(np.float32)
+        X, ST, AC = T(x, cuda), T(st, cuda), T(ac, cuda)
+        dst = torch.zeros(M, 64, device=cuda)
+        jobs.append(dict(x=X, ldx=Fd, M=M, dsts=[(dst, 0, 64)], cats=[(ST, dst, Fd, 64), (AC, dst, Fd + 5, 64)], keep=(X, ST, AC, dst)))
+        ref = F.layer_norm(torch.from_numpy(x), (Fd,), G.cpu(), Bt.cpu(), 1e-5)
+        wants.append(np.concatenate([ref.numpy(), st, ac, np.zeros((M, 64 - Fd - 11), np.float32)], 1))
+    hip.layernorm_rows_fwd_multi(jobs, G, Bt, Fd, 1e-5)
+    for job, want in zip(jobs, wants):
+        np.testing.assert_allclose(job["keep"][3].cpu().numpy(), want, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("defer", [False, True], ids=["finalize-now", "finalize-in-gather"])
+def test_fused_adam_polyak_gradnorm_matches_torch(cuda, defer):
+    """pcrl_adam_step_f32 == torch.optim.Adam (+ soft_update on a parameter range, + grad 2-norm, + device step count),
+    with the pass's second half either launched right away or deferred into pcrl_gather_scalars_f32."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(2)
+    n, t0, t1, tau = 10_007, 4_000, 10_007, 0.01
+    w0 = g.randn(n).astype(np.float32)
+    p_ref = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+    opt = torch.optim.Adam([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    tgt_ref = torch.from_numpy(g.randn(t1 - t0).astype(np.float32))
+    P, M, V = T(w0, cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    TG = tgt_ref.clone().to(cuda)
+    step, norm = torch.zeros(1, dtype=torch.int32, device=cuda), torch.zeros(1, device=cuda)
+    ws = torch.empty(hip.adam_workspace_bytes(n), dtype=torch.uint8, device=cuda)
+    seen = torch.zeros(2, device=cuda)
+    for it in range(3):
+        grad = g.randn(n).astype(np.float32) * (10.0 ** -it)
+        p_ref.grad = torch.from_numpy(grad * 0.5)
+        opt.step()
+        tgt_ref = tgt_ref * (1 - tau) + p_ref.detach()[t0:t1] * tau
+        pend = hip.adam_step(P, T(grad, cuda), M, V, 1e-3, 0.9, 0.999, 1e-8, 0.5, step, norm, ws, target=TG, target_begin=t0,
+                             target_end=t1, tau=tau, defer=defer)
+        if defer:
+            assert pend is not None and int(step.item()) == it         # the count advances only when the pass is finished
+            hip.gather_scalars([(norm, seen[0:], False), (P[5:], seen[1:], True)], pending=[pend])
+            assert abs(float(seen[0]) - float(norm)) == 0 and abs(float(seen[1]) - np.exp(float(P[5]))) < 1e-6
+        assert int(step.item()) == it + 1
+        np.testing.assert_allclose(float(norm), np.linalg.norm(grad * 0.5), rtol=1e-5)
+        np.testing.assert_allclose(P.cpu().numpy(), p_ref.detach().numpy(), atol=2e-6, rtol=0)
+        np.testing.assert_allclose(TG.cpu().numpy(), tgt_ref.numpy(), atol=2e-6, rtol=0)

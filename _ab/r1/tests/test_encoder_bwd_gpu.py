@@ -1,0 +1,173 @@
+"""GPU parity: HIP encoder backward (C ABI) vs autograd through the PyTorch-CPU restatement."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_encoder_weights, make_obs
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {"conv0.weight": "w0", "conv0.bias": "b0", "conv1.weight": "w1", "norm1.weight": "g1", "norm1.bias": "be1",
+         "conv2.weight": "w2", "norm2.weight": "g2", "norm2.bias": "be2"}
+
+
+def torch_reference_grads(obs_np, w_np, gpool_np, jitter=None):
+    from oracle import torch_ref
+    P = {}
+    for ref_name, k in NAMES.items():
+        t = torch.from_numpy(np.ascontiguousarray(w_np[k])).clone()
+        if t.ndim == 2:
+            t = t[..., None]
+        P[torch_ref.ENC + "conv.mlp." + ref_name] = t.requires_grad_(True)
+    obs = {k: torch.from_numpy(v) for k, v in obs_np.items()}
+    if jitter is not None:
+        obs["xyz"] = obs["xyz"] + torch.from_numpy(jitter)
+    pre = torch_ref.pointnet_prepool(P, obs)
+    pooled, idx = pre.max(-1)
+    (pooled * torch.from_numpy(gpool_np)).sum().backward()
+    return {n: P[torch_ref.ENC + "conv.mlp." + n].grad.numpy() for n in NAMES}, idx.numpy().astype(np.int32), pooled.detach().numpy()
+
+
+def hip_grads(obs_np, w_np, gpool_np, dev, jitter=None, with_pooled=True):
+    from pointcloud_rl_amd import hip
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in w_np.items()}
+    ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=dev)
+    hip.encoder_pack_weights(ew, packed)
+    obs = {k: torch.from_numpy(v).to(dev) for k, v in obs_np.items()}
+    desc, keep = hip.make_cloud_desc(obs)
+    aug = None
+    if jitter is not None:
+        jt = torch.from_numpy(jitter).to(dev)
+        aug = hip.make_aug_desc(jitter_noise=jt)
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug)
+    flat, n_act = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool_np).to(dev), aug=aug, want_n_active=True,
+                                  pooled=pooled if with_pooled else None)
+    views = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
+    torch.cuda.synchronize()
+    return views, argmax.cpu().numpy(), pooled.cpu().numpy(), n_act.cpu().numpy()
+
+
+def assert_grads_close(got, ref):
+    for name in NAMES:
+        g, r = got[name].reshape(-1), ref[name].reshape(-1)
+        scale = max(np.abs(r).max(), 1e-6)
+        err = np.abs(g - r).max() / scale
+        assert err < 2e-5, f"{name}: max rel-to-max err {err:.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("B,N,extra,c1", [
+    (3, 64, dict(), 64),                 # n_active <= 64: two tiles per cloud at most
+    (2, 400, dict(), 64),                # many active points, several waves busy
+    (4, 37, dict(), 64),                 # ragged N < 64
+    (2, 300, dict(pos_encoding=3), 64),  # C = 9
+    (3, 250, dict(seg=1), 128),          # ManiSkill nets: C = 7, c1 = 128
+    (1, 1, dict(), 64),                  # a single point owns every channel
+])
+def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
+    obs = make_obs(B, N, seed=17 * B + N, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, c1, 128, 256, seed=N + 1)
+    gpool = np.random.RandomState(N).randn(B, 256).astype(np.float32)
+    ref, idx_ref, pooled_ref = torch_reference_grads(obs, w, gpool)
+    got, idx, pooled, n_act = hip_grads(obs, w, gpool, cuda)
+    assert np.array_equal(idx, idx_ref)
+    np.testing.assert_allclose(pooled, pooled_ref, atol=1e-5, rtol=0)
+    assert np.array_equal(n_act, [len(np.unique(r)) for r in idx_ref])
+    assert_grads_close(got, ref)
+    # the same without the forward's pooled values (dense search for the owned channels)
+    got_dense, _, _, _ = hip_grads(obs, w, gpool, cuda, with_pooled=False)
+    assert_grads_close(got_dense, ref)
+
+
+def test_bwd_with_jitter_noise(cuda):
+    obs = make_obs(3, 200, seed=5)
+    w = make_encoder_weights(6, 64, 128, 256, seed=9)
+    gpool = np.random.RandomState(1).randn(3, 256).astype(np.float32)
+    jitter = np.random.RandomState(2).uniform(-0.01, 0.01, (3, 3, 200)).astype(np.float32)
+    ref, idx_ref, _ = torch_reference_grads(obs, w, gpool, jitter)
+    got, idx, _, _ = hip_grads(obs, w, gpool, cuda, jitter)
+    assert np.array_equal(idx, idx_ref)
+    assert_grads_close(got, ref)
+
+
+def test_bwd_is_deterministic_and_linear(cuda):
+    # size-independent properties at the K1 launch geometry: bitwise reproducible, linear in grad_pooled
+    obs = make_obs(256, 1024, seed=1)
+    w = make_encoder_weights(6, 64, 128, 256, seed=0)
+    g1 = np.random.RandomState(3).randn(256, 256).astype(np.float32)
+    g2 = np.random.RandomState(4).randn(256, 256).astype(np.float32)
+    a, _, _, n_act = hip_grads(obs, w, g1, cuda)
+    a2, _, _, _ = hip_grads(obs, w, g1, cuda)
+    b, _, _, _ = hip_grads(obs, w, g2, cuda)
+    c, _, _, _ = hip_grads(obs, w, (g1 + g2), cuda)
+    assert (n_act >= 1).all() and (n_act <= 256).all()
+    for name in NAMES:
+        assert np.array_equal(a[name], a2[name]), name
+        scale = np.abs(c[name]).max()
+        assert np.abs(a[name] + b[name] - c[name]).max() <= 2e-5 * scale, name
+    # a slice of the batch against the oracle (per-cloud partial sums are independent)
+    sel = slice(0, 3)
+    obs_s = {k: v[sel] for k, v in obs.items()}
+    ref, _, _ = torch_reference_grads(obs_s, w, g1[sel])
+    got, _, _, _ = hip_grads(obs_s, w, g1[sel], cuda)
+    assert_grads_close(got, ref)
+
+
+def _bf16_reference_grads(obs_np, w_np, gpool_np, eps=1e-6):
+    """Autograd through the rounding emulation of the mixed-precision forward, roundings straight-through."""
+    import torch.nn.functional as F
+    from oracle import c_oracle
+    x = torch.from_numpy(c_oracle.preprocess(obs_np))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).clone().requires_grad_(True) for k, v in w_np.items()}
+    st = lambda a: a + (a.to(torch.bfloat16).to(torch.float32) - a).detach()
+    h0 = F.relu(torch.einsum("oc,bcn->bon", t["w0"], x) + t["b0"][None, :, None])
+    z1 = torch.einsum("oc,bcn->bon", st(t["w1"]), st(h0))
+    h1 = F.relu(F.layer_norm(z1.permute(0, 2, 1), (z1.shape[1],), t["g1"], t["be1"], eps).permute(0, 2, 1))
+    z2 = torch.einsum("oc,bcn->bon", st(t["w2"]), st(h1))
+    h2 = F.relu(F.layer_norm(z2.permute(0, 2, 1), (z2.shape[1],), t["g2"], t["be2"], eps).permute(0, 2, 1))
+    return t, h2
+
+
+@pytest.mark.parametrize("B,N,extra,c1", [(3, 200, dict(), 64), (2, 1200, dict(seg=1), 128)])
+def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, c1):
+    """Mixed-precision backward: gradients w.r.t. the fp32 master weights of the function the bf16 forward computes.
+    The kernel's own argmax is used to pick the pooled points of the emulation (a rounding tie may move an argmax, which
+    is a different -- equally valid -- subgradient).  Tolerance: 3e-2 of each tensor's largest gradient entry."""
+    from pointcloud_rl_amd import hip
+    obs = make_obs(B, N, seed=23, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, c1, 128, 256, seed=6)
+    gpool = np.random.RandomState(N).randn(B, 256).astype(np.float32)
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda) for k, v in w.items()}
+    ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep = hip.make_cloud_desc({k: torch.from_numpy(v).to(cuda) for k, v in obs.items()})
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=True)
+    flat = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True)
+    got = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
+    t, h2 = _bf16_reference_grads(obs, w, gpool)
+    picked = torch.gather(h2, 2, argmax.cpu().long()[:, :, None])[:, :, 0]
+    np.testing.assert_allclose(pooled.cpu().numpy(), picked.detach().numpy(), atol=3e-2, rtol=0)
+    (picked * torch.from_numpy(gpool)).sum().backward()
+    for name, k in NAMES.items():
+        g, r = got[name].reshape(-1), t[k].grad.numpy().reshape(-1)
+        scale = max(np.abs(r).max(), 1e-6)
+        assert np.abs(g - r).max() / scale < 3e-2, f"{name}: {np.abs(g - r).max() / scale:.3e}"
+    # bitwise reproducible
+    assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True))
+
+
+def test_bwd_zero_gamma_falls_back_to_the_dense_path(cuda):
+    """norm2.weight == 0 on some channels: xhat cannot be recovered from pooled there, the kernel must take the dense path for
+    the cloud and still match autograd."""
+    obs = make_obs(2, 150, seed=31)
+    w = make_encoder_weights(6, 64, 128, 256, seed=7)
+    w["g2"] = w["g2"].copy(); w["g2"][::5] = 0.0
+    w["be2"] = np.abs(w["be2"]) + 0.1                     # y = beta > 0 on those channels: they are live
+    gpool = np.random.RandomState(5).randn(2, 256).astype(np.float32)
+    ref, idx_ref, _ = torch_reference_grads(obs, w, gpool)
+    got, idx, _, _ = hip_grads(obs, w, gpool, cuda)
+    assert np.array_equal(idx, idx_ref)
+    assert_grads_close(got, ref)

@@ -1,0 +1,225 @@
+"""GPU parity of the whole update step: pointcloud_rl_amd SAC / DrQ agents (HIP encoder forward and
+backward through the C ABI) vs golden vectors captured from the reference's update_parameters."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STEP_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "sac_*.npz")) + glob.glob(os.path.join(GOLDEN, "drq_*.npz")))
+
+
+class Memory:
+    """Stand-in for ReplayMemory: .sample(bs) -> object with .to_torch(device=, non_blocking=) (sac.py:104)."""
+
+    def __init__(self, batch):
+        self.batch = batch
+
+    def sample(self, batch_size):
+        return self
+
+    def to_torch(self, device=None, non_blocking=False):
+        from pointcloud_rl_amd.utils.torch_utils import to_torch
+        return to_torch(self.batch, device=device, non_blocking=non_blocking)
+
+
+def build_from_fixture(d, dev, fused=True):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    B, N, A, S, n_updates = [int(x) for x in d["meta/dims"]]
+    kind = str(d["meta/agent_type"])
+    hidden = d["init/actor.backbone.final_mlp.mlp.linear0.weight"].shape[0]
+    C = d["init/actor.backbone.visual_nn.conv.mlp.conv0.weight"].shape[1]
+    if kind == "SAC":
+        cfg = configs.sac_dmc(C, A, B, hidden)
+    elif S == 0:
+        cfg = configs.drq_dmc(C, A, B, hidden)
+    else:
+        cfg = configs.drq_maniskill(C, A, S, B, hidden)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    agent = build_agent(cfg)
+    state = {k[5:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("init/")}
+    with torch.no_grad():
+        for n, p in agent.named_parameters():
+            p.copy_(state[n])
+    agent.use_fused_step = fused
+    return agent.to(dev), n_updates
+
+
+def batch_of(d, u):
+    pre = f"u{u}/batch/"
+    batch = {"obs": {}, "next_obs": {}}
+    for k in d.files:
+        if k.startswith(pre):
+            rest = k[len(pre):]
+            if "/" in rest:
+                side, key = rest.split("/")
+                batch[side][key] = d[k]
+            else:
+                batch[rest] = d[k]
+    return batch
+
+
+def draws(d, u, prefix, dev):
+    out, i = [], 0
+    while f"u{u}/{prefix}{i}" in d.files:
+        out.append(torch.from_numpy(d[f"u{u}/{prefix}{i}"]).to(dev))
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused-kernels", "autograd-heads"])
+@pytest.mark.parametrize("path", STEP_FIXTURES, ids=os.path.basename)
+def test_update_parameters_matches_reference(cuda, path, fused):
+    d = np.load(path)
+    agent, n_updates = build_from_fixture(d, cuda, fused)
+    for u in range(1, n_updates + 1):
+        agent.actor.head.noise_override = draws(d, u, "eps", cuda)
+        if hasattr(agent, "obs_aug") and agent.obs_aug is not None:
+            agent.obs_aug[0].noise_override = draws(d, u, "jitter", cuda)
+        ret = agent.update_parameters(Memory(batch_of(d, u)), u)
+        assert (agent._fused is not None) == fused
+        assert not agent.actor.head.noise_override
+        ref_keys = [k for k in d.files if k.startswith(f"u{u}/ret/")]
+        assert {k.split("/", 1)[1] for k in ret} == {k[len(f"u{u}/ret/"):] for k in ref_keys}
+        for k, v in ret.items():
+            ref = float(d[f"u{u}/ret/{k.split('/', 1)[1]}"])
+            assert abs(v - ref) <= 5e-5 * max(1.0, abs(ref)), (u, k, v, ref)
+        # encoder argmax of the obs pass (the reference's passes 3/4 are the obs encodes)
+        for name, p in agent.named_parameters():
+            s = d[f"u{u}/paramsum/{name}"]
+            got = np.array([float(p.detach().double().sum()), float(p.detach().double().abs().sum())])
+            np.testing.assert_allclose(got, s, rtol=2e-5, atol=2e-5, err_msg=f"u{u} {name}")
+        if u == 2:
+            for name, p in agent.named_parameters():
+                err = np.abs(p.detach().cpu().numpy() - d[f"u2/param/{name}"])
+                # 1e-5 everywhere, except that Adam's first updates are lr * g / (|g| + 1e-8): an element whose
+                # gradient is ~1e-8 turns a 1e-10 gradient difference into a ~1e-5 parameter difference.
+                assert (err <= 1e-5).mean() >= 0.999 and err.max() <= 1e-4, (name, err.max(), (err > 1e-5).sum())
+
+
+def test_agent_refuses_cpu_update():
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    cfg = configs.sac_dmc(6, 6, 4, 32)
+    cfg["env_params"] = configs.env_params({"xyz": [3, 16], "rgb": [3, 16]}, 6)
+    agent = build_agent(cfg)
+    with pytest.raises(RuntimeError):
+        agent.update_parameters(Memory({}), 1)
+
+
+def test_graph_replay_matches_eager(cuda):
+    """The hipGraph-replayed step and the eager step produce the same metrics and parameters when fed the
+    same batches and the same device RNG state."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+
+    def run(graphs):
+        cfg = configs.sac_dmc(6, 6, 16, head_hidden=64)
+        cfg["env_params"] = configs.env_params({"xyz": [3, 96], "rgb": [3, 96]}, 6)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        if graphs:
+            agent.enable_graphs(warmup=1)
+        mem = SyntheticReplay(16, 96, 6, seed=5, device=cuda)
+        torch.manual_seed(123)
+        rets = [agent.update_parameters(mem, u) for u in range(1, 9)]
+        return rets, {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}, agent
+
+    eager, p_eager, _ = run(False)
+    graphed, p_graph, agent = run(True)
+    assert len(agent._graphs) == 2          # one graph for critic-only steps, one for actor + target steps
+    for a, b in zip(eager, graphed):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    for n in p_eager:
+        assert torch.allclose(p_eager[n], p_graph[n], atol=1e-6, rtol=0), n
+
+
+def test_drq_mixed_precision_step_tracks_the_fp32_step(cuda):
+    """BASELINE config 3 (DrQ, jitter, bf16 encoder): same batch, same injected policy / jitter noise -- the bf16 agent's
+    losses stay within 5e-2 (relative) of the fp32 agent's over a few updates; parameters: Adam moves an entry by at most lr
+    per step whatever the gradient's size, so an entry whose tiny gradient changes sign under bf16 rounding can end up
+    2 * lr * steps = 8e-3 away -- the bound on the worst entry -- while the mean distance stays below 3e-4.  The
+    graph-replayed step runs."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A, S = 8, 160, 5, 7
+    agents = {}
+    for dt in ("f32", "bf16"):
+        cfg = configs.drq_maniskill(7, A, S, B, head_hidden=64, encoder_dtype=dt)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N], "seg": [1, N], "agent": S}, A)
+        torch.manual_seed(0)
+        agents[dt] = build_agent(cfg).to(cuda)
+    assert agents["bf16"].encoder.compute_dtype == "bf16" and agents["f32"].encoder.compute_dtype == "f32"
+    mem = SyntheticReplay(B, N, A, seed=4, device=cuda, seg=1, agent=S)
+    g = torch.Generator().manual_seed(7)
+    rets = {"f32": [], "bf16": []}
+    for u in range(1, 5):
+        eps = [torch.randn(2 * B, A, generator=g), torch.randn(B, A, generator=g)]
+        jit = [torch.empty(2 * B, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)]
+        for dt, agent in agents.items():
+            agent.actor.head.noise_override = [e.to(cuda) for e in eps][:2 if u % 2 == 0 else 1]
+            agent.obs_aug[0].noise_override = [j.to(cuda) for j in jit]
+            rets[dt].append(agent.update_parameters(mem, u))
+    for a, b in zip(rets["f32"], rets["bf16"]):
+        for k in ("drq/critic_loss", "drq/q", "drq/q_target"):
+            assert abs(a[k] - b[k]) <= 5e-2 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    pa, pb = dict(agents["f32"].named_parameters()), dict(agents["bf16"].named_parameters())
+    diffs = torch.cat([(pa[n].detach() - pb[n].detach()).abs().reshape(-1) for n in pa])
+    assert 0 < float(diffs.max()) <= 8.5e-3 and float(diffs.mean()) < 3e-4, (float(diffs.max()), float(diffs.mean()))
+    bf = agents["bf16"]
+    bf.enable_graphs(warmup=1)
+    more = [bf.update_parameters(mem, u) for u in range(5, 11)]
+    assert bf._graphs and all(np.isfinite(list(r.values())).all() for r in more)
+
+
+def test_checkpoint_resume_continues_bit_for_bit(cuda, tmp_path):
+    """Train 4 steps, save in the reference's checkpoint format, load into a freshly built agent, train 4 more: parameters,
+    Adam moments and step counts equal those of 8 uninterrupted steps exactly (same injected policy noise)."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    from pointcloud_rl_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+    B, N, A = 8, 96, 4
+
+    def make(seed):
+        cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(seed)
+        return build_agent(cfg).to(cuda)
+
+    mem = SyntheticReplay(B, N, A, seed=6, device=cuda)
+    g = torch.Generator().manual_seed(11)
+    eps = [[torch.randn(B, A, generator=g).to(cuda) for _ in range(2)] for _ in range(8)]
+
+    def run(agent, lo, hi):
+        for u in range(lo, hi + 1):
+            agent.actor.head.noise_override = list(eps[u - 1][:2 if u % 2 == 0 else 1])
+            agent.update_parameters(mem, u)
+
+    whole = make(0)
+    run(whole, 1, 8)
+    first = make(0)
+    run(first, 1, 4)
+    path = str(tmp_path / "model_4.ckpt")
+    save_checkpoint(first, path)
+    resumed = make(123)                                     # different init: everything must come from the file
+    load_checkpoint(resumed, path, map_location="cpu", strict=True)
+    run(resumed, 5, 8)
+    for (n, p), (_, q) in zip(whole.named_parameters(), resumed.named_parameters()):
+        assert torch.equal(p, q), n
+    for name in ("critic_optim", "actor_optim", "alpha_optim"):
+        a, b = getattr(whole, name), getattr(resumed, name)
+        assert int(a.step_counter) == int(b.step_counter) > 0
+        assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq), name
+    # the target network's own (non-shared) parameters travel too
+    for (n, p), (_, q) in zip(whole.target_critic.named_parameters(), resumed.target_critic.named_parameters()):
+        assert torch.equal(p, q), n

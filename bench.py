@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="analysis only: override the global batch size (the JSON line then is NOT the "
                     "BASELINE metric; used to look at the per-GPU share of a multi-GPU run on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0")
+    ap.add_argument("--single-rank-exchange", action="store_true", help="debug: with one rank, still create the process group and run the "
+                    "data-parallel schedule (segmented graphs + async all-reduces over a one-rank group): exercises RCCL on a one-GPU box; "
+                    "the line is tagged and is not the headline")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16", "f32split"], help="override the workload's encoder arithmetic; "
                     "f32split = the EXPERIMENTAL three-term bf16 split of the fp32 contractions (~1e-6 of fp32, not bit-comparable): the JSON "
                     "line then says dtype f32split and is not the headline configuration")
@@ -161,7 +164,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1
+    if args.single_rank_exchange and world == 1:
+        os.environ["PCRL_EXCHANGE_SINGLE_RANK"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist_on = True
+    if dist_on:
         torch.distributed.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     assert wl["B"] % world == 0, "batch must divide over the ranks"
     b_rank = wl["B"] // world
@@ -169,7 +178,7 @@ def main():
     from pointcloud_rl_amd import hip
     from pointcloud_rl_amd.synthetic import SyntheticReplay
     agent, C = build_agent(wl, b_rank, device, args.encoder_dtype)
-    if world > 1:
+    if dist_on:
         agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
         # device-resident replay (pointcloud_rl_amd/replay.py): every rank owns a ring of synthetic transitions and each
@@ -204,7 +213,7 @@ def main():
         agent.enable_graphs()
 
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -232,7 +241,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     nocomm_ms = None
-    if world > 1:
+    if dist_on:
         # the same step with the gradient exchange switched off (every rank trains on its shard alone): what is left of
         # ms_per_step is compute, the difference is what the (overlapped) all-reduces still cost
         agent.to_normal()
@@ -260,7 +269,7 @@ def main():
             agent.update_parameters(memory, updates)
         sync()
     timer, hip.TIMER = hip.TIMER, None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed, nocomm_ms], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, nocomm_ms = float(t[0].item()), float(t[1].item())
@@ -282,7 +291,7 @@ def main():
         peak = 2500.0 if is_bf16 else 157.3        # dense MFMA peaks of MI355X_MICROARCH.md (bf16 / fp32)
         traffic, traffic_src = None, None
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.workload}.json")))
-        if cands and not args.batch and world == 1:
+        if cands and not args.batch and not dist_on:
             # HBM bytes per encoder_fwd launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process.
             # The file names the hash of the kernel's sources it was measured on: a figure from another kernel is not reported.
@@ -310,7 +319,9 @@ def main():
         if nocomm_ms is not None:
             out["ms_per_step_nocomm"] = nocomm_ms
             out["comm_ms_per_step"] = elapsed / args.steps * 1e3 - nocomm_ms
-        if world == 1 and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
+        if dist_on and world == 1:
+            out["debug"] = f"single-rank exchange over backend {args.backend}: data-parallel schedule with a one-rank process group"
+        if not dist_on and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
             # bounded samples (about 10-30 s of CPU work each): every granted core on a slice of the batch that takes a few
             # seconds per step, and the reference's shipped single-thread setting (pyrl/utils/meta/__init__.py:38-49) on a
             # smaller slice
@@ -320,7 +331,7 @@ def main():
             if not args.cpu_threads:
                 one_b = max(4, int(wl["B"] * 24_000 / points))
                 out["cpu_baseline_1thread"] = cpu_baseline(agent, wl, 2, 1, sample_batch=one_b)
-        if (world == 1 and not args.batch and args.encoder_dtype is None and not args.no_experimental and out["dtype"] == "f32"
+        if (not dist_on and not args.batch and args.encoder_dtype is None and not args.no_experimental and out["dtype"] == "f32"
                 and args.replay == "device"):
             # Not the headline: the same step with the EXPERIMENTAL split-precision encoder forward (three-term bf16 split of the
             # fp32 contractions, within ~3e-6 of the exact kernel, argmax exact on the reference fixtures)
@@ -346,7 +357,7 @@ def main():
                                             "note": "encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); "
                                                     "opt-in, not the reported value"}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -387,12 +387,24 @@ int pcrl_replay_gather(const pcrl_gather_seg* segs, int32_t n_segs, const int32_
  * (b, draw); `draw` is the host's sample-call count.  The rows used are written to idx_out (may be NULL). */
 int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t size, int64_t capacity,
                               uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream);
+/* The same launch with its two per-call values read from device memory, so that it can be a node of a replayed hipGraph
+ * (the sampling becomes part of the captured update step): state[0] = draw (the launch's last workgroup to finish advances
+ * it by one), state[1] = size (the host stores len(buffer) there after every push), state[2] = workgroup ticket (0 between
+ * launches).  Same rows as pcrl_replay_sample_gather(..., size = state[1], draw = state[0], ...). */
+int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t capacity, uint64_t seed,
+                                    uint64_t* state, int32_t* idx_out, void* stream);
 
 /* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
  * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196).  Up to 4 deferred optimizer
  * passes (pcrl_adam_pending) are finished first, so their gradient norms can be among the gathered scalars. */
 int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
                             const pcrl_adam_pending* pending, int32_t n_pending, void* stream);
+/* Same, and the n gathered values are also stored to host_out[0..n) -- pinned host memory the device can address
+ * (hipHostMalloc / torch pin_memory) -- followed, after a system-scope fence, by host_out[n] = 1.0f: a host that cleared
+ * host_out[n] before the launch reads the step's metrics as soon as the flag turns, without a device->host copy node in
+ * the captured step and without a stream synchronisation (the `.item()` reads of sac.py:150-159,199-204). */
+int pcrl_gather_scalars_host_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                                 const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream);
 
 #ifdef __cplusplus
 }

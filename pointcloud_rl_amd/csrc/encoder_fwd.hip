@@ -34,6 +34,22 @@ struct FwdParams {
 // fed to the next layer) with fp32 accumulation; conv0, both LayerNorms and the max-pool are unchanged fp32 code.
 // SPLIT (experimental, never together with BF16): conv1 / conv2 in ~fp32 accuracy on the bf16 matrix cores, every operand split
 // into three bf16 terms (dense_layer_split); conv2's hi and mid weight images live in LDS, the lo image streams from L2.
+#ifndef PCRL_FWD_W1_LDS
+#define PCRL_FWD_W1_LDS 1
+#endif
+// LDS bytes of everything but conv1 row blocks (small tables + the conv2 image; the split mode keeps two bf16 images = the same
+// bytes as the fp32 one), and how many 32-row blocks of the fp32 conv1 image fit in what is left of the CU's 160 KB.
+__host__ __device__ constexpr size_t fwd_lds_base_bytes(int T0, int C1, int C2, int C3, bool bf16) {
+    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 +
+           sizeof(float) * ((size_t)C3 * C2 / (bf16 ? 2 : 1) + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
+}
+__host__ __device__ constexpr int fwd_w1_lds_blocks(int T0, int C1, int C2, int C3, bool bf16, bool split) {
+    if (bf16 || split || !PCRL_FWD_W1_LDS) return 0;
+    const size_t room = 160 * 1024 - fwd_lds_base_bytes(T0, C1, C2, C3, false);
+    const int fit = (int)(room / (sizeof(float) * 32 * (size_t)C1));
+    return fit < C2 / 32 ? fit : C2 / 32;
+}
+
 template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
     constexpr PackedLayout L{T0, C1, C2, C3};
@@ -47,7 +63,11 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     float* s_ln2 = s_ln1 + 2 * C2;
     float* s_b0 = s_ln2 + 2 * C3;
     float* s_w0 = s_b0 + C1;
-    float* s_w2 = s_w0 + MB1 * T0 * 64;
+    // exact fp32 mode: as many 32-row blocks of the conv1 image as the 160 KB of LDS still hold next to the conv2 image
+    // (K1: 3 of 4) sit here too; the rest streams from L2 as before
+    constexpr int W1L = fwd_w1_lds_blocks(T0, C1, C2, C3, BF16, SPLIT);
+    float* s_w1 = s_w0 + MB1 * T0 * 64;
+    float* s_w2 = s_w1 + W1L * 32 * C1;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -59,6 +79,12 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
         if (nthreads == 512) stage_to_lds<512, N16>(s, g, tid);
         else for (int i = tid; i < N16; i += nthreads) s[i] = g[i];
         for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
+        if constexpr (W1L > 0) {
+            const f32x4* g1 = reinterpret_cast<const f32x4*>(p.packed + L.w1());
+            f32x4* s1 = reinterpret_cast<f32x4*>(s_w1);
+            if (nthreads == 512) stage_to_lds<512, W1L * 8 * C1>(s1, g1, tid);
+            else for (int i = tid; i < W1L * 8 * C1; i += nthreads) s1[i] = g1[i];
+        }
         for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
         ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
         ln_pair_table(s_ln2, p.packed + L.ln2(), C3, tid, nthreads);
@@ -67,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
     const unsigned lane16 = 16u * (unsigned)lane;
     const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
+    const f32x4* s_w1v = reinterpret_cast<const f32x4*>(s_w1);
 
     for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
         const int b = work / p.S, seg = work - b * p.S;
@@ -114,7 +141,9 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                     [&](int t) { return a0[t >> 4][t & 15]; });
             else
                 dense_layer_mfma<MB2, C1 / 8, 3>(
-                    a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                    a1, [&](int mb, int tq) {
+                        return mb < W1L ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane]
+                                        : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
             ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
 
@@ -388,14 +417,13 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
     return PCRL_OK;
 }
 
-static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16) {
-    return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 +
-           sizeof(float) * ((size_t)C3 * C2 / (bf16 ? 2 : 1) + (size_t)(C1 / 32) * T0 * 64 + C1 + 2 * C2 + 2 * C3);
+static size_t fwd_lds_bytes(int T0, int C1, int C2, int C3, bool bf16, bool split) {
+    return fwd_lds_base_bytes(T0, C1, C2, C3, bf16) + sizeof(float) * 32 * (size_t)C1 * fwd_w1_lds_blocks(T0, C1, C2, C3, bf16, split);
 }
 
 template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
-    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16);
+    const size_t lds = fwd_lds_bytes(T0, C1, C2, C3, BF16, SPLIT);
     auto kern = encoder_fwd_kernel<T0, C1, C2, C3, BF16, SPLIT>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);

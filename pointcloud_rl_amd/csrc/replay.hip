@@ -15,6 +15,8 @@ struct GatherParams {
     const int* idx; int B; long long capacity;
     // idx == NULL: row b is drawn in the kernel, uniform on [0, size), Philox4x32-10 keyed by seed, counter (b, draw)
     int* idx_out; unsigned size, seed_lo, seed_hi, draw_lo, draw_hi;
+    // state != NULL: draw and size come from device memory ({draw, size, ticket}); the last workgroup advances draw
+    unsigned long long* state;
 };
 
 __global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p) {
@@ -23,10 +25,30 @@ __global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p
     if (p.idx) {
         row = p.idx[b];
     } else {
+        unsigned draw_lo = p.draw_lo, draw_hi = p.draw_hi, size = p.size;
+        if (p.state) {
+            const unsigned long long d = __builtin_nontemporal_load(p.state), n = __builtin_nontemporal_load(p.state + 1);
+            draw_lo = (unsigned)d; draw_hi = (unsigned)(d >> 32);
+            size = (unsigned)(n < 1 ? 1 : (n > (unsigned long long)p.capacity ? (unsigned long long)p.capacity : n));
+        }
         uint32_t w[4];
-        philox4x32_10((uint32_t)b, p.draw_lo, p.draw_hi, 0x52455055u, p.seed_lo, p.seed_hi, w);
-        row = (long long)(((unsigned long long)w[0] * p.size) >> 32);       // multiply-shift: bias < size / 2^32
+        philox4x32_10((uint32_t)b, draw_lo, draw_hi, 0x52455055u, p.seed_lo, p.seed_hi, w);
+        row = (long long)(((unsigned long long)w[0] * size) >> 32);       // multiply-shift: bias < size / 2^32
         if (seg == 0 && threadIdx.x == 0 && p.idx_out) p.idx_out[b] = (int)row;
+        if (p.state) {
+            // every workgroup has read the draw count before it takes a ticket; the one that takes the last ticket is the
+            // only one left, advances the count for the next launch and puts the ticket counter back to zero
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
+                if (atomicAdd(p.state + 2, 1ull) == total - 1) {
+                    p.state[2] = 0ull;
+                    p.state[0] = (((unsigned long long)draw_hi << 32) | draw_lo) + 1ull;
+                    __threadfence();
+                }
+            }
+        }
     }
     row = row < 0 ? 0 : (row >= p.capacity ? p.capacity - 1 : row);       // never read outside the ring
     const long long nbytes = p.row_bytes[seg];
@@ -71,6 +93,17 @@ extern "C" int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_
     GatherParams p{};
     p.idx = nullptr; p.B = B; p.capacity = capacity; p.idx_out = idx_out; p.size = (unsigned)size;
     p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.draw_lo = (unsigned)draw; p.draw_hi = (unsigned)(draw >> 32);
+    return gather_launch(segs, n_segs, p, stream);
+}
+
+extern "C" int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t capacity, uint64_t seed,
+                                               uint64_t* state, int32_t* idx_out, void* stream) {
+    if (!state) return fail(PCRL_E_ARG, "NULL argument");
+    if (capacity < 1 || capacity > 0xFFFFFFFFll) return fail(PCRL_E_ARG, "replay sample: 1 <= capacity < 2^32");
+    GatherParams p{};
+    p.idx = nullptr; p.B = B; p.capacity = capacity; p.idx_out = idx_out; p.size = 1;
+    p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32);
+    p.state = reinterpret_cast<unsigned long long*>(state);
     return gather_launch(segs, n_segs, p, stream);
 }
 

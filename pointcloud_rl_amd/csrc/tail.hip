@@ -211,6 +211,7 @@ constexpr int kMaxFinalize = 4;
 struct ScalarListParams {
     const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n;
     const float* partial[kMaxFinalize]; int n_partial[kMaxFinalize]; float* norm[kMaxFinalize]; int* step[kMaxFinalize]; int n_fin;
+    float* host_out;      // optional pinned host mirror: values [0, n), then the "ready" flag at [n]
 };
 __global__ __launch_bounds__(256) void gather_scalars_kernel(const ScalarListParams p) {
     __shared__ float s_part[4];
@@ -230,9 +231,20 @@ __global__ __launch_bounds__(256) void gather_scalars_kernel(const ScalarListPar
     __threadfence_block();
     __syncthreads();
     const int i = threadIdx.x;
+    float out = 0.0f;
     if (i < p.n) {
         const float v = p.src[i][0];
-        p.dst[i][0] = ((p.exp_mask >> i) & 1u) ? expf(v) : v;
+        out = ((p.exp_mask >> i) & 1u) ? expf(v) : v;
+        p.dst[i][0] = out;
+    }
+    if (p.host_out) {       // the n values cross PCIe first, the flag after a system-scope fence: flag seen => values there
+        if (i < p.n) __builtin_nontemporal_store(out, p.host_out + i);
+        __threadfence_system();
+        __syncthreads();
+        if (i == 0) {
+            __builtin_nontemporal_store(1.0f, p.host_out + p.n);
+            __threadfence_system();
+        }
     }
 }
 
@@ -242,6 +254,11 @@ using namespace pcrl;
 
 extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
                                        const pcrl_adam_pending* pending, int32_t n_pending, void* stream) {
+    return pcrl_gather_scalars_host_f32(src, dst, take_exp, n, pending, n_pending, nullptr, stream);
+}
+
+extern "C" int pcrl_gather_scalars_host_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                                            const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream) {
     if (n < 0 || n > kMaxScalars || (n > 0 && (!src || !dst))) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
     if (n_pending < 0 || n_pending > kMaxFinalize || (n_pending > 0 && !pending))
         return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n_pending <= %d", kMaxFinalize);
@@ -259,6 +276,7 @@ extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* ds
         p.norm[f] = pending[f].grad_norm_out; p.step[f] = pending[f].step_counter;
     }
     p.n_fin = n_pending;
+    p.host_out = host_out;
     hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("gather_scalars_kernel");
     return PCRL_OK;

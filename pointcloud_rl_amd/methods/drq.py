@@ -109,10 +109,4 @@ class DrQ(SAC):
         return (obs, next_obs, batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), dict(
             group=self.num_aug, repeat=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
 
-    def update_parameters(self, memory, updates):
-        if self._flat is None:
-            self._prepare()
-        sampled_batch = memory.sample(self.batch_size).to_torch(device=self.device, non_blocking=True)
-        if self.use_episode_dones:
-            sampled_batch["dones"] = sampled_batch["episode_dones"]
-        return self._run_step(sampled_batch, updates)
+    _process_sampled_obs = False        # drq.py:46-49 samples without process_obs; update_parameters itself is SAC's

@@ -18,8 +18,10 @@ from ..networks.pointnet import PointNet
 
 
 class PackedStats(dict):
-    """name -> device scalar (views into `packed`, one contiguous float32 tensor in the same order)."""
+    """name -> device scalar (views into `packed`, one contiguous float32 tensor in the same order); `host`: pinned float32
+    tensor that receives the same values from the launch that fills `packed`, followed by a ready flag (hip.gather_scalars)."""
     packed = None
+    host = None
 
 
 def ceil4(x):
@@ -166,6 +168,7 @@ class FusedStep:
         self.ldq, self.lda = ceil4(self.Din_q), ceil4(self.Din_a)
         self.bufs = {}
         # head tails (csrc/headtail.hip): the last Linear of a head fused with the loss / squashed-Gaussian head that follows
+        self.host_stats = None       # pinned mirror of the step's metrics (+ ready flag), allocated on first use
         self.tails = (self.H % 256 == 0 and self.H <= 1024 and 2 * self.A <= 64 and self.q.dims[2][1] == 1
                       and not bool(int(__import__("os").environ.get("PCRL_NO_TAILS", "0"))))
         dev = fc.data.device
@@ -264,8 +267,8 @@ class FusedStep:
         from ..utils.dist import Exchange
         ex = Exchange(enabled=self.a._be_data_parallel)
         gen = self.steps(*args, **kwargs)
-        kind, pieces = next(gen)
         try:
+            kind, pieces = next(gen)
             while True:
                 for t in pieces:
                     ex.start(t)
@@ -278,7 +281,7 @@ class FusedStep:
         all-reduce may begin, and ("finish", [pieces]) when the remaining pieces must be reduced and every started one
         waited for -- it then receives the factor 1/world to fold into the optimizer pass.  Between two yields no
         cross-rank communication is issued, so every stretch can be captured as its own hipGraph while the collectives stay
-        eager; a caller without peers skips the "start" yields (exchanging=False) and keeps the step in one graph."""
+        eager; a caller without peers passes exchanging=False: no yields at all, the step is one graph."""
         a = self.a
         enc, F, S, A, H = a.encoder, self.F, self.S, self.A, self.H
         ldq, lda = self.ldq, self.lda
@@ -369,7 +372,7 @@ class FusedStep:
                                       c_ones=fc.grad[off[pre + "0.bias"]:]),
                         hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
-        scale = yield ("finish", [fc.grad[:self.q_base] if exchanging else fc.grad])
+        scale = (yield ("finish", [fc.grad[:self.q_base]])) if exchanging else 1.0
         pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
         stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
@@ -409,7 +412,7 @@ class FusedStep:
                                   d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
-            scale = yield ("finish", [fa.grad, fal.grad] if a.sync_alpha else [fa.grad])
+            scale = (yield ("finish", [fa.grad, fal.grad] if a.sync_alpha else [fa.grad])) if exchanging else 1.0
             stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
             a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
@@ -419,7 +422,10 @@ class FusedStep:
         entries = [(a.log_alpha, out[i:], True) if k == "new_alpha" else (stats[k], out[i:], False) for i, k in enumerate(names)]
         if "new_alpha" in stats:
             entries.append((a.log_alpha, a._alpha_t, True))
-        hip.gather_scalars(entries, pending=pending)
+        if self.host_stats is None:
+            self.host_stats = torch.zeros(32, dtype=torch.float32).pin_memory()
+        hip.gather_scalars(entries, pending=pending, host_out=self.host_stats)
         packed = PackedStats((k, out[i]) for i, k in enumerate(names))
         packed.packed = out[:len(names)]
+        packed.host = self.host_stats
         return packed

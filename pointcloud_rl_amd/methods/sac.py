@@ -12,6 +12,7 @@ is executed:
 """
 import contextlib
 import gc
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -22,7 +23,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.dist import Exchange, allreduce_sum_, world_size
+from ..utils.dist import Exchange, allreduce_sum_, exchange_active, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -401,6 +402,32 @@ class SAC(BaseAgent):
             stats["alpha_loss"] = torch.zeros((), device=self.device)
         stats["new_alpha"] = self._alpha_t.reshape(()).clone()
 
+    def _ret_template(self, keys):
+        """[(returned key, index into the step's metric vector | None, constant)] in the reference's order (sac.py:150-159,199-204),
+        cached per metric-name tuple."""
+        cache = self.__dict__.setdefault("_ret_templates", {})
+        keys = tuple(keys)
+        if keys not in cache:
+            pre, at = self.metric_prefix, {k: i for i, k in enumerate(keys)}
+            tpl = [(f"{pre}/critic_loss", at["critic_loss"], None), (f"{pre}/max_critic_abs_err", at["max_critic_abs_err"], None),
+                   (f"{pre}/alpha", None, "alpha"), (f"{pre}/q", at["q"], None), (f"{pre}/q_target", at["q_target"], None),
+                   (f"{pre}/target_entropy", None, self.target_entropy), (f"{pre}/critic_grad", at["critic_grad"], None),
+                   (f"{pre}/grad_steps", None, 1)]
+            if "actor_loss" in at:
+                tpl += [(f"{pre}/actor_loss", at["actor_loss"], None), (f"{pre}/alpha_loss", at["alpha_loss"], None),
+                        (f"{pre}/entropy", at["entropy"], None), (f"{pre}/actor_grad", at["actor_grad"], None)]
+            new_alpha = at.get("new_alpha") if ("actor_loss" in at and self.automatic_alpha_tuning) else None
+            cache[keys] = (tpl, new_alpha)
+        return cache[keys]
+
+    def _ret_from_values(self, keys, vals):
+        tpl, new_alpha = self._ret_template(keys)
+        alpha = self.alpha                        # the value the step ran with (sac.py:153 reads it before the temperature update)
+        ret = {k: (vals[i] if i is not None else (alpha if c == "alpha" else c)) for k, i, c in tpl}
+        if new_alpha is not None:
+            self.alpha = vals[new_alpha]
+        return ret
+
     def _finish(self, stats, updates, host_values=None):
         """One device->host copy for every metric the reference reads with .item() (sac.py:140-203)."""
         keys = list(stats.keys())
@@ -410,17 +437,7 @@ class SAC(BaseAgent):
             vals = stats.packed.tolist()
         else:
             vals = torch.stack([stats[k].reshape(()).float() for k in keys]).tolist()
-        got = dict(zip(keys, vals))
-        pre = self.metric_prefix
-        ret = {f"{pre}/critic_loss": got["critic_loss"], f"{pre}/max_critic_abs_err": got["max_critic_abs_err"],
-               f"{pre}/alpha": self.alpha, f"{pre}/q": got["q"], f"{pre}/q_target": got["q_target"],
-               f"{pre}/target_entropy": self.target_entropy, f"{pre}/critic_grad": got["critic_grad"], f"{pre}/grad_steps": 1}
-        if "actor_loss" in got:
-            ret.update({f"{pre}/actor_loss": got["actor_loss"], f"{pre}/alpha_loss": got["alpha_loss"],
-                        f"{pre}/entropy": got["entropy"], f"{pre}/actor_grad": got["actor_grad"]})
-            if self.automatic_alpha_tuning:
-                self.alpha = got["new_alpha"]
-        return ret
+        return self._ret_from_values(keys, vals)
 
     def _polyak_now(self, updates):
         """True when this step's target update is fused into the critic's optimizer pass.  The critic's
@@ -451,6 +468,7 @@ class SAC(BaseAgent):
         alpha, the Adam step counts and the Philox offsets live in device memory."""
         self._use_graphs, self._graph_warmup = enabled, warmup
         self._graphs, self._graph_seen, self._static_batch = {}, {}, None
+        self._graph_sampler, self._graph_flag, self._fast = {}, {}, None
 
     def _to_static(self, batch):
         """Copy `batch` into buffers whose addresses the captured graphs refer to."""
@@ -472,36 +490,55 @@ class SAC(BaseAgent):
     def _fused_args(self, batch, do_actor, polyak):
         return (batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), {}
 
-    def _run_step(self, batch, updates):
+    def _run_step(self, batch, updates, sampler=None):
+        """batch: the sampled batch, or a callable `fetch(launch=True)` returning it -- then `sampler` is the replay it samples
+        from, and when that replay's sampling is one host-free launch (`DeviceReplay.graph_sampling`) the launch becomes the
+        first node of the captured step: replays call `fetch(launch=False)` (bookkeeping only)."""
+        fetch = batch if callable(batch) else (lambda launch=True: batch)
+        if not (callable(batch) and getattr(sampler, "graph_sampling", False) and os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1"):
+            sampler = None
         do_actor = updates % self.actor_update_interval == 0
         polyak = self._polyak_now(updates)
-        exchanging = self._be_data_parallel and world_size() > 1
+        exchanging = self._be_data_parallel and exchange_active()
         graphable = getattr(self, "_use_graphs", False) and (not (updates % self.target_update_interval == 0) or polyak) \
             and (not exchanging or self._fused is not None)
         if not graphable:
-            stats = self._step_body(batch, do_actor, polyak)
+            stats = self._step_body(fetch(), do_actor, polyak)
             self._soft_update(updates)
             return self._finish({k: v for k, v in stats.items()}, updates)
-        batch = self._to_static(batch)
         # launches bake lr / betas / eps in as kernel arguments: a changed hyper-parameter invalidates the captured graphs
         hyper = tuple(opt.hyper() for opt in (self.critic_optim, self.actor_optim, self.alpha_optim) if isinstance(opt, HipAdam))
         if hyper != getattr(self, "_graph_hyper", hyper):
-            self._graphs, self._graph_seen = {}, {k: self._graph_warmup for k in self._graph_seen}
+            self._graphs, self._graph_seen, self._fast = {}, {k: self._graph_warmup for k in self._graph_seen}, None
         self._graph_hyper = hyper
         key = (do_actor, polyak, exchanging)       # a step with exchanges is cut into segments, one without is one graph
+        if key in self._graphs and self._graph_sampler.get(key) not in (None, sampler):
+            # this variant was captured with another replay's sampling launch inside: capture again
+            self._graphs, self._graph_seen, self._fast = {}, {k: self._graph_warmup for k in self._graph_seen}, None
         if key not in self._graphs:
             seen = self._graph_seen.get(key, 0)
             self._graph_seen[key] = seen + 1
             if seen < self._graph_warmup:          # eager warm-up: lazy initialisation must not be captured
-                return self._finish(self._step_body(batch, do_actor, polyak), updates)
+                return self._finish(self._step_body(self._to_static(fetch()), do_actor, polyak), updates)
             for enc in {id(e): e for owners in self._packed_owners.values() for e in owners}.values():
                 enc.invalidate_packed()            # every replay starts by re-packing the (updated) weights
+            batch = self._to_static(fetch(launch=False) if sampler is not None else fetch())
+            pre = (lambda: sampler.launch_sample(self.batch_size)) if sampler is not None else None
             torch.cuda.synchronize()
-            self._graphs[key] = self._capture_segments(batch, do_actor, polyak) if exchanging else self._capture_whole(batch, do_actor, polyak)
+            self._graph_sampler[key] = sampler
+            self._graphs[key] = self._capture_segments(batch, do_actor, polyak, pre) if exchanging else self._capture_whole(batch, do_actor, polyak, pre)
+            self._refresh_fast()
             if exchanging:                          # capturing a segmented step also executed it
                 segments, names, out = self._graphs[key]
                 return self._finish(dict(zip(names, out.unbind(0))), updates)
+        elif self._graph_sampler.get(key) is not None:
+            fetch(launch=False)                     # the graph holds the sampling launch; the staging tensors are its inputs
+        else:
+            self._to_static(fetch())
         segments, names, out = self._graphs[key]
+        flag = self._graph_flag.get(key)
+        if flag is not None:
+            flag[0][flag[1]] = 0.0                  # "ready" flag of the pinned metrics mirror, set by the step's last kernel
         ex = Exchange()
         for graph, (kind, pieces) in segments:
             graph.replay()
@@ -509,6 +546,8 @@ class SAC(BaseAgent):
                 ex.start(t)
             if kind == "finish":
                 ex.finish()
+        if flag is not None:
+            return self._finish(dict.fromkeys(names), updates, host_values=self._await_flag(*flag))
         if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
             stream = self.__dict__.get("_sync_stream")
             if stream is None or stream.cuda_stream != hip.raw_stream():
@@ -517,21 +556,42 @@ class SAC(BaseAgent):
             return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
         return self._finish(dict(zip(names, out.unbind(0))), updates)
 
-    def _capture_whole(self, batch, do_actor, polyak):
+    @staticmethod
+    def _await_flag(view, n):
+        """Spin on the pinned mirror's flag (the step's last kernel stores the metrics, fences, then stores the flag): no stream
+        synchronisation, no copy node.  A step that has not finished after 20 s is reported through the stream's error."""
+        spins = 0
+        while view[n] == 0.0:
+            spins += 1
+            if spins & 0xFFFFF == 0:                # every ~1 M polls (~0.1 s): give a failed launch the chance to surface
+                if torch.cuda.current_stream().query() and view[n] == 0.0:
+                    torch.cuda.synchronize()
+                    if view[n] == 0.0:
+                        raise RuntimeError("update step finished without publishing its metrics")
+        return view[:n].tolist()
+
+    def _capture_whole(self, batch, do_actor, polyak, pre=None):
         graph = torch.cuda.CUDAGraph()
         host = None
         pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
+        key = (do_actor, polyak, False)
+        self._graph_flag.pop(key, None)
         with _no_gc(), torch.cuda.graph(graph):
+            if pre is not None:
+                pre()                       # the replay's sampling launch: first node of the step
             stats = self._step_body(batch, do_actor, polyak)
             names = list(stats.keys())
             packed = getattr(stats, "packed", None)
+            mirror = getattr(stats, "host", None)
             out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
-            if packed is not None:          # the metrics land in pinned host memory as the graph's last node
+            if mirror is not None:          # the step's last kernel stored the metrics to pinned host memory itself
+                self._graph_flag[key] = (mirror.numpy(), len(names))
+            elif packed is not None:        # the metrics land in pinned host memory as the graph's last node
                 host = pinned[:len(names)]
                 host.copy_(out, non_blocking=True)
         return [(graph, ("finish", []))], names, (host if host is not None else out)
 
-    def _capture_segments(self, batch, do_actor, polyak):
+    def _capture_segments(self, batch, do_actor, polyak, pre=None):
         """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay
         eager between the graph launches (no collective is ever captured).  Capturing records without
         executing, so each segment is replayed right after its capture to carry the step forward."""
@@ -546,7 +606,9 @@ class SAC(BaseAgent):
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
             with _no_gc(), torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
                 try:
-                    if gen is None:     # batch preparation (DrQ: augmentation draws) belongs to the first segment
+                    if gen is None:     # sampling and batch preparation (DrQ: augmentation draws) belong to the first segment
+                        if pre is not None:
+                            pre()
                         args, kwargs = self._fused_args(batch, do_actor, polyak)
                         gen = self._fused.steps(*args, **kwargs)
                         exchange = next(gen)
@@ -556,6 +618,8 @@ class SAC(BaseAgent):
                     stats = done.value
                     names = list(stats.keys())
                     out = torch.stack([stats[k].reshape(()).float() for k in names])
+                    if getattr(stats, "host", None) is not None:
+                        self._graph_flag[(do_actor, polyak, True)] = (stats.host.numpy(), len(names))
             kind, pieces = exchange
             graph.replay()
             for t in pieces:
@@ -565,11 +629,76 @@ class SAC(BaseAgent):
             segments.append((graph, (kind, list(pieces))))
         return segments, names, out
 
+    _process_sampled_obs = True
+
+    def _fetcher(self, memory):
+        """`fetch(launch=True)` -> the sampled batch on the device (sac.py:104-107); launch=False asks a graph-sampling replay
+        for its staging batch without launching (the captured step holds the launch)."""
+        def fetch(launch=True):
+            sample = memory.sample(self.batch_size) if launch else memory.sample(self.batch_size, launch=False)
+            sampled_batch = sample.to_torch(device=self.device, non_blocking=True)
+            if self._process_sampled_obs:          # sac.py:106 (drq.py's update_parameters does not call it)
+                sampled_batch = self.process_obs(sampled_batch)
+            if self.use_episode_dones:
+                sampled_batch["dones"] = sampled_batch["episode_dones"]
+            return sampled_batch
+        return fetch
+
     def update_parameters(self, memory, updates):
         if self._flat is None:
             self._prepare()
-        sampled_batch = memory.sample(self.batch_size).to_torch(device=self.device, non_blocking=True)
-        sampled_batch = self.process_obs(sampled_batch)
-        if self.use_episode_dones:
-            sampled_batch["dones"] = sampled_batch["episode_dones"]
-        return self._run_step(sampled_batch, updates)
+        fast = self.__dict__.get("_fast")
+        if fast is not None:
+            ret = self._replay_fast(fast, memory, updates)
+            if ret is not None:
+                return ret
+        return self._run_step(self._fetcher(memory), updates, sampler=memory)
+
+    # Steady state of a graph-replayed agent fed by a DeviceReplay: everything `_run_step` decides per call has been decided
+    # when the variants were captured, so a call is: count the sample, clear the flag, launch the graph(s), spin on the flag,
+    # build the dict.  Anything unusual (a variant not captured yet, another replay object, a changed learning rate, the
+    # data-parallel switch flipped, every 128th call for the full hyper-parameter check) falls back to `_run_step`.
+    def _refresh_fast(self):
+        self._fast = None
+        if os.environ.get("PCRL_FAST_REPLAY", "1") != "1":
+            return
+        if not (getattr(self, "_use_graphs", False) and self._fused is not None and self._target_flat is not None
+                and all(isinstance(o, HipAdam) for o in (self.critic_optim, self.actor_optim, self.alpha_optim))):
+            return
+        entries = {}
+        for key, (segments, names, out) in self._graphs.items():
+            flag, sampler = self._graph_flag.get(key), self._graph_sampler.get(key)
+            if flag is None or sampler is None:
+                return
+            entries[key] = (segments, tuple(names), flag[0], flag[1], sampler)
+        if entries:
+            opts = (self.critic_optim, self.actor_optim, self.alpha_optim)
+            self._fast = dict(entries=entries, lrs=[(o.param_groups[0], o.param_groups[0]["lr"]) for o in opts], calls=0,
+                              dp=self._be_data_parallel)
+
+    def _replay_fast(self, fast, memory, updates):
+        fast["calls"] += 1
+        if fast["calls"] & 127 == 0 or self._be_data_parallel != fast["dp"] or not self._use_graphs:
+            return None
+        exchanging = fast["dp"] and exchange_active()
+        entry = fast["entries"].get((updates % self.actor_update_interval == 0, updates % self.target_update_interval == 0, exchanging))
+        if entry is None or entry[4] is not memory:
+            return None
+        for group, lr in fast["lrs"]:
+            if group["lr"] != lr:
+                return None
+        segments, names, view, n, _ = entry
+        memory.sample(self.batch_size, launch=False)
+        view[n] = 0.0
+        if exchanging:
+            ex = Exchange()
+            for graph, (kind, pieces) in segments:
+                graph.replay()
+                for t in pieces:
+                    ex.start(t)
+                if kind == "finish":
+                    ex.finish()
+        else:
+            for graph, _ in segments:
+                graph.replay()
+        return self._ret_from_values(names, self._await_flag(view, n))

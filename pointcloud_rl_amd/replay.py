@@ -63,6 +63,9 @@ class DeviceReplay:
         self._staging = {}             # batch_size -> (flat key -> tensor [B, ...], nested mapping, idx device, pinned idx x2)
         self._flip = 0
         self.host_rng, self.draws = host_rng, 0
+        # device copy of {sample-call count, len(self), workgroup ticket}: the sampling launch reads its per-call values from here
+        # (and advances the count itself), so a captured update step can contain it (`sample(..., launch=False)`)
+        self.state = torch.zeros(3, dtype=torch.int64, device=device)
         self.items, self.item_index, self.need_update = None, 0, False    # without-replacement state (sampling_strategy.py:21-24)
 
     # -- ring ------------------------------------------------------------------------------------------
@@ -72,6 +75,13 @@ class DeviceReplay:
     def reset(self):
         self.position = self.running_count = 0
         self.items, self.item_index = None, 0
+        self.state[1:2].fill_(0)
+
+    @property
+    def graph_sampling(self):
+        """True when `sample` is one launch that reads nothing from the host: an agent may capture it in its step graph and
+        call `sample(batch_size, launch=False)` on replays (bookkeeping only)."""
+        return not self.host_rng
 
     def _as_tensor(self, v):
         t = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
@@ -96,6 +106,7 @@ class DeviceReplay:
                 self.storage[k][:n - first].copy_(v[first:])
         self.running_count += n
         self.position = (self.position + n) % self.capacity
+        self.state[1:2].fill_(len(self))
         self.need_update = True                              # OneStepTransition.push_batch (sampling_strategy.py:80-83)
 
     def get_all(self):
@@ -159,7 +170,17 @@ class DeviceReplay:
         self.item_index += batch_size
         return index
 
-    def sample(self, batch_size, auto_restart=True, drop_last=True):
+    def launch_sample(self, batch_size):
+        """The sampling launch alone (device-drawn rows into the staging batch), not counted as a call: what an agent puts at
+        the head of its captured step; every later `sample(batch_size, launch=False)` stands for one replay of it."""
+        assert self.graph_sampling, "host-drawn row numbers cannot be captured"
+        flat, sample, idx, pinned, segs = self._stage(batch_size)
+        hip.replay_sample_gather_state(segs, batch_size, self.capacity, self.seed, self.state, idx)
+        return sample
+
+    def sample(self, batch_size, auto_restart=True, drop_last=True, launch=True):
+        """launch=False (only with `graph_sampling`): the caller replays a hipGraph that contains this call's launch -- the
+        staging batch is returned and the call is counted, nothing is launched here."""
         size = len(self)
         if size == 0:
             raise RuntimeError("sampling from an empty replay buffer")
@@ -175,8 +196,8 @@ class DeviceReplay:
             host.numpy()[:] = index
             idx.copy_(host, non_blocking=True)
             hip.replay_gather(segs, idx, self.capacity)
-        else:
-            hip.replay_sample_gather(segs, batch_size, size, self.capacity, self.seed, self.draws, idx)
+        elif launch:
+            hip.replay_sample_gather_state(segs, batch_size, self.capacity, self.seed, self.state, idx)
         self.draws += 1
         return sample
 

@@ -5,6 +5,8 @@ bucketed gradients inside every backward (pyrl/utils/torch/module_utils.py:322-3
 Here every optimizer owns ONE flat gradient buffer, so the exchange is a single sum all-reduce per
 backward; the 1/world factor is folded into the fused optimizer kernel's `grad_scale`.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -17,14 +19,23 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
+def exchange_active():
+    """True when gradient exchanges have to run: more than one rank -- or one rank with PCRL_EXCHANGE_SINGLE_RANK=1, which
+    drives the whole exchange path (segmented graphs, async RCCL all-reduces on the process group's stream, the waits)
+    through a one-rank process group; a one-rank SUM leaves the buffer as it is, so the step must equal the plain one bit
+    for bit (tests/test_data_parallel_gpu.py runs RCCL itself this way on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("PCRL_EXCHANGE_SINGLE_RANK", "0") == "1"
+
+
 def allreduce_sum_(flat_grad, enabled=True):
     """In-place SUM all-reduce of a flat gradient buffer.  Returns the scale (1/world) the caller must
     apply to obtain the mean, 1.0 when nothing was exchanged."""
-    w = world_size()
-    if not enabled or w == 1:
+    if not enabled or not exchange_active():
         return 1.0
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
-    return 1.0 / w
+    return 1.0 / world_size()
 
 
 class Exchange:
@@ -36,7 +47,7 @@ class Exchange:
     the encoder backward starts, and the small encoder + feature-head range after it."""
 
     def __init__(self, enabled=True):
-        self.enabled = enabled and world_size() > 1
+        self.enabled = enabled and exchange_active()
         self.pending = []
         self.scale = 1.0 / world_size() if self.enabled else 1.0
 
@@ -53,7 +64,7 @@ class Exchange:
 
 def broadcast_parameters_(module, src=0):
     """Make every rank start from rank `src`'s weights (what DDP's constructor does implicitly)."""
-    if world_size() == 1:
+    if not exchange_active():
         return
     for p in module.parameters():
         dist.broadcast(p.data, src)

@@ -231,9 +231,9 @@ class BaseAgent(ExtendedModule):
         before building the agent (run_rl.py:263), so without that broadcast the replicas would start from different
         weights and, with only gradients averaged, never meet.  Same effect here: every parameter of the agent
         (actor, critic, target critic, log_alpha; in place, so flat-buffer views stay valid) is broadcast from rank 0."""
-        from .dist import broadcast_parameters_, world_size
+        from .dist import broadcast_parameters_, exchange_active
         self._device_ids = device_ids
-        if world_size() > 1:
+        if exchange_active():
             broadcast_parameters_(self)
             for enc in (m for m in self.modules() if hasattr(m, "invalidate_packed")):
                 enc.invalidate_packed()

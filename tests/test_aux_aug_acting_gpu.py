@@ -442,3 +442,64 @@ def test_fused_acting_path_equals_the_module_tree(cuda):
     for a, b in zip(out[True], out[False]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5, rtol=0)
     assert not torch.equal(out[True][0], out[True][1])
+
+
+def test_state_driven_sampling_launch_equals_the_explicit_one_and_counts_itself(cuda):
+    """pcrl_replay_sample_gather_state reads (draw, size) from device memory and advances draw itself: same rows as the launch that
+    gets them as arguments, call after call, also when the valid size changes between calls."""
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A, B = 96, 32, 4, 48
+    mem = DeviceReplay(cap, device=cuda, seed=21)
+    mem.push_batch(make_batch_np(40, N, A, seed=3))
+    ref_idx = torch.zeros(B, dtype=torch.int32, device=cuda)
+    for call in range(6):
+        if call == 3:
+            mem.push_batch(make_batch_np(30, N, A, seed=4))                 # size 40 -> 70
+        assert mem.state.tolist() == [call, len(mem), 0]
+        mem.sample(B)
+        flat, _, idx, _, segs = mem._stage(B)
+        got = {k: v.clone() for k, v in flat.items()}
+        hip.replay_sample_gather(segs, B, len(mem), cap, mem.seed, call, ref_idx)
+        assert torch.equal(idx, ref_idx) and int(idx.max()) < len(mem)
+        for k, v in flat.items():
+            assert torch.equal(v, got[k]), k
+    assert mem.state.tolist() == [6, 70, 0] and mem.draws == 6
+
+
+def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
+    """With a DeviceReplay that draws its rows on the device, the sampling launch is the first node of the captured step and
+    the metrics come back through the pinned mirror's flag (no copy node, no stream synchronisation): every returned metric and
+    every parameter equal the eager run's bit for bit, and the replay counted every call."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A, steps = 8, 64, 4, 12
+
+    def run(graphs):
+        cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        mem = DeviceReplay(64, device=cuda, seed=3)
+        mem.push_batch(make_batch_np(48, N, A, seed=5))
+        if graphs:
+            agent.enable_graphs(warmup=1)
+        rets = []
+        for u in range(1, steps + 1):
+            if u == 7:
+                mem.push_batch(make_batch_np(16, N, A, seed=6))            # the ring grows between two replays
+            rets.append(agent.update_parameters(mem, u))
+        torch.cuda.synchronize()
+        return agent, mem, rets
+
+    eager, mem_e, rets_e = run(False)
+    graph, mem_g, rets_g = run(True)
+    assert len(graph._graphs) == 2 and all(s is mem_g for s in graph._graph_sampler.values()) and len(graph._graph_flag) == 2
+    assert mem_g.draws == mem_e.draws == steps and mem_g.state.tolist() == mem_e.state.tolist() == [steps, 64, 0]
+    for ra, rb in zip(rets_e, rets_g):
+        assert ra == rb
+    for (n, p), (_, q) in zip(eager.named_parameters(), graph.named_parameters()):
+        assert torch.equal(p, q), n

@@ -144,3 +144,66 @@ def test_overlapped_exchange_pieces_cover_the_flat_buffer_once(cuda):
     base = fc.grad.data_ptr()
     assert b_ptr == base and a_ptr == base + 4 * b_n and a_n + b_n == fc.grad.numel() and a_n > 0 and b_n > 0
     assert seen[2][0] == (fa.grad.data_ptr(), fa.grad.numel())
+
+
+def _rccl_worker(rank, port, graphs, exchange, out):
+    """One rank; with `exchange` the data-parallel schedule runs over a one-rank RCCL group (PCRL_EXCHANGE_SINGLE_RANK)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PCRL_EXCHANGE_SINGLE_RANK="1" if exchange else "0")
+    torch.cuda.set_device(0)
+    if exchange:
+        dist.init_process_group("nccl", rank=0, world_size=1)       # "nccl" is RCCL on ROCm
+    agent = _agent(B)
+    if exchange:
+        agent.to_ddp(device_ids=["cuda"])
+        assert agent.is_data_parallel()
+    if graphs:
+        agent.enable_graphs(warmup=1)
+    mem = _memory(slice(0, B))
+    rets = []
+    for u in range(1, STEPS + 1 + (4 if graphs else 0)):
+        if not graphs:
+            agent.actor.head.noise_override = [e.to("cuda:0") for e in _eps(u)][:2 if u % 2 == 0 else 1]
+        rets.append(agent.update_parameters(mem, u))
+    if graphs and exchange:
+        assert all(len(segs) >= 2 for segs, _, _ in agent._graphs.values())      # cut at every exchange
+    if graphs and not exchange:
+        assert all(len(segs) == 1 for segs, _, _ in agent._graphs.values())
+    torch.cuda.synchronize()
+    torch.save({"params": {n: p.detach().cpu() for n, p in agent.named_parameters()}, "rets": rets}, os.path.join(out, f"x{int(exchange)}.pt"))
+    if exchange:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
+def test_rccl_single_rank_exchange_equals_plain_step(cuda, graphs):
+    """RCCL itself (backend "nccl"), which refuses two ranks on the one GPU of the test box, driven with ONE rank: the step runs the
+    data-parallel schedule -- segmented hipGraphs, the Q-head range all-reduced asynchronously on RCCL's stream under the encoder
+    backward, the waits before each optimizer pass -- and, a one-rank sum being the identity, must equal the plain step bit for bit."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as out:
+        for exchange in (True, False):
+            mp.spawn(_rccl_worker, args=(_free_port(), graphs, exchange, out), nprocs=1, join=True)
+        a, b = torch.load(os.path.join(out, "x1.pt")), torch.load(os.path.join(out, "x0.pt"))
+    for n in a["params"]:
+        assert torch.equal(a["params"][n], b["params"][n]), n
+    for ra, rb in zip(a["rets"], b["rets"]):
+        assert ra.keys() == rb.keys()
+        for k in ra:
+            assert ra[k] == rb[k] or (np.isnan(ra[k]) and np.isnan(rb[k])), k
+
+
+def test_bench_single_rank_exchange_over_rccl(cuda):
+    """bench.py's data-parallel leg (process group, to_ddp, segmented graphs, comm / no-comm timing) over RCCL with one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "6", "--backend", "nccl", "--single-rank-exchange",
+           "--no-cpu-baseline", "--replay-capacity", "512"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "debug" in d and d["value"] > 0
+    assert "ms_per_step_nocomm" in d and "comm_ms_per_step" in d
+    assert d["config"]["graph_variants"] >= 2 if "graph_variants" in d["config"] else True
