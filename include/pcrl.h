@@ -389,8 +389,8 @@ int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32
                               uint64_t seed, uint64_t draw, int32_t* idx_out, void* stream);
 /* The same launch with its two per-call values read from device memory, so that it can be a node of a replayed hipGraph
  * (the sampling becomes part of the captured update step): state[0] = draw (the launch's last workgroup to finish advances
- * it by one), state[1] = size (the host stores len(buffer) there after every push), state[2] = workgroup ticket (0 between
- * launches).  Same rows as pcrl_replay_sample_gather(..., size = state[1], draw = state[0], ...). */
+ * it by one), state[1] = size (the host stores len(buffer) there after every push), state[2] and state[3 .. 3 + B) =
+ * workgroup tickets (0 between launches; `state` holds 3 + B words).  Same rows as pcrl_replay_sample_gather(..., size = state[1], draw = state[0], ...). */
 int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t capacity, uint64_t seed,
                                     uint64_t* state, int32_t* idx_out, void* stream);
 
@@ -400,9 +400,10 @@ int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs,
 int pcrl_gather_scalars_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
                             const pcrl_adam_pending* pending, int32_t n_pending, void* stream);
 /* Same, and the n gathered values are also stored to host_out[0..n) -- pinned host memory the device can address
- * (hipHostMalloc / torch pin_memory) -- followed, after a system-scope fence, by host_out[n] = 1.0f: a host that cleared
- * host_out[n] before the launch reads the step's metrics as soon as the flag turns, without a device->host copy node in
- * the captured step and without a stream synchronisation (the `.item()` reads of sac.py:150-159,199-204). */
+ * (hipHostMalloc / torch pin_memory) -- each as one 4-byte store.  A host that filled the n slots with the bit pattern
+ * 0xFFFFFFFF before the launch reads a metric as soon as its slot holds anything else (a value with that pattern is stored
+ * as the canonical NaN): no device->host copy node in the captured step and no stream synchronisation for the `.item()`
+ * reads of sac.py:150-159,199-204. */
 int pcrl_gather_scalars_host_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
                                  const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream);
 

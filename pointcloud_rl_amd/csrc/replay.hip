@@ -15,7 +15,7 @@ struct GatherParams {
     const int* idx; int B; long long capacity;
     // idx == NULL: row b is drawn in the kernel, uniform on [0, size), Philox4x32-10 keyed by seed, counter (b, draw)
     int* idx_out; unsigned size, seed_lo, seed_hi, draw_lo, draw_hi;
-    // state != NULL: draw and size come from device memory ({draw, size, ticket}); the last workgroup advances draw
+    // state != NULL: draw and size come from device memory ({draw, size, ticket, B row tickets}); the last workgroup advances draw
     unsigned long long* state;
 };
 
@@ -36,16 +36,21 @@ __global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p
         row = (long long)(((unsigned long long)w[0] * size) >> 32);       // multiply-shift: bias < size / 2^32
         if (seg == 0 && threadIdx.x == 0 && p.idx_out) p.idx_out[b] = (int)row;
         if (p.state) {
-            // every workgroup has read the draw count before it takes a ticket; the one that takes the last ticket is the
-            // only one left, advances the count for the next launch and puts the ticket counter back to zero
+            // Every workgroup has read the draw count before it takes a ticket.  Tickets are two-level so that no address sees
+            // more than gridDim.y + gridDim.x atomics (thousands on ONE address serialise in L2: 56 us for 2 816 workgroups):
+            // the last workgroup of a row takes a global ticket, the last of those is the only workgroup left -- it advances
+            // the count for the next launch; every counter is put back to zero by its last taker.
+            // (No __threadfence here: on a multi-XCD part a device-scope release writes the XCD's whole L2 back -- measured
+            // 50 us with the previous step's dirty lines in it.  None is needed: the barrier waits for the loads above, the
+            // tickets are device-scope atomics, and the plain stores below only have to be visible to the NEXT launch.)
             __syncthreads();
             if (threadIdx.x == 0) {
-                __threadfence();
-                const unsigned long long total = (unsigned long long)gridDim.x * gridDim.y;
-                if (atomicAdd(p.state + 2, 1ull) == total - 1) {
-                    p.state[2] = 0ull;
-                    p.state[0] = (((unsigned long long)draw_hi << 32) | draw_lo) + 1ull;
-                    __threadfence();
+                if (atomicAdd(p.state + 3 + b, 1ull) == (unsigned long long)gridDim.y - 1) {
+                    p.state[3 + b] = 0ull;
+                    if (atomicAdd(p.state + 2, 1ull) == (unsigned long long)gridDim.x - 1) {
+                        p.state[2] = 0ull;
+                        p.state[0] = (((unsigned long long)draw_hi << 32) | draw_lo) + 1ull;
+                    }
                 }
             }
         }

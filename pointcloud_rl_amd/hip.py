@@ -489,9 +489,9 @@ def replay_sample_gather(segs, B, size, capacity, seed, draw, idx_out=None):
 
 
 def replay_sample_gather_state(segs, B, capacity, seed, state, idx_out=None):
-    """The same launch with (draw, size) read from the device int64 tensor `state` [3] = {draw, size, ticket}; the launch advances
-    draw itself, so it can be replayed from a hipGraph."""
-    assert state.is_cuda and state.dtype == torch.int64 and state.numel() >= 3 and state.is_contiguous()
+    """The same launch with (draw, size) read from the device int64 tensor `state` [3 + B] = {draw, size, ticket, B row tickets};
+    the launch advances draw itself, so it can be replayed from a hipGraph."""
+    assert state.is_cuda and state.dtype == torch.int64 and state.numel() >= 3 + B and state.is_contiguous()
     with _span("replay_gather"):
         check(lib().pcrl_replay_sample_gather_state(segs, len(segs), B, ctypes.c_int64(capacity), ctypes.c_uint64(seed & (2 ** 64 - 1)),
                                                     _ptr(state), _ptr(idx_out), _stream()))
@@ -500,7 +500,8 @@ def replay_sample_gather_state(segs, B, capacity, seed, state, idx_out=None):
 def gather_scalars(entries, pending=(), host_out=None):
     """entries: [(src scalar tensor, dst scalar tensor, take_exp)] -> dst = exp?(src), one launch for up to 16 scalars;
     pending: AdamPending objects of deferred adam_step calls, finished by the same launch before the copies;
-    host_out: pinned float32 host tensor [>= n + 1] that also receives the n values, then 1.0 at [n] (the "ready" flag)."""
+    host_out: pinned float32 host tensor [>= n] that also receives the n values, one 4-byte store each (a host that pre-filled
+    the slots with the bit pattern 0xFFFFFFFF sees a value as soon as its slot changes)."""
     n = len(entries)
     pend = (_lib.AdamPending * max(len(pending), 1))(*pending)
     src = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
@@ -509,7 +510,7 @@ def gather_scalars(entries, pending=(), host_out=None):
     if host_out is None:
         check(lib().pcrl_gather_scalars_f32(src, dst, flags, n, pend, len(pending), _stream()))
         return
-    assert host_out.dtype == torch.float32 and host_out.is_pinned() and host_out.numel() >= n + 1 and host_out.is_contiguous()
+    assert host_out.dtype == torch.float32 and host_out.is_pinned() and host_out.numel() >= n and host_out.is_contiguous()
     check(lib().pcrl_gather_scalars_host_f32(src, dst, flags, n, pend, len(pending), ctypes.c_void_p(host_out.data_ptr()), _stream()))
 
 

@@ -19,7 +19,7 @@ from ..networks.pointnet import PointNet
 
 class PackedStats(dict):
     """name -> device scalar (views into `packed`, one contiguous float32 tensor in the same order); `host`: pinned float32
-    tensor that receives the same values from the launch that fills `packed`, followed by a ready flag (hip.gather_scalars)."""
+    tensor that receives the same values from the launch that fills `packed`, one 4-byte store per value (hip.gather_scalars)."""
     packed = None
     host = None
 

@@ -538,7 +538,7 @@ class SAC(BaseAgent):
         segments, names, out = self._graphs[key]
         flag = self._graph_flag.get(key)
         if flag is not None:
-            flag[0][flag[1]] = 0.0                  # "ready" flag of the pinned metrics mirror, set by the step's last kernel
+            flag[0][:flag[1]] = 0xFFFFFFFF          # sentinel in every slot of the pinned metrics mirror (the step's last kernel fills them)
         ex = Exchange()
         for graph, (kind, pieces) in segments:
             graph.replay()
@@ -558,17 +558,17 @@ class SAC(BaseAgent):
 
     @staticmethod
     def _await_flag(view, n):
-        """Spin on the pinned mirror's flag (the step's last kernel stores the metrics, fences, then stores the flag): no stream
-        synchronisation, no copy node.  A step that has not finished after 20 s is reported through the stream's error."""
-        spins = 0
-        while view[n] == 0.0:
+        """Spin until the step's last kernel has stored all n metrics into the pinned mirror (slots pre-filled with the sentinel
+        0xFFFFFFFF; `view` is the mirror as uint32): no stream synchronisation, no copy node.  If the stream drains without the
+        slots changing, the launch failed and the error is raised from the synchronisation."""
+        slots, spins = view[:n], 0
+        while (slots == 0xFFFFFFFF).any():
             spins += 1
-            if spins & 0xFFFFF == 0:                # every ~1 M polls (~0.1 s): give a failed launch the chance to surface
-                if torch.cuda.current_stream().query() and view[n] == 0.0:
-                    torch.cuda.synchronize()
-                    if view[n] == 0.0:
-                        raise RuntimeError("update step finished without publishing its metrics")
-        return view[:n].tolist()
+            if spins & 0xFFFF == 0 and torch.cuda.current_stream().query():
+                torch.cuda.synchronize()
+                if (slots == 0xFFFFFFFF).any():
+                    raise RuntimeError("update step finished without publishing its metrics")
+        return slots.view(np.float32).tolist()
 
     def _capture_whole(self, batch, do_actor, polyak, pre=None):
         graph = torch.cuda.CUDAGraph()
@@ -585,7 +585,7 @@ class SAC(BaseAgent):
             mirror = getattr(stats, "host", None)
             out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
             if mirror is not None:          # the step's last kernel stored the metrics to pinned host memory itself
-                self._graph_flag[key] = (mirror.numpy(), len(names))
+                self._graph_flag[key] = (mirror.numpy().view(np.uint32), len(names))
             elif packed is not None:        # the metrics land in pinned host memory as the graph's last node
                 host = pinned[:len(names)]
                 host.copy_(out, non_blocking=True)
@@ -619,7 +619,7 @@ class SAC(BaseAgent):
                     names = list(stats.keys())
                     out = torch.stack([stats[k].reshape(()).float() for k in names])
                     if getattr(stats, "host", None) is not None:
-                        self._graph_flag[(do_actor, polyak, True)] = (stats.host.numpy(), len(names))
+                        self._graph_flag[(do_actor, polyak, True)] = (stats.host.numpy().view(np.uint32), len(names))
             kind, pieces = exchange
             graph.replay()
             for t in pieces:
@@ -689,7 +689,7 @@ class SAC(BaseAgent):
                 return None
         segments, names, view, n, _ = entry
         memory.sample(self.batch_size, launch=False)
-        view[n] = 0.0
+        view[:n] = 0xFFFFFFFF
         if exchanging:
             ex = Exchange()
             for graph, (kind, pieces) in segments:

@@ -48,6 +48,8 @@ def _flatten(items, prefix=""):
 
 
 class DeviceReplay:
+    MAX_BATCH = 16384         # rows per sample() the launch's ticket words are sized for
+
     def __init__(self, capacity, device="cuda", seed=None, with_replacement=True, host_rng=False):
         device = torch.device(device)
         if device.type != "cuda":
@@ -65,7 +67,7 @@ class DeviceReplay:
         self.host_rng, self.draws = host_rng, 0
         # device copy of {sample-call count, len(self), workgroup ticket}: the sampling launch reads its per-call values from here
         # (and advances the count itself), so a captured update step can contain it (`sample(..., launch=False)`)
-        self.state = torch.zeros(3, dtype=torch.int64, device=device)
+        self.state = torch.zeros(3 + self.MAX_BATCH, dtype=torch.int64, device=device)
         self.items, self.item_index, self.need_update = None, 0, False    # without-replacement state (sampling_strategy.py:21-24)
 
     # -- ring ------------------------------------------------------------------------------------------
@@ -175,6 +177,7 @@ class DeviceReplay:
         the head of its captured step; every later `sample(batch_size, launch=False)` stands for one replay of it."""
         assert self.graph_sampling, "host-drawn row numbers cannot be captured"
         flat, sample, idx, pinned, segs = self._stage(batch_size)
+        assert batch_size <= self.MAX_BATCH
         hip.replay_sample_gather_state(segs, batch_size, self.capacity, self.seed, self.state, idx)
         return sample
 
@@ -197,6 +200,7 @@ class DeviceReplay:
             idx.copy_(host, non_blocking=True)
             hip.replay_gather(segs, idx, self.capacity)
         elif launch:
+            assert batch_size <= self.MAX_BATCH
             hip.replay_sample_gather_state(segs, batch_size, self.capacity, self.seed, self.state, idx)
         self.draws += 1
         return sample

@@ -457,7 +457,7 @@ def test_state_driven_sampling_launch_equals_the_explicit_one_and_counts_itself(
     for call in range(6):
         if call == 3:
             mem.push_batch(make_batch_np(30, N, A, seed=4))                 # size 40 -> 70
-        assert mem.state.tolist() == [call, len(mem), 0]
+        assert mem.state[:3].tolist() == [call, len(mem), 0] and int(mem.state[3:].abs().sum()) == 0
         mem.sample(B)
         flat, _, idx, _, segs = mem._stage(B)
         got = {k: v.clone() for k, v in flat.items()}
@@ -465,7 +465,7 @@ def test_state_driven_sampling_launch_equals_the_explicit_one_and_counts_itself(
         assert torch.equal(idx, ref_idx) and int(idx.max()) < len(mem)
         for k, v in flat.items():
             assert torch.equal(v, got[k]), k
-    assert mem.state.tolist() == [6, 70, 0] and mem.draws == 6
+    assert mem.state[:3].tolist() == [6, 70, 0] and int(mem.state[3:].abs().sum()) == 0 and mem.draws == 6
 
 
 def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
@@ -498,7 +498,7 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
     eager, mem_e, rets_e = run(False)
     graph, mem_g, rets_g = run(True)
     assert len(graph._graphs) == 2 and all(s is mem_g for s in graph._graph_sampler.values()) and len(graph._graph_flag) == 2
-    assert mem_g.draws == mem_e.draws == steps and mem_g.state.tolist() == mem_e.state.tolist() == [steps, 64, 0]
+    assert mem_g.draws == mem_e.draws == steps and mem_g.state[:3].tolist() == mem_e.state[:3].tolist() == [steps, 64, 0]
     for ra, rb in zip(rets_e, rets_g):
         assert ra == rb
     for (n, p), (_, q) in zip(eager.named_parameters(), graph.named_parameters()):
