@@ -619,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
 // GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
 // through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
 constexpr int kTileTabBytes = 256 + 4 * 256;       // per wave: slot bytes + dx floats of the tile's cloud (c3 <= 256)
-constexpr int kMaxTileModeClouds = 256;           // tile mode needs the clouds' tile prefix in LDS
+constexpr int kMaxTileModeClouds = 2048;          // tile mode keeps the clouds' tile prefix in LDS
 template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
@@ -647,10 +647,18 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
         for (int i = tid; i < 2 * kC2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
         for (int i = tid; i < 2 * kC3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
         if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
-        if (tid == 0) {           // exclusive prefix of the clouds' tile counts (B <= 256: a serial walk is ~1 us)
+        if (wave == 0) {          // exclusive prefix of the clouds' tile counts: 64 clouds per wave-wide scan step
             int run = 0;
-            for (int b = 0; b < p.cl.B; ++b) { s_tstart[b] = run; run += (p.n_act[b] + 31) >> 5; }
-            s_tstart[p.cl.B] = run;
+            for (int b0 = 0; b0 < p.cl.B; b0 += 64) {
+                const int b = b0 + lane;
+                const int nt = b < p.cl.B ? (p.n_act[b] + 31) >> 5 : 0;
+                int inc = nt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int up = __shfl_up(inc, off, 64); if (lane >= off) inc += up; }
+                if (b < p.cl.B) s_tstart[b] = run + inc - nt;
+                run += __shfl(inc, 63, 64);
+            }
+            if (lane == 0) s_tstart[p.cl.B] = run;
         }
     }
     __syncthreads();
@@ -662,11 +670,10 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 
     // Work items: the tiles of all clouds form one list and wave w of workgroup g takes item w * grid + g, so the first
     // `grid` items go to wave 0 of every workgroup (one tile per SIMD before any SIMD gets a second one).  With B < #CUs
-    // there are at most 8 * B <= 8 * grid items: one per wave at most.
-    {
+    // there are at most 8 * B <= 8 * grid items: one per wave at most; a larger batch makes further rounds of the same deal.
+    const int n_items = s_tstart[p.cl.B];
+    for (int item = wave * (int)gridDim.x + (int)blockIdx.x; item < n_items; item += 8 * (int)gridDim.x) {
         int b, tile, n_act;
-        const int item = wave * (int)gridDim.x + (int)blockIdx.x;
-        if (item >= s_tstart[p.cl.B]) return;
         {
             int lo = 0, hi = p.cl.B;             // largest b with s_tstart[b] <= item
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tstart[mid] <= item) lo = mid; else hi = mid; }
@@ -1221,7 +1228,14 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     p.pt = reinterpret_cast<float2*>(base + ws.pt); p.n1part = reinterpret_cast<float*>(base + ws.n1part);
     p.grads = grads;
     if (p.cl.N > 32 * kBitmapMaxWords) return fail(PCRL_E_ARG, "encoder backward: N = %d > %d points per cloud", p.cl.N, 32 * kBitmapMaxWords);
-    p.tile_mode = (p.cl.B < num_cus() && p.cl.B <= kMaxTileModeClouds) ? 1 : 0;
+    {
+        static const int forced = [] { const char* e = getenv("PCRL_BWD_TILE_MODE"); return e ? atoi(e) : -1; }();   // -1: automatic
+        // measured (tools/bench_encoder.py, PCRL_BWD_TILE_MODE=0/1): dealing single tiles over all SIMDs also wins for large
+        // batches of the c1 = 64 shapes (B 256: 212 -> 207 us, B 1024: 822 -> 739 us); with c1 = 128 the two schedules tie
+        // (946 vs 960 us at B 1024, N 1200) and the one-workgroup-per-cloud kernel stays
+        const bool automatic = p.cl.B < num_cus() || w->c1 <= 64;
+        p.tile_mode = (forced >= 0 ? forced != 0 : automatic) && p.cl.B <= kMaxTileModeClouds ? 1 : 0;
+    }
     p.parts = 1;
     while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;
 
