@@ -142,8 +142,10 @@ class RefAgent:
 
     def __init__(self, params, kind="sac", gamma=0.99, reward_scale=1.0, alpha=0.1, target_entropy=None,
                  actor_update_interval=2, target_update_interval=2, update_coeff=0.01, num_aug=2,
-                 jitter_range=None, lr=1e-3, alpha_betas=(0.5, 0.999), mirror_redundancy=True):
+                 jitter_range=None, lr=1e-3, alpha_betas=(0.5, 0.999), mirror_redundancy=True, svea=False):
         self.kind, self.gamma, self.reward_scale = kind, gamma, reward_scale
+        self.svea = bool(svea)          # drq.py:24-28: num_aug must be 1
+        assert not self.svea or (kind == "drq" and num_aug == 1)
         self.actor_update_interval, self.target_update_interval = actor_update_interval, target_update_interval
         self.update_coeff, self.num_aug, self.jitter_range = update_coeff, num_aug, jitter_range
         self.mirror_redundancy = mirror_redundancy
@@ -227,7 +229,13 @@ class RefAgent:
         obs, next_obs = batch["obs"], batch["next_obs"]
         actions, rewards, dones = batch["actions"], batch["rewards"], batch["dones"]
         B = actions.shape[0]
-        if self.kind == "drq":
+        plain_obs = obs
+        if self.kind == "drq" and self.svea:
+            # drq.py:62-67: rows [aug(s_b), s_b] interleaved; s', rewards and dones are neither augmented nor repeated
+            aug = self._aug(obs, jitter_list[0] if jitter_list else None)
+            obs = {k: torch.stack([aug[k], v], dim=1).flatten(0, 1) for k, v in obs.items()}
+            actions = torch.repeat_interleave(actions, 2, dim=0)
+        elif self.kind == "drq":
             # drq.py:52-63
             obs = self._aug(obs, jitter_list[0] if jitter_list else None)
             next_obs = self._aug(next_obs, jitter_list[1] if jitter_list else None)
@@ -239,10 +247,11 @@ class RefAgent:
             q_next = self.critic(next_obs, next_a, which="target_critic")
             min_q_next = torch.min(q_next, dim=-1, keepdim=True).values
             min_q_next = min_q_next + self.alpha * neg_logp
-            if self.kind == "drq":    # drq.py:79-87 (no reward_scale; mean over the aug axis)
+            if self.kind == "drq":    # drq.py:79-88 (no reward_scale; mean over the aug axis, SVEA: one target per [aug, plain] pair)
                 q_target = rewards + (1 - dones.float()) * self.gamma * min_q_next
-                q_target = q_target.reshape(B, self.num_aug).mean(1, keepdim=True)
-                q_target = torch.repeat_interleave(q_target, self.num_aug, dim=0).repeat(1, q_next.shape[-1])
+                if not self.svea:
+                    q_target = q_target.reshape(B, self.num_aug).mean(1, keepdim=True)
+                q_target = torch.repeat_interleave(q_target, self.num_aug + int(self.svea), dim=0).repeat(1, q_next.shape[-1])
             else:                      # sac.py:131-134
                 q_target = rewards * self.reward_scale + (1 - dones.float()) * self.gamma * min_q_next
                 q_target = q_target.repeat_interleave(q_next.shape[-1], dim=-1)
@@ -262,7 +271,9 @@ class RefAgent:
             f"{pre}/target_entropy": self.target_entropy, f"{pre}/critic_grad": critic_grad, f"{pre}/grad_steps": 1,
         }
         if updates % self.actor_update_interval == 0:
-            if self.kind == "drq":    # drq.py:115: first augmentation of every sample
+            if self.kind == "drq" and self.svea:     # drq.py:115: the sampled (plain) observations
+                a_obs = plain_obs
+            elif self.kind == "drq":  # drq.py:115: first augmentation of every sample
                 a_obs = {k: v.reshape(B, self.num_aug, *v.shape[1:])[:, 0] for k, v in obs.items()}
             else:
                 a_obs = obs

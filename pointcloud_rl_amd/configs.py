@@ -79,10 +79,10 @@ def sac_maniskill(pcd_channels=7, action_dim=22, agent_dim=68, batch_size=256, h
     return cfg
 
 
-def drq_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, obs_aug=JITTER, num_aug=2):
+def drq_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, obs_aug=JITTER, num_aug=2, svea=False):
     """configs/mfrl/drq/dm_control/{base/pn_base.py, pn_jitter.py}"""
     cfg = _agent_cfg("DrQ", DMC_NETS, pcd_channels, action_dim, 0, batch_size, 0.95, head_hidden,
-                     dict(num_aug=num_aug, svea=False, obs_aug=dict(obs_aug) if obs_aug else None))
+                     dict(num_aug=num_aug, svea=svea, obs_aug=dict(obs_aug) if obs_aug else None))
     cfg["critic_cfg"]["nn_cfg"]["mlp_cfg"]["bias"] = True
     return cfg
 

@@ -1,15 +1,18 @@
 """DrQ agent (data-regularised Q) on the MI355X hot path.
 
-Contract of the reference's pyrl/methods/mfrl/drq.py:21-165 (svea=False): every sample is
+Contract of the reference's pyrl/methods/mfrl/drq.py:21-165.  svea=False (every shipped pn_* config): every sample is
 augmented `num_aug` times (repeat_interleave, independent noise for obs and next_obs), the TD
 target is averaged over a sample's augmentations, the critic trains on all B*num_aug clouds and
 the actor on augmentation #0 of every sample.  The augmentation itself is fused into the encoder
-kernel's load (pointcloud_rl_amd/augmentations.py).
+kernel's load (pointcloud_rl_amd/augmentations.py).  svea=True (drq.py:62-67,87-88,115; num_aug must be 1): the critic
+trains on [augmented s_b, plain s_b] pairs against ONE target per sample computed from the plain s'_b, the actor on the
+plain observations -- no shipped config turns it on, so it runs on the HIP encoder + autograd-heads path, not on the
+fused launch sequence.
 """
 import torch
 
 from ..augmentations import build_data_augmentations
-from ..networks.pointnet import AugmentedObs
+from ..networks.pointnet import AugmentedObs, materialize
 from ..utils.torch_utils import to_torch
 from .builder import MFRL
 from .sac import SAC
@@ -54,7 +57,7 @@ class DrQ(SAC):
     def __init__(self, num_aug=2, obs_aug=None, svea=False, inference_aug=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
         if svea:
-            raise NotImplementedError("SVEA is outside the point-cloud DrQ hot path (svea=False in every pn_* config)")
+            assert num_aug == 1, "SVEA only needs num_aug=1"          # drq.py:24-25 (FusedStep.supported declines such an agent)
         self.num_aug, self.svea = num_aug, svea
         self.obs_aug = build_data_augmentations(obs_aug)
         self.inference_aug = self.obs_aug if inference_aug == "same" else build_data_augmentations(inference_aug)
@@ -86,6 +89,19 @@ class DrQ(SAC):
         if self._fused is not None:
             args, kwargs = self._fused_args(batch, do_actor, polyak)
             return self._fused.run(*args, **kwargs)
+        if self.svea:
+            with torch.no_grad():
+                # GDict.stack([aug(obs), obs], axis=1).merge_axes([0, 1]) (drq.py:64-65): rows 2b = augmented, 2b + 1 = plain
+                aug = materialize(self._augment(batch["obs"]))
+                obs = {k: torch.stack([aug[k].to(v.dtype), v], dim=1).flatten(0, 1) for k, v in batch["obs"].items()}
+                actions = torch.repeat_interleave(batch["actions"], 2, dim=0)
+            stats = {}
+            # next_obs, rewards and dones stay un-augmented, one target per sample, repeated over the pair (drq.py:69-88)
+            q_target = torch.repeat_interleave(self._q_target(batch["next_obs"], batch["rewards"], batch["dones"]), 2, dim=0)
+            self._critic_step(obs, actions, q_target, stats, polyak=polyak)
+            if do_actor:
+                self._actor_step(batch["obs"], stats)                  # drq.py:115: the plain observations
+            return stats
         with torch.no_grad():
             obs = self._augment(batch["obs"])
             actions = torch.repeat_interleave(batch["actions"], self.num_aug, dim=0)

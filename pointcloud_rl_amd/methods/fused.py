@@ -131,6 +131,8 @@ class FusedStep:
     def supported(agent):
         from .sac import HipAdam
         enc = agent.encoder
+        if getattr(agent, "svea", False):        # DrQ(svea=True): [aug, plain] pairs against one target per pair (drq.py:62-88)
+            return False
         if not isinstance(enc, PointNet) or enc.final_mlp is None or not agent._dedup or not agent.detach_actor_feature:
             return False
         if not all(isinstance(getattr(agent, f"{n}_optim"), HipAdam) for n in ("critic", "actor", "alpha")):

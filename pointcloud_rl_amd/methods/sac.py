@@ -656,8 +656,8 @@ class SAC(BaseAgent):
 
     # Steady state of a graph-replayed agent fed by a DeviceReplay: everything `_run_step` decides per call has been decided
     # when the variants were captured, so a call is: count the sample, clear the flag, launch the graph(s), spin on the flag,
-    # build the dict.  Anything unusual (a variant not captured yet, another replay object, a changed learning rate, the
-    # data-parallel switch flipped, every 128th call for the full hyper-parameter check) falls back to `_run_step`.
+    # build the dict.  Anything unusual (a variant not captured yet, another replay object, a changed learning rate, every
+    # 128th call for the full hyper-parameter check) falls back to `_run_step`.
     def _refresh_fast(self):
         self._fast = None
         if os.environ.get("PCRL_FAST_REPLAY", "1") != "1":
@@ -673,14 +673,13 @@ class SAC(BaseAgent):
             entries[key] = (segments, tuple(names), flag[0], flag[1], sampler)
         if entries:
             opts = (self.critic_optim, self.actor_optim, self.alpha_optim)
-            self._fast = dict(entries=entries, lrs=[(o.param_groups[0], o.param_groups[0]["lr"]) for o in opts], calls=0,
-                              dp=self._be_data_parallel)
+            self._fast = dict(entries=entries, lrs=[(o.param_groups[0], o.param_groups[0]["lr"]) for o in opts], calls=0)
 
     def _replay_fast(self, fast, memory, updates):
         fast["calls"] += 1
-        if fast["calls"] & 127 == 0 or self._be_data_parallel != fast["dp"] or not self._use_graphs:
+        if fast["calls"] & 127 == 0 or not self._use_graphs:
             return None
-        exchanging = fast["dp"] and exchange_active()
+        exchanging = self._be_data_parallel and exchange_active()
         entry = fast["entries"].get((updates % self.actor_update_interval == 0, updates % self.target_update_interval == 0, exchanging))
         if entry is None or entry[4] is not memory:
             return None

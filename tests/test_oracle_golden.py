@@ -52,7 +52,8 @@ def make_ref_agent(d, **kw):
     kind = "drq" if str(d["meta/agent_type"]) == "DrQ" else "sac"
     return torch_ref.RefAgent(torch_ref.params_from_fixture(d), kind=kind, gamma=gamma, reward_scale=reward_scale, alpha=alpha,
                               target_entropy=target_entropy, actor_update_interval=int(aui), target_update_interval=int(tui),
-                              update_coeff=float(d["meta/update_coeff_default"]), num_aug=int(num_aug), **kw)
+                              update_coeff=float(d["meta/update_coeff_default"]), num_aug=int(num_aug),
+                              svea=bool(d["meta/svea"]) if "meta/svea" in d.files else False, **kw)
 
 
 def fixture_grad_name(tag, name):

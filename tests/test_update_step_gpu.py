@@ -40,7 +40,8 @@ def build_from_fixture(d, dev, fused=True):
         extra = dict(use_episode_dones=True) if ("meta/use_episode_dones" in d.files and bool(d["meta/use_episode_dones"])) else {}
         cfg = configs.sac_dmc(C, A, B, hidden, nets=nets, **extra)
     elif S == 0:
-        cfg = configs.drq_dmc(C, A, B, hidden)
+        svea = "meta/svea" in d.files and bool(d["meta/svea"])
+        cfg = configs.drq_dmc(C, A, B, hidden, num_aug=int(d["meta/hyper"][6]), svea=svea)
     else:
         cfg = configs.drq_maniskill(C, A, S, B, hidden)
     cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
@@ -85,7 +86,7 @@ def test_update_parameters_matches_reference(cuda, path, fused):
         if hasattr(agent, "obs_aug") and agent.obs_aug is not None:
             agent.obs_aug[0].noise_override = draws(d, u, "jitter", cuda)
         ret = agent.update_parameters(Memory(batch_of(d, u)), u)
-        assert (agent._fused is not None) == fused
+        assert (agent._fused is not None) == (fused and not getattr(agent, "svea", False))     # SVEA: autograd-heads path only
         assert not agent.actor.head.noise_override
         ref_keys = [k for k in d.files if k.startswith(f"u{u}/ret/")]
         assert {k.split("/", 1)[1] for k in ret} == {k[len(f"u{u}/ret/"):] for k in ref_keys}

@@ -111,6 +111,7 @@ def gen_step(name, cfg_file, overrides, obs_kw, B, N, A, n_updates, seed):
                                   agent.target_entropy, agent.actor_update_interval, agent.target_update_interval,
                                   getattr(agent, "num_aug", 1)], dtype=np.float64)
     out["meta/use_episode_dones"] = np.array(bool(getattr(agent, "use_episode_dones", False)))
+    out["meta/svea"] = np.array(bool(getattr(agent, "svea", False)))
     out["meta/update_coeff_default"] = np.array(agent.update_coeff["default"] if isinstance(agent.update_coeff, dict) else agent.update_coeff)
     for k, v in unique_named_params(agent).items():
         out[f"init/{k}"] = np_(v)
@@ -219,6 +220,11 @@ if __name__ == "__main__":
     }
     gen_step("sac_dmc_small", f"{REF}/configs/mfrl/sac/dm_control/pn.py", small_heads, {}, B=8, N=64, A=6, n_updates=4, seed=0)
     gen_step("drq_dmc_jitter_small", f"{REF}/configs/mfrl/drq/dm_control/pn_jitter.py", small_heads, {}, B=4, N=64, A=6, n_updates=4, seed=1)
+    # SVEA (drq.py:62-67,87-88,115): no shipped config sets it, the constructor argument exists; pn_jitter with svea / num_aug 1.
+    # (seed 7: with seed 6 one element of the critic's gradient is a 1.3e-9 cancellation residue, inside Adam's eps band, and the
+    # first update of that element differs by 1e-4 between any two summation orders -- DESIGN.md section 2.)
+    gen_step("drq_svea_dmc_jitter_small", f"{REF}/configs/mfrl/drq/dm_control/pn_jitter.py",
+             dict(small_heads, **{"agent_cfg.svea": True, "agent_cfg.num_aug": 1}), {}, B=4, N=64, A=6, n_updates=4, seed=7)
     # BASELINE config 1 layout (dmc_walker_walk: 3 stacked frames, C = 9 = xyz + rgb + one-hot frame id)
     gen_step("sac_dmc_k0_posenc_small", f"{REF}/configs/mfrl/sac/dm_control/pn.py", small_heads, dict(pos_encoding=3), B=4, N=96, A=6,
              n_updates=2, seed=3)
