@@ -61,10 +61,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-experimental", action="store_true", help="skip the extra (non-headline) run with the split-precision encoder forward")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
-    ap.add_argument("--settle-seconds", type=float, default=5.0, help="after the W warm-up steps keep stepping (untimed) for this long before "
-                    "the timed region: under sustained load an MI355X raises its clocks for several seconds (20 timed steps after 5 / 500 / "
-                    "2000 / 5000 warm-up steps: 1018 / 1074 / 1086 / 1134 steps/s), and the metric is the steady-state rate of a training run; "
-                    "0 times the K steps right after the warm-up")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the cpu_baseline leg (0: every CPU the box grants this process; the "
                     "reference ships torch.set_num_threads(1), pyrl/utils/meta/__init__.py:38-49)")
@@ -233,18 +229,6 @@ def main():
                 break
             updates += 1
             agent.update_parameters(memory, updates)
-    # steady state: the device keeps raising its clocks for several seconds of sustained load (see --settle-seconds)
-    settle_steps, t_settle = 0, time.perf_counter()
-    while True:
-        left = torch.tensor([args.settle_seconds - (time.perf_counter() - t_settle)], device=device, dtype=torch.float64)
-        if dist_on:                       # every rank must take the same number of steps (each one holds collectives)
-            torch.distributed.all_reduce(left, op=torch.distributed.ReduceOp.MAX)
-        if float(left.item()) <= 0.0:
-            break
-        for _ in range(20):
-            updates += 1
-            agent.update_parameters(memory, updates)
-        settle_steps += 20
     graphed = bool(getattr(agent, "_graphs", None))
     n_graph_variants = len(getattr(agent, "_graphs", {}) or {})
     if not graphed:
@@ -324,8 +308,7 @@ def main():
             "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32"), "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
-                       "hip_graphs": graphed, "untimed_settle_steps": settle_steps, "settle_seconds": args.settle_seconds,
-                       "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
+                       "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * agent.encoder.mlp_spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,

@@ -104,7 +104,7 @@ def test_bench_two_ranks_prints_the_contract_line(cuda):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5", "--settle-seconds", "0.2",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
            "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--replay-capacity", "512"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -199,7 +199,7 @@ def test_bench_single_rank_exchange_over_rccl(cuda):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "6", "--settle-seconds", "0.2", "--backend", "nccl", "--single-rank-exchange",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "6", "--backend", "nccl", "--single-rank-exchange",
            "--no-cpu-baseline", "--replay-capacity", "512"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

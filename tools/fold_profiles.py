@@ -13,7 +13,7 @@ for wl in ("k1", "k2", "k3", "k4"):
     if os.path.exists(t) and os.path.exists(b):
         d, bench = json.load(open(t)), json.load(open(b))
         d["command"] = (f"tools/pmc_traffic.sh {wl}: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv "
-                        f"-- python3 bench.py --workload {wl} --no-graphs --steps 20 --warmup 5 --settle-seconds 0 --no-cpu-baseline")
+                        f"-- python3 bench.py --workload {wl} --no-graphs --steps 20 --warmup 5 --no-cpu-baseline")
         d["algorithmic_bytes_per_launch"] = bench["roofline"]["algorithmic_bytes_per_launch"]
         d["note"] = ("in situ (inside the eager update step), averaged over the step's encoder launches (the merged s|s' launch and the actor's "
                      "s launch); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a 16 B/lane streaming read), WRITE_SIZE as reported")

@@ -4,6 +4,6 @@
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/gemm_trace}
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace -d $OUT -- python3 bench.py --steps 60 --warmup 30 --settle-seconds 0 --no-cpu-baseline > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace -d $OUT -- python3 bench.py --steps 60 --warmup 30 --no-cpu-baseline > $OUT/log.txt 2>&1
 python3 tools/_gemm_trace_sum.py $OUT
 find $OUT -name "*.db" -delete

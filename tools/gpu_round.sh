@@ -15,7 +15,7 @@ for wl in $WLS; do
   [ "$wl" = "k4" ] && { steps=200; warm=40; }
   python bench.py --workload $wl --steps $steps --warmup $warm > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; echo "bench $wl rc=$?"
   tail -c 1500 $OUT/bench_$wl.json
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -- python3 bench.py --workload $wl --steps 100 --warmup 30 --settle-seconds 1 --no-cpu-baseline > $OUT/prof_$wl.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$wl -- python3 bench.py --workload $wl --steps 100 --warmup 30 --no-cpu-baseline > $OUT/prof_$wl.log 2>&1
   find $OUT/prof_$wl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_$wl.csv
   find $OUT/prof_$wl -name "*.csv" ! -name "*kernel_stats.csv" -delete; find $OUT/prof_$wl -name "*.db" -delete
   head -25 $OUT/kernel_stats_$wl.csv
