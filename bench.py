@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-experimental", action="store_true", help="skip the extra (non-headline) run with the split-precision encoder forward")
     ap.add_argument("--no-graphs", action="store_true", help="run the step eagerly instead of replaying hipGraphs")
+    ap.add_argument("--device-warmup-seconds", type=float, default=0.5, help="encoder-forward launches (no parameter update, the training "
+                    "state stays where the W warm-up steps left it) right before the timed region")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the cpu_baseline leg (0: every CPU the box grants this process; the "
                     "reference ships torch.set_num_threads(1), pyrl/utils/meta/__init__.py:38-49)")
@@ -229,6 +231,17 @@ def main():
                 break
             updates += 1
             agent.update_parameters(memory, updates)
+    # Device warm-up without touching the training state: a fresh process comes out of graph capture (synchronisations, an idle
+    # device at its lowest P-state a second ago) -- half a second of encoder forward launches on the current batch, no update.
+    if args.device_warmup_seconds > 0 and args.replay == "device":
+        vis = memory.sample(b_rank).to_torch(device=device)["obs"]
+        vis = {k: v for k, v in vis.items() if k in ("xyz", "rgb", "seg", "pos_encoding")}
+        t_w = time.perf_counter()
+        with torch.no_grad():
+            while time.perf_counter() - t_w < args.device_warmup_seconds:
+                for _ in range(20):
+                    agent.encoder.encode_raw(vis)
+                torch.cuda.synchronize()
     graphed = bool(getattr(agent, "_graphs", None))
     n_graph_variants = len(getattr(agent, "_graphs", {}) or {})
     if not graphed:
@@ -308,7 +321,7 @@ def main():
             "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32"), "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
-                       "hip_graphs": graphed, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
+                       "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * agent.encoder.mlp_spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
