@@ -618,6 +618,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
 // inputs, ReLU masks and argmax relations are those of the forward that produced `argmax`) and so do the two data-gradient
 // GEMMs (bf16 transposed weight images, gradients rounded to bf16 as they enter, fp32 accumulation; roundings straight-
 // through).  The weight-gradient GEMMs of kernel B stay fp32 on the unrounded operands.
+#ifdef PCRL_BWD_STAMPS
+// Development build only (-DPCRL_BWD_STAMPS on the fp32 unit): shader-clock stamps at the phase boundaries of a tile's chain,
+// read back with pcrl_debug_bwd_stamps (tools/bwd_stamps.py prints the per-phase medians).
+__device__ unsigned long long g_bwd_stamps[16384][8];
+#define PCRL_STAMP(k) do { if (lane == 0 && item < 16384) g_bwd_stamps[item][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PCRL_STAMP(k) do { } while (0)
+#endif
 constexpr int kTileTabBytes = 256 + 4 * 256;       // per wave: slot bytes + dx floats of the tile's cloud (c3 <= 256)
 constexpr int kMaxTileModeClouds = 2048;          // tile mode keeps the clouds' tile prefix in LDS
 template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false>
@@ -706,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
             const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
             const unsigned xs_off = 4u * (unsigned)(tile * 64 * 64 + lane);
 
+            PCRL_STAMP(0);
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pidx);
             if (half == 0) {   // B operand of the conv0 weight gradient: rows = input channels, row C = 1 (bias)
 #pragma unroll
@@ -734,6 +743,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
                 }
             }
+            PCRL_STAMP(1);
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
             if (SPLIT)      // the split-precision forward's arithmetic: the recompute is bit-identical to that forward
@@ -761,6 +771,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
                 }
             }
+            PCRL_STAMP(2);
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
             if (SPLIT)
@@ -779,6 +790,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     [&](int t) { return a1[t >> 4][t & 15]; });
             const float rstd2 = ln_to_xhat<kC3>(a2, p.eps);
 
+            PCRL_STAMP(3);
             // ---- max-pool + ReLU + LN2 backward ----------------------------------------------------
             // dY2[point][c] = grad_pooled[c] if this point is channel c's argmax, else 0; a point owns
             // ~c3/n_act channels.  own[] marks the channels whose argmax lies in THIS tile (wave-uniform
@@ -841,6 +853,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     a2[mb][r] = dz;
                     buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
                 }
+            PCRL_STAMP(4);
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
             if (SPLIT)
@@ -855,6 +868,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                 dense_layer_mfma<MB2, kC3 / 8, 3>(
                     d1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w2t() + (mb * (kC3 / 8) + tq) * 256)); },
                     [&](int t) { return a2[t >> 4][t & 15]; });
+            PCRL_STAMP(5);
             f32x16 xh1[MB2];
             float s1 = 0.0f, s2 = 0.0f, lo, hi;
 #pragma unroll
@@ -896,6 +910,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
                     d1[mb][r] = rstd1 * ((d1[mb][r] - n1) - xh1[mb][r] * n2);
                     buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
                 }
+            PCRL_STAMP(6);
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
             if (SPLIT)
@@ -915,6 +930,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
+            PCRL_STAMP(7);
         }
     }
 }
@@ -1277,4 +1293,11 @@ extern "C" int pcrl_encoder_bwd_f32split(const pcrl_cloud_desc* clouds, const pc
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return encoder_bwd_impl(2, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
 }
+#ifdef PCRL_BWD_STAMPS
+extern "C" int pcrl_debug_bwd_stamps(unsigned long long* host_out, int n_items) {
+    PCRL_CHECK_HIP(hipDeviceSynchronize());
+    PCRL_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(pcrl::g_bwd_stamps), sizeof(unsigned long long) * 8 * (size_t)n_items));
+    return PCRL_OK;
+}
+#endif
 #endif  // PCRL_BWD_MODE == 0
