@@ -296,6 +296,32 @@ int pcrl_layernorm_rows_bwd_f32(const float* dy0, const float* dy1, int64_t lddy
 int pcrl_layernorm_rows_bwd_partials_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
                                          const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
                                          void* workspace, size_t workspace_bytes, void* stream);
+/* PointNet.final_mlp (Linear(c3, F) + LayerNorm(F), pointnet.py:152-153) as the epilogue of the encoder launch: the
+ * workgroup that finishes a cloud's max-pool (or the merge launch, for clouds split over workgroups) also forms
+ * y = weight . pooled + bias (fixed summation order), normalises it and writes the rows exactly as
+ * pcrl_layernorm_rows_fwd_multi_f32 would -- destinations, xhat / rstd saves and pass-through columns of `job[i]` (its x / ldx
+ * are ignored), for the clouds [begin[i], begin[i] + job[i].M) of the launch; row = cloud - begin[i].  Saves the feature GEMM
+ * launch and the LayerNorm launch of every encoder pass. */
+typedef struct pcrl_feature_head {
+    const float* weight;           /* [F][c3] row-major (final_mlp.0.weight) */
+    const float* bias;             /* [F] */
+    const float* gamma; const float* beta;    /* [F] (final_mlp.1) */
+    int32_t F;                     /* 1 <= F <= 256 */
+    float eps;
+    int32_t n_ranges;              /* 1 or 2 */
+    int32_t begin[2];
+    pcrl_ln_job job[2];
+} pcrl_feature_head;
+int pcrl_encoder_fwd_head_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, const pcrl_encoder_weights* w, const void* packed,
+                              float* pooled, int32_t* argmax, const pcrl_feature_head* head,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int pcrl_encoder_fwd_head_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, const pcrl_encoder_weights* w, const void* packed,
+                               float* pooled, int32_t* argmax, const pcrl_feature_head* head,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int pcrl_encoder_fwd_head_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, const pcrl_encoder_weights* w, const void* packed,
+                                   float* pooled, int32_t* argmax, const pcrl_feature_head* head,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fixed-order column reductions of per-workgroup partial results, up to 12 jobs in one launch:
  *   out[c] = scale * (op == 0 ? sum : max)_{b < nblk} part[b * blk_stride + c]   for c < ncols. */
 typedef struct pcrl_colsum_job { const float* part; int64_t blk_stride; int32_t nblk, ncols; float* out; float scale; int32_t op; } pcrl_colsum_job;

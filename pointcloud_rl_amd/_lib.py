@@ -54,6 +54,12 @@ class LnJob(ctypes.Structure):
                 ("cat_ld_dst", ctypes.c_int64 * 2), ("cat_n", ctypes.c_int32 * 2), ("cat_row_div", ctypes.c_int32 * 2)]
 
 
+class FeatureHead(ctypes.Structure):
+    _fields_ = [("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("F", ctypes.c_int32), ("eps", ctypes.c_float), ("n_ranges", ctypes.c_int32), ("begin", ctypes.c_int32 * 2),
+                ("job", LnJob * 2)]
+
+
 class ColsumJob(ctypes.Structure):
     _fields_ = [("part", ctypes.c_void_p), ("blk_stride", ctypes.c_int64), ("nblk", ctypes.c_int32), ("ncols", ctypes.c_int32),
                 ("out", ctypes.c_void_p), ("scale", ctypes.c_float), ("op", ctypes.c_int32)]

@@ -20,6 +20,103 @@
 
 namespace pcrl {
 
+// PointNet.final_mlp as the epilogue of the launch (pcrl_feature_head)
+struct HeadRange {
+    int begin, count, n_dst;
+    float* y[4]; long long ldy[4];
+    float* xhat; float* rstd;
+    const float* cat_src[2]; float* cat_dst[2]; long long cat_lds[2], cat_ldd[2]; int cat_n[2], cat_div[2];
+};
+struct HeadParams {
+    const float* weight; const float* bias; const float* gamma; const float* beta;
+    int F; float eps; int n_ranges;
+    HeadRange range[2];
+};
+
+// y = weight . pooled + bias, LayerNorm, outputs: run by the `nwaves` waves of a workgroup that holds the cloud's pooled values
+// as floats at s_val[2 c] (the low words of the max-pool keys, which the caller has just read out) and may use s_val[2 f + 1]
+// (the high words) for y.  Fixed order: lane l sums channels l, l + 64, ... then a DPP/swizzle butterfly; same arithmetic as
+// layernorm_rows_fwd_kernel afterwards.  Must be entered by all threads; ends with every output written.
+__device__ __forceinline__ void feature_head_epilogue(const HeadParams& h, int cloud, int C3, float* s_val, int tid, int nthreads) {
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    // wave 0's LayerNorm parameters are fetched now, under the dot products' loads
+    float gam[4] = {0.f, 0.f, 0.f, 0.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (lane + 64 * j < h.F) { gam[j] = h.gamma[lane + 64 * j]; bet[j] = h.beta[lane + 64 * j]; }
+    }
+    __syncthreads();
+    {
+        // a wave takes eight consecutive features at a time: their 32 weight loads per lane are all in flight together (one
+        // feature after the other paid an L2 round trip each: +10 us per cloud), then eight butterflies advance side by side
+        constexpr int FC = 8;
+        float pv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = lane + 64 * j < C3 ? s_val[2 * (lane + 64 * j)] : 0.0f;
+        for (int f0 = wave * FC; f0 < h.F; f0 += nwaves * FC) {
+            float wv[FC][4];
+            const float bias_l = (lane < FC && f0 + lane < h.F) ? h.bias[f0 + lane] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < FC; ++k) {
+                const int f = f0 + k < h.F ? f0 + k : h.F - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wv[k][j] = lane + 64 * j < C3 ? h.weight[(long long)f * C3 + lane + 64 * j] : 0.0f;
+            }
+            float acc[FC];
+#pragma unroll
+            for (int k = 0; k < FC; ++k) {
+                acc[k] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[k] = __builtin_fmaf(wv[k][j], pv[j], acc[k]);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+                for (int k = 0; k < FC; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+            if (lane < FC && f0 + lane < h.F) {
+                float mine = acc[0];
+#pragma unroll
+                for (int k = 1; k < FC; ++k) mine = lane == k ? acc[k] : mine;
+                s_val[2 * (f0 + lane) + 1] = mine + bias_l;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    int ri = 0;
+    if (h.n_ranges > 1 && cloud >= h.range[1].begin) ri = 1;
+    const HeadRange& rg = h.range[ri];
+    const int row = cloud - rg.begin;
+    if (row < 0 || row >= rg.count) return;
+    float v[4], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; v[j] = f < h.F ? s_val[2 * f + 1] : 0.0f; s += v[j]; }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)h.F;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = lane + 64 * j; const float d = f < h.F ? v[j] - mean : 0.0f; q += d * d; }
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / __builtin_sqrtf(q / (float)h.F + h.eps);
+    if (rg.rstd && lane == 0) rg.rstd[row] = rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = lane + 64 * j;
+        if (f < h.F) {
+            const float xh = (v[j] - mean) * rstd;
+            if (rg.xhat) rg.xhat[(long long)row * h.F + f] = xh;
+            const float y = xh * gam[j] + bet[j];
+            for (int d = 0; d < rg.n_dst; ++d) rg.y[d][(long long)row * rg.ldy[d] + f] = y;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (rg.cat_src[c])
+            for (int f = lane; f < rg.cat_n[c]; f += 64)
+                rg.cat_dst[c][(long long)row * rg.cat_ldd[c] + f] = rg.cat_src[c][(long long)(row / rg.cat_div[c]) * rg.cat_lds[c] + f];
+}
+
 struct FwdParams {
     CloudParams cl;
     int S, tiles_total, tiles_per_seg;
@@ -28,6 +125,7 @@ struct FwdParams {
     float* pooled;
     int* argmax;
     unsigned long long* partial;   // [B][S][C3] keys when S > 1
+    HeadParams head;               // head.weight != NULL: feature head epilogue
 };
 
 // BF16: conv1 / conv2 contract bf16 operands (weights rounded once by the pack kernel, activations rounded as they are
@@ -246,6 +344,16 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             }
         }
     }
+    // Feature head (PointNet.final_mlp) of the clouds this workgroup finished -- after the tile loop, so that its parameters
+    // are not live across it (inside the loop they cost the tile loop 17 spilled VGPRs / 55 SGPRs and 3 % of its speed).
+    if (p.S == 1 && p.head.weight) {
+        float* s_val = reinterpret_cast<float*>(s_keys);
+        for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x) {
+            __syncthreads();
+            for (int c = tid; c < C3; c += nthreads) s_val[2 * c] = p.pooled[(long long)b * C3 + c];
+            feature_head_epilogue(p.head, b, C3, s_val, tid, nthreads);
+        }
+    }
 }
 
 // Second stage of the split-cloud pool: max over the S partial keys of a cloud.
@@ -263,6 +371,26 @@ __global__ void encoder_merge_kernel(const unsigned long long* __restrict__ part
     if (vb > 0x7F800000u) vb = 0x7FC00000u;
     pooled[i] = u2f(vb);
     argmax[i] = (int)~(unsigned)key;
+}
+
+// The same merge for launches with a feature head: one workgroup per cloud (thread c owns channel c), then the head.
+__global__ __launch_bounds__(256) void encoder_merge_head_kernel(const unsigned long long* __restrict__ partial, int S, int C3,
+                                                                 float* __restrict__ pooled, int* __restrict__ argmax, const HeadParams head) {
+    __shared__ float s_val[2 * 256];
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c < C3) {
+        unsigned long long key = 0ull;
+        for (int s = 0; s < S; ++s) {
+            const unsigned long long k = partial[((long long)b * S + s) * C3 + c];
+            key = k > key ? k : key;
+        }
+        unsigned vb = (unsigned)(key >> 32);
+        if (vb > 0x7F800000u) vb = 0x7FC00000u;
+        pooled[(long long)b * C3 + c] = u2f(vb);
+        argmax[(long long)b * C3 + c] = (int)~(unsigned)key;
+        s_val[2 * c] = u2f(vb);
+    }
+    feature_head_epilogue(head, b, C3, s_val, threadIdx.x, 256);
 }
 
 // Weights (reference state_dict layout) -> operand order.  One thread per packed float.
@@ -488,7 +616,7 @@ extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void
 static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
                             float* pooled, int32_t* argmax,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream, const pcrl_feature_head* head = nullptr) {
     if (!clouds || !w || !packed || !pooled || !argmax) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
@@ -502,6 +630,29 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         p.partial = static_cast<unsigned long long*>(workspace);
     }
     p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.pooled = pooled; p.argmax = argmax;
+    if (head) {
+        if (!head->weight || !head->bias || !head->gamma || !head->beta) return fail(PCRL_E_ARG, "feature head: NULL parameter");
+        if (head->F < 1 || head->F > 256 || head->F > w->c3 || head->n_ranges < 1 || head->n_ranges > 2)
+            return fail(PCRL_E_ARG, "feature head: 1 <= F <= min(256, c3), 1 <= n_ranges <= 2");
+        HeadParams& h = p.head;
+        h.weight = head->weight; h.bias = head->bias; h.gamma = head->gamma; h.beta = head->beta; h.F = head->F; h.eps = head->eps;
+        h.n_ranges = head->n_ranges;
+        for (int i = 0; i < head->n_ranges; ++i) {
+            const pcrl_ln_job& s = head->job[i];
+            HeadRange& d = h.range[i];
+            if (s.M < 0 || s.n_dst < 0 || s.n_dst > 4 || head->begin[i] < 0 || head->begin[i] + s.M > p.cl.B)
+                return fail(PCRL_E_ARG, "feature head: bad range %d", i);
+            if (i == 1 && head->begin[1] < head->begin[0] + head->job[0].M) return fail(PCRL_E_ARG, "feature head: ranges must be ascending and disjoint");
+            d.begin = head->begin[i]; d.count = s.M; d.n_dst = s.n_dst; d.xhat = s.xhat; d.rstd = s.rstd;
+            for (int k = 0; k < s.n_dst; ++k) { if (!s.dst[k]) return fail(PCRL_E_ARG, "NULL destination"); d.y[k] = s.dst[k]; d.ldy[k] = s.ld_dst[k]; }
+            for (int c = 0; c < 2; ++c) {
+                if (s.cat_n[c] > 0 && (!s.cat_src[c] || !s.cat_dst[c])) return fail(PCRL_E_ARG, "NULL pass-through columns");
+                d.cat_src[c] = s.cat_n[c] > 0 ? s.cat_src[c] : nullptr; d.cat_dst[c] = s.cat_dst[c];
+                d.cat_lds[c] = s.cat_ld_src[c]; d.cat_ldd[c] = s.cat_ld_dst[c]; d.cat_n[c] = s.cat_n[c];
+                d.cat_div[c] = s.cat_row_div[c] > 1 ? s.cat_row_div[c] : 1;
+            }
+        }
+    }
 
     const int grid = min(p.cl.B * p.S, num_cus());
     const int T0 = (p.cl.C + 1) / 2;
@@ -517,7 +668,10 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
 #undef PCRL_FWD_CASE
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
-    if (p.S > 1) {
+    if (p.S > 1 && head) {
+        hipLaunchKernelGGL(encoder_merge_head_kernel, dim3(p.cl.B), dim3(256), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
+        PCRL_CHECK_LAUNCH("encoder_merge_head_kernel");
+    } else if (p.S > 1) {
         const long long n = (long long)p.cl.B * w->c3;
         hipLaunchKernelGGL(encoder_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                            p.partial, p.cl.B, p.S, w->c3, pooled, argmax);
@@ -525,6 +679,18 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     }
     return PCRL_OK;
 }
+
+#define PCRL_FWD_HEAD_ENTRY(NAME, MODE)                                                                                             \
+    extern "C" int NAME(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, const pcrl_encoder_weights* w, const void* packed,  \
+                        float* pooled, int32_t* argmax, const pcrl_feature_head* head, void* workspace, size_t workspace_bytes,       \
+                        void* stream) {                                                                                               \
+        if (!head) return fail(PCRL_E_ARG, "NULL argument");                                                                          \
+        return encoder_fwd_impl(MODE, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream, head);              \
+    }
+PCRL_FWD_HEAD_ENTRY(pcrl_encoder_fwd_head_f32, 0)
+PCRL_FWD_HEAD_ENTRY(pcrl_encoder_fwd_head_bf16, 1)
+PCRL_FWD_HEAD_ENTRY(pcrl_encoder_fwd_head_f32split, 2)
+#undef PCRL_FWD_HEAD_ENTRY
 
 extern "C" int pcrl_encoder_fwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                                     const pcrl_encoder_weights* w, const void* packed,

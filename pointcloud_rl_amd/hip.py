@@ -199,9 +199,10 @@ def color_jitter_u8(rgb, color):
     return out
 
 
-def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False, split=False):
+def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False, split=False, head=None):
     """Returns pooled [B,c3] f32 and argmax [B,c3] int32 (new tensors on the current device).  bf16=True: conv1 / conv2 on
-    the bf16 matrix cores with fp32 accumulation (pcrl_encoder_fwd_bf16)."""
+    the bf16 matrix cores with fp32 accumulation (pcrl_encoder_fwd_bf16).  head: (pcrl_feature_head, keep-alive) of
+    make_feature_head -- PointNet.final_mlp applied by the same launch."""
     B, c3 = desc.B, ew.c3
     dev = packed.device
     pooled = torch.empty((B, c3), dtype=torch.float32, device=dev)
@@ -212,10 +213,15 @@ def encoder_fwd(desc, ew, packed, aug=None, workspace=None, bf16=False, split=Fa
     if need.value and (workspace is None or workspace.numel() * workspace.element_size() < need.value):
         workspace = torch.empty(need.value, dtype=torch.uint8, device=dev)
     with _span("encoder_fwd"):
-        fn = lib().pcrl_encoder_fwd_f32split if split else lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
-        check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
-                                         ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
-                                         _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
+        if head is not None:
+            fn = lib().pcrl_encoder_fwd_head_f32split if split else lib().pcrl_encoder_fwd_head_bf16 if bf16 else lib().pcrl_encoder_fwd_head_f32
+            check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew), _ptr(packed), _ptr(pooled),
+                     _ptr(argmax), ctypes.byref(head[0]), _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
+        else:
+            fn = lib().pcrl_encoder_fwd_f32split if split else lib().pcrl_encoder_fwd_bf16 if bf16 else lib().pcrl_encoder_fwd_f32
+            check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None,
+                     ctypes.byref(ew), _ptr(packed), _ptr(pooled), _ptr(argmax),
+                     _ptr(workspace), ctypes.c_size_t(need.value), _stream()))
     return pooled, argmax
 
 
@@ -339,21 +345,40 @@ def layernorm_rows_fwd(x, ldx, gamma, beta, M, F, eps, dsts, xhat=None, rstd=Non
                                             _ptr(xhat), _ptr(rstd), _stream()))
 
 
+def make_feature_head(weight, bias, gamma, beta, F, eps, ranges):
+    """pcrl_feature_head for encoder_fwd(head=...): ranges = [(first cloud, job dict as in layernorm_rows_fwd_multi without x / ldx)]."""
+    h = _lib.FeatureHead()
+    h.weight, h.bias, h.gamma, h.beta = weight.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    h.F, h.eps, h.n_ranges = F, eps, len(ranges)
+    keep = [weight, bias, gamma, beta]
+    for i, (begin, job) in enumerate(ranges):
+        h.begin[i] = begin
+        _fill_ln_job(h.job[i], job)
+        keep.append(job)
+    return h, keep
+
+
+def _fill_ln_job(j, job):
+    if job.get("x") is not None:
+        j.x, j.ldx = job["x"].data_ptr(), job["ldx"]
+    j.M, j.n_dst = job["M"], len(job["dsts"])
+    for i, (t, off, ld) in enumerate(job["dsts"]):
+        j.dst[i], j.ld_dst[i] = t.data_ptr() + 4 * off, ld
+    j.xhat = job["xhat"].data_ptr() if job.get("xhat") is not None else None
+    j.rstd = job["rstd"].data_ptr() if job.get("rstd") is not None else None
+    for c, cat in enumerate(job.get("cats", [])):
+        src, dst, off, ld = cat[:4]
+        assert src.dtype == torch.float32 and src.stride(-1) == 1
+        j.cat_src[c], j.cat_dst[c], j.cat_ld_src[c], j.cat_ld_dst[c], j.cat_n[c] = src.data_ptr(), dst.data_ptr() + 4 * off, src.stride(0), ld, src.shape[1]
+        j.cat_row_div[c] = int(cat[4]) if len(cat) > 4 else 1        # source stored once per sample, read by each augmentation row
+
+
 def layernorm_rows_fwd_multi(jobs, gamma, beta, F, eps):
     """jobs: [dict(x=, ldx=, M=, dsts=[(tensor, column offset, leading dim)], xhat=None, rstd=None,
     cats=[(src tensor [M, n] (row stride src.stride(0)), dst tensor, dst column offset, dst leading dim)])], one launch."""
     arr = (_lib.LnJob * len(jobs))()
     for j, job in zip(arr, jobs):
-        j.x, j.ldx, j.M, j.n_dst = job["x"].data_ptr(), job["ldx"], job["M"], len(job["dsts"])
-        for i, (t, off, ld) in enumerate(job["dsts"]):
-            j.dst[i], j.ld_dst[i] = t.data_ptr() + 4 * off, ld
-        j.xhat = job["xhat"].data_ptr() if job.get("xhat") is not None else None
-        j.rstd = job["rstd"].data_ptr() if job.get("rstd") is not None else None
-        for c, cat in enumerate(job.get("cats", [])):
-            src, dst, off, ld = cat[:4]
-            assert src.dtype == torch.float32 and src.stride(-1) == 1
-            j.cat_src[c], j.cat_dst[c], j.cat_ld_src[c], j.cat_ld_dst[c], j.cat_n[c] = src.data_ptr(), dst.data_ptr() + 4 * off, src.stride(0), ld, src.shape[1]
-            j.cat_row_div[c] = int(cat[4]) if len(cat) > 4 else 1        # source stored once per sample, read by each augmentation row
+        _fill_ln_job(j, job)
     check(lib().pcrl_layernorm_rows_fwd_multi_f32(arr, len(jobs), _ptr(gamma), _ptr(beta), F, _f(eps), _stream()))
 
 

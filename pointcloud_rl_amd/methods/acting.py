@@ -1,10 +1,10 @@
-"""Acting path on libpcrl_hip.so: observation -> action in seven launches.
+"""Acting path on libpcrl_hip.so: observation -> action in five launches.
 
 The reference's `BaseAgent.forward` (pyrl/utils/torch/module_utils.py:147-159) runs the actor module tree --
 `Visuomotor.forward` (visuomotor.py:56-146) -> `PointNet.forward` -> `LinearMLP` -> `TanhGaussianHead.forward`
 (gaussian.py:83-87) -- which on a GPU is ~25 small ATen launches per environment step (`Rollout.forward_with_policy`,
-rollout.py:78-114, B = 1 ... num_envs).  Here the same function is: [re-pack] -> fused encoder -> feature Linear ->
-LayerNorm (+ robot state) -> two dense layers -> last layer + squashed-Gaussian head.  Used by SAC / DrQ `forward` when the
+rollout.py:78-114, B = 1 ... num_envs).  Here the same function is: [re-pack] -> fused encoder with the feature Linear + LayerNorm
+(+ robot state) as its epilogue (pcrl_feature_head) -> two dense layers -> last layer + squashed-Gaussian head.  Used by SAC / DrQ `forward` when the
 actor has the topology of the shipped point-cloud configs; every other case falls back to the module tree.
 """
 import torch
@@ -57,17 +57,16 @@ class FusedActor:
         enc, lin = bb.visual_nn, bb.final_mlp.linears
         visual, state = type(bb).split_obs(obs)
         M = batch_rows(visual) if isinstance(visual, dict) else visual.shape[0]
-        pooled, _, _ = enc.encode_raw(visual)
         fl, ln = enc.final_mlp[0], enc.final_mlp[1]
         F, c3, S = fl.out_features, fl.in_features, 0 if state is None else state.shape[-1]
         A, H = head.dim_output, lin[0].out_features
         assert lin[0].in_features == F + S, f"actor MLP expects {lin[0].in_features} inputs, got {F} + {S}"
         lda = ceil4(F + S)
-        y = self._buf("feat_pre", M, F)
-        hip.gemm(pooled, fl.weight, y, M, F, c3, (c3, 1), (1, c3), F, bias=fl.bias)
         XA = self._buf("XA", M, lda)
         cats = [] if state is None else [(state.float().contiguous(), XA, F, lda)]
-        hip.layernorm_rows_fwd_multi([dict(x=y, ldx=F, M=M, dsts=[(XA, 0, lda)], cats=cats)], ln.weight, ln.bias, F, ln.eps)
+        # final_mlp (Linear + LayerNorm) and the robot-state columns are written by the encoder launch itself (pcrl_feature_head)
+        fh = hip.make_feature_head(fl.weight, fl.bias, ln.weight, ln.bias, F, ln.eps, [(0, dict(M=M, dsts=[(XA, 0, lda)], cats=cats))])
+        enc.encode_raw(visual, head=fh)
         h1, h2 = self._buf("h1", M, H), self._buf("h2", M, H)
         k0 = F + S
         hip.gemm(XA, lin[0].weight, h1, M, H, k0, (lda, 1), (1, k0), H, bias=lin[0].bias, relu=True)

@@ -209,18 +209,15 @@ class FusedStep:
         return out
 
     # -- pieces -------------------------------------------------------------------------------------
-    def _features(self, jobs):
-        """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) for several pooled batches at once:
-        jobs = [(pooled, M, tag, dsts, save, cats)]; the Linear GEMMs share one launch and so do the LayerNorms, which
-        also drop the pass-through columns `cats` = [(src [M / div, n], dst buffer, dst column[, div])] (robot state, replay actions:
-        Visuomotor's torch.cat, visuomotor.py:130-141) into the head inputs.  Returns [(xhat, rstd)]."""
-        fc, off, F, c3 = self.a._flat["critic"], self.off, self.F, self.c3
+    def _feature_jobs(self, jobs):
+        """PointNet.final_mlp: Linear(c3, F) + LayerNorm(F) (pointnet.py:152-153) as the epilogue of the encoder launch
+        (pcrl_feature_head): jobs = [(first cloud of the launch, M, tag, dsts, save, cats)] -- dsts = the head-input buffers the
+        normalised rows go to, cats = [(src [M / div, n], dst buffer, dst column[, div])] the pass-through columns (robot state,
+        replay actions: Visuomotor's torch.cat, visuomotor.py:130-141).  Returns (head for encode_raw, [(xhat, rstd)])."""
+        fc, off, F = self.a._flat["critic"], self.off, self.F
         pre = "values.0.backbone.visual_nn.final_mlp."
-        ys = [self._buf(f"feat_pre_{tag}", M, F) for _, M, tag, _, _, _ in jobs]
-        hip.gemm_group([hip.gemm_desc(pooled, fc.data[off[pre + "0.weight"]:], y, M, F, c3, (c3, 1), (1, c3), F, bias=fc.data[off[pre + "0.bias"]:])
-                        for (pooled, M, _, _, _, _), y in zip(jobs, ys)])
-        out, ln_jobs = [], []
-        for (_, M, tag, dsts, save, cats), y in zip(jobs, ys):
+        out, ranges = [], []
+        for begin, M, tag, dsts, save, cats in jobs:
             xhat = self._buf(f"feat_xhat_{tag}", M, F) if save else None
             rstd = self._buf(f"feat_rstd_{tag}", M) if save else None
             pending = [(c[0] if c[0].dtype == torch.float32 else c[0].float(), c[1], c[2], c[1].shape[1], c[3] if len(c) > 3 else 1)
@@ -228,10 +225,11 @@ class FusedStep:
             while len(pending) > 2:                      # the kernel takes two pass-through blocks per job
                 src, dst, col, _, div = pending.pop()
                 dst[:, col:col + src.shape[1]].copy_(torch.repeat_interleave(src, div, dim=0) if div > 1 else src)
-            ln_jobs.append(dict(x=y, ldx=F, M=M, dsts=dsts, xhat=xhat, rstd=rstd, cats=pending))
+            ranges.append((begin, dict(M=M, dsts=dsts, xhat=xhat, rstd=rstd, cats=pending)))
             out.append((xhat, rstd))
-        hip.layernorm_rows_fwd_multi(ln_jobs, fc.data[off[pre + "1.weight"]:], fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps)
-        return out
+        head = hip.make_feature_head(fc.data[off[pre + "0.weight"]:], fc.data[off[pre + "0.bias"]:], fc.data[off[pre + "1.weight"]:],
+                                     fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps, ranges)
+        return head, out
 
     def _actor_forward(self, XA, M, tag, act_dst, ld_act, save):
         """Actor MLP + TanhGaussianHead mode="max-entropy"; the action goes straight into the Q input."""
@@ -300,19 +298,21 @@ class FusedStep:
         vis_n, state_n = split(next_obs)
         vis_o, state_o = split(obs)
         both = _adjacent_halves(vis_o, vis_n)
+        XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
+        job_n = lambda begin: (begin, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F, repeat), (state_n, XQ_n, F, repeat)])
+        job_o = lambda begin: (begin, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F, repeat), (actions, XQ_o, F + S, repeat)])
         if both is not None:              # s and s' sit back to back (DeviceReplay's staging): one launch of 2 M clouds
-            pooled_all, argmax_all, _ = enc.encode_raw(both)
+            head, ((xhat, rstd), _) = self._feature_jobs([job_o(0), job_n(M)])
+            pooled_all, argmax_all, _ = enc.encode_raw(both, head=head)
             Mo = pooled_all.shape[0] // 2
             pooled_o, pooled_n, argmax_o = pooled_all[:Mo], pooled_all[Mo:], argmax_all[:Mo]
             ctx_o = enc.ctx_for(vis_o, pooled_o)
         else:
-            pooled_n, _, _ = enc.encode_raw(vis_n)
-            pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o)
+            head_n, _ = self._feature_jobs([job_n(0)])
+            pooled_n, _, _ = enc.encode_raw(vis_n, head=head_n)
+            head_o, ((xhat, rstd),) = self._feature_jobs([job_o(0)])
+            pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o, head=head_o)
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
-        XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
-        (_, _), (xhat, rstd) = self._features([
-            (pooled_n, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F, repeat), (state_n, XQ_n, F, repeat)]),
-            (pooled_o, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F, repeat), (actions, XQ_o, F + S, repeat)])])
         _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
@@ -384,9 +384,9 @@ class FusedStep:
             a_obs = obs if actor_obs is None else actor_obs
             vis_a, state_a = split(a_obs)
             Ma = M if actor_obs is None else vis_a["xyz"].shape[0]
-            pooled_a, _, _ = enc.encode_raw(vis_a)                    # updated encoder weights, no gradient
             XA_a, XQ_a = self._buf("XA_a", Ma, lda), self._buf("XQ_a", Ma, ldq)
-            self._features([(pooled_a, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False, [(state_a, XA_a, F), (state_a, XQ_a, F)])])
+            head_a, _ = self._feature_jobs([(0, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False, [(state_a, XA_a, F), (state_a, XQ_a, F)])])
+            pooled_a, _, _ = enc.encode_raw(vis_a, head=head_a)      # updated encoder weights, no gradient
             feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)
             q_pi = self._buf("q_pi", Ma, 2)

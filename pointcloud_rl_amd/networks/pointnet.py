@@ -182,8 +182,9 @@ class PointNet(ExtendedModule):
         return _EncoderFn.apply(self, desc, keep, aug, *self.conv.kernel_params())
 
     # -- autograd-free entry points used by the fused update step --------------------------------
-    def encode_raw(self, inputs):
-        """(pooled [B,c3], argmax [B,c3] int32, ctx) without building an autograd graph."""
+    def encode_raw(self, inputs, head=None):
+        """(pooled [B,c3], argmax [B,c3] int32, ctx) without building an autograd graph.  head: hip.make_feature_head(...) --
+        final_mlp (Linear + LayerNorm) applied to every cloud by the same launch, written where the head's jobs say."""
         aug = getattr(inputs, "aug", None)
         if torch.is_tensor(inputs):
             inputs = {"xyz": inputs.to(dtype=torch.float32)}
@@ -191,7 +192,7 @@ class PointNet(ExtendedModule):
         ew, packed = self._weights_desc()
         aug_desc = hip.make_aug_desc(**aug) if aug else None
         pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug_desc, workspace=self._workspace("fwd"), bf16=self.compute_dtype == "bf16",
-                                         split=self.compute_dtype == "f32split")
+                                         split=self.compute_dtype == "f32split", head=head)
         return pooled, argmax, (desc, keep, aug, aug_desc, ew, packed, pooled)
 
     def ctx_for(self, inputs, pooled):
