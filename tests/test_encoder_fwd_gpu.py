@@ -270,3 +270,50 @@ def test_split_precision_forward_k1_shape_against_the_exact_kernel(cuda):
     assert int(moved.sum()) <= 8 and (not moved.any() or float(diff[moved].max()) <= 1e-6)
     p2, a2 = hip.encoder_fwd(desc, ew, packed, split=True)
     assert torch.equal(p1, p2) and torch.equal(a1, a2)              # deterministic
+
+
+@pytest.mark.parametrize("B,N,c1,F,S", [
+    (6, 2048, 64, 50, 0),         # B < #CUs: clouds split over workgroups -> the merge launch carries the head
+    (300, 96, 64, 50, 5),         # B > #CUs: one workgroup per cloud, several clouds per workgroup; robot-state columns passed through
+    (40, 200, 128, 128, 9),       # ManiSkill nets: F = 128 (two features per lane in the LayerNorm)
+    (9, 64, 32, 50, 0),           # mlp_spec [32, 64, 128]
+])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f32split"])
+def test_feature_head_epilogue_matches_linear_layernorm(cuda, B, N, c1, F, S, mode):
+    """pcrl_encoder_fwd_head_*: PointNet.final_mlp (Linear + LayerNorm, pointnet.py:152-153) applied by the encoder launch to two
+    ranges of its clouds, with destinations at column offsets, saved xhat / rstd and pass-through columns -- against torch's
+    F.linear + F.layer_norm of the launch's own pooled output (1e-5: the dot products sum in a different order than torch's)."""
+    import torch.nn.functional as Fn
+    from pointcloud_rl_amd import hip
+    c2, c3 = (64, 128) if c1 == 32 else (128, 256)
+    obs_np = make_obs(B, N, seed=B + N)
+    C = sum(v.shape[1] for v in obs_np.values())
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda) for k, v in make_encoder_weights(C, c1, c2, c3).items()}
+    ew, _ = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep = hip.make_cloud_desc({k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()})
+    g = torch.Generator().manual_seed(B)
+    W = (torch.randn(F, c3, generator=g) / c3 ** 0.5).to(cuda)
+    b, gam, bet = (torch.randn(F, generator=g).to(cuda) * 0.1, (1 + 0.3 * torch.randn(F, generator=g)).to(cuda), torch.randn(F, generator=g).to(cuda) * 0.2)
+    B0 = B // 3                                         # range 0 = clouds [0, B0), range 1 = clouds [B0, B)
+    ld0, ld1 = F + S + 3, F + 2
+    X0, X0b, X1 = torch.zeros(B0, ld0, device=cuda), torch.zeros(B0, ld1, device=cuda), torch.zeros(B - B0, ld0, device=cuda)
+    xhat1, rstd1 = torch.zeros(B - B0, F, device=cuda), torch.zeros(B - B0, device=cuda)
+    state = torch.randn(B - B0, max(S, 1), generator=g).to(cuda)
+    jobs = [(0, dict(M=B0, dsts=[(X0, 1, ld0), (X0b, 2, ld1)])),
+            (B0, dict(M=B - B0, dsts=[(X1, 0, ld0)], xhat=xhat1, rstd=rstd1, cats=[(state, X1, F, ld0)] if S else []))]
+    head = hip.make_feature_head(W, b, gam, bet, F, 1e-5, jobs)
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, bf16=mode == "bf16", split=mode == "f32split", head=head)
+    plain, plain_arg = hip.encoder_fwd(desc, ew, packed, bf16=mode == "bf16", split=mode == "f32split")
+    assert torch.equal(pooled, plain) and torch.equal(argmax, plain_arg)             # the encoder's own outputs are untouched
+    y = Fn.linear(pooled, W, b)
+    ref = Fn.layer_norm(y, (F,), gam, bet, 1e-5)
+    assert (X0[:, 1:1 + F] - ref[:B0]).abs().max() <= 1e-5 and (X0b[:, 2:2 + F] - ref[:B0]).abs().max() <= 1e-5
+    assert (X1[:, :F] - ref[B0:]).abs().max() <= 1e-5
+    assert float(X0[:, 0].abs().max()) == 0.0 and float(X0[:, 1 + F:].abs().max()) == 0.0      # nothing outside the destination columns
+    mean, var = y[B0:].mean(-1, keepdim=True), y[B0:].var(-1, unbiased=False, keepdim=True)
+    assert (xhat1 - (y[B0:] - mean) / torch.sqrt(var + 1e-5)).abs().max() <= 1e-5
+    assert (rstd1 - 1 / torch.sqrt(var[:, 0] + 1e-5)).abs().max() <= 1e-4 * float(rstd1.abs().max())
+    if S:
+        assert torch.equal(X1[:, F:F + S], state) and float(X1[:, F + S:].abs().max()) == 0.0
