@@ -126,6 +126,7 @@ __device__ __forceinline__ unsigned dpp_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 }
 __device__ __forceinline__ unsigned umax_(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ int imax_(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ unsigned allreduce_umax32(unsigned v) {
     v = umax_(v, dpp_u<0xB1>(v));    // quad_perm [1,0,3,2]
     v = umax_(v, dpp_u<0x4E>(v));    // quad_perm [2,3,0,1]

@@ -194,7 +194,9 @@ __device__ __forceinline__ float ln_center_rstd(f32x16 (&a)[C / 32], float eps, 
 // set (LayerNormkD.forward, reference pyrl/networks/modules/nn_layer.py:207-219).
 // s_ln holds, per channel pair (2j, 2j + 1), {gamma_2j, gamma_2j+1, beta_2j, beta_2j+1} (ln_pair_table).
 // Returns true for a point whose variance is NaN (all outputs NaN).
-template <int C, bool INT_RELU>
+// NO_RELU: the affine output is left as it is (the max-pool that follows orders the raw bits as SIGNED integers, which is
+// the ReLU for free: every non-positive value sorts below the smallest positive one).
+template <int C, bool INT_RELU, bool NO_RELU = false>
 __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __restrict__ s_ln, int half, float eps) {
     constexpr int MB = C / 32;
     bool nan_pt;
@@ -220,7 +222,10 @@ __device__ __forceinline__ bool ln_relu_acc(f32x16 (&a)[C / 32], const float* __
             const f32x2 y = __builtin_elementwise_fma(PCRL_PAIR(a[mb], r) * rstd2, __builtin_shufflevector(g4, g4, 0, 1),
                                                       __builtin_shufflevector(g4, g4, 2, 3));
             const float y0 = y[0], y1 = y[1];
-            if (INT_RELU) {
+            if (NO_RELU) {
+                a[mb][r] = y0;
+                a[mb][r + 1] = y1;
+            } else if (INT_RELU) {
                 const int i0 = __builtin_bit_cast(int, y0), i1 = __builtin_bit_cast(int, y1);
                 a[mb][r] = __builtin_bit_cast(float, i0 > 0 ? i0 : 0);
                 a[mb][r + 1] = __builtin_bit_cast(float, i1 > 0 ? i1 : 0);

@@ -243,7 +243,16 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                         return mb < W1L ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane]
                                         : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
-            ln_relu_acc<C2, false>(a1, s_ln1, half, p.eps);
+            // ReLU as an integer max (one instruction per register instead of compare + select); a NaN of either sign is restored
+            // below: a point with any NaN channel has a NaN variance, and LayerNorm then makes ALL its channels NaN
+            const bool nan_pt1 = ln_relu_acc<C2, true>(a1, s_ln1, half, p.eps);
+            if (__builtin_expect(__ballot(nan_pt1) != 0ull, 0)) {
+#pragma unroll
+                for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (nan_pt1) a1[mb][r] = u2f(0x7FC00000u);
+            }
 
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
@@ -261,14 +270,18 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 dense_layer_mfma<MB3, C2 / 8, 2>(
                     a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
-            const bool nan_pt = ln_relu_acc<C3, true>(a2, s_ln2, half, p.eps);
+            // No ReLU instructions after LayerNorm-2: the pool compares the raw bits as SIGNED integers, where every value <= 0
+            // (and -0, and a NaN with the sign bit) sorts below the smallest positive float, i.e. below max(key, 1) -- exactly the
+            // lanes the ReLU would have zeroed.  What reaches a key is positive, so the keys' unsigned order is unchanged.
+            const bool nan_pt = ln_relu_acc<C3, true, true>(a2, s_ln2, half, p.eps);
             if (__builtin_expect(__ballot(nan_pt) != 0ull, 0)) {
-                // torch: a NaN wins the max and the first NaN's index is returned
+                // torch: a NaN wins the max and the first NaN's index is returned.  Marker 0x7FFFFFFF: the largest signed
+                // AND (among what reaches the keys) the largest unsigned pattern; read out as the canonical NaN.
 #pragma unroll
                 for (int mb = 0; mb < MB3; ++mb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (nan_pt) a2[mb][r] = u2f(0xFFFFFFFFu);
+                        if (nan_pt) a2[mb][r] = u2f(0x7FFFFFFFu);
             }
 
             // ---- symmetric max-pool with first-index argmax --------------------------------
@@ -281,28 +294,28 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 for (int mb = 0; mb < MB3; ++mb) {
                     // 16 independent reductions advance together: each DPP step of one register fills the
                     // wait states of the others, and the 16 conditional key updates are issued back to back.
-                    unsigned m[16];
+                    int m[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = f2u(a2[mb][r]);
+                    for (int r = 0; r < 16; ++r) m[r] = (int)f2u(a2[mb][r]);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0xB1>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = imax_(m[r], (int)dpp_u<0xB1>((unsigned)m[r]));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x4E>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = imax_(m[r], (int)dpp_u<0x4E>((unsigned)m[r]));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x141>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = imax_(m[r], (int)dpp_u<0x141>((unsigned)m[r]));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m[r] = umax_(m[r], dpp_u<0x140>(m[r]));
+                    for (int r = 0; r < 16; ++r) m[r] = imax_(m[r], (int)dpp_u<0x140>((unsigned)m[r]));
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        auto sw = __builtin_amdgcn_permlane16_swap(m[r], m[r], false, false);
-                        // post-ReLU values are >= +0 (or the NaN marker), so unsigned order == float order.  max(.., 1):
-                        // a zero maximum matches no lane (nobody reports it: the key's initial value already says so)
-                        m[r] = umax_(umax_(sw[0], sw[1]), 1u);
+                        auto sw = __builtin_amdgcn_permlane16_swap((unsigned)m[r], (unsigned)m[r], false, false);
+                        // max(.., 1): a maximum that is not positive matches no lane (nobody reports it: the key's initial value
+                        // already says "zero everywhere, point 0")
+                        m[r] = imax_(imax_((int)sw[0], (int)sw[1]), 1);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned v = f2u(a2[mb][r]);
-                        if (v == m[r]) {
+                        if ((int)v == m[r]) {
                             const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
                             atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
                         }
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned v = f2u(a2[mb][r]);
-                        if (v >= umax_(cur[r], 1u)) {
+                        if ((int)v >= imax_((int)cur[r], 1)) {       // key values are >= 0 as integers (positive floats, or the NaN marker)
                             const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
                             atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
                         }
