@@ -414,7 +414,7 @@ class FusedStep:
                                   d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
             mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
-            scale = (yield ("finish", [fa.grad, fal.grad] if a.sync_alpha else [fa.grad])) if exchanging else 1.0
+            scale = (yield ("finish", [a._actor_alpha_grad] if a.sync_alpha else [fa.grad])) if exchanging else 1.0
             stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
             a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)

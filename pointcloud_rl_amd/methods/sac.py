@@ -242,6 +242,11 @@ class SAC(BaseAgent):
             "actor": FlatBuffer(select_optimizer_params(self.actor, self._actor_optim_cfg.get("param_cfg"))),
         }
         self._flat["alpha"] = FlatBuffer([("log_alpha", self.log_alpha)])
+        # the temperature's gradient lives right behind the actor's: their data-parallel exchange is ONE all-reduce
+        fa, fal = self._flat["actor"], self._flat["alpha"]
+        self._actor_alpha_grad = torch.zeros(fa.total + fal.total, dtype=torch.float32, device=dev)
+        fa.grad, fal.grad = self._actor_alpha_grad[:fa.total], self._actor_alpha_grad[fa.total:]
+        fa.zero_grad(), fal.zero_grad()                # re-attaches every p.grad to its view of the joint buffer
         for name in ("critic", "actor", "alpha"):      # torch.optim.Adam (one group per tensor) -> one fused launch
             old = getattr(self, f"{name}_optim")
             hp = _plain_adam(old)

@@ -143,7 +143,10 @@ def test_overlapped_exchange_pieces_cover_the_flat_buffer_once(cuda):
     (b_ptr, b_n), = seen[1]
     base = fc.grad.data_ptr()
     assert b_ptr == base and a_ptr == base + 4 * b_n and a_n + b_n == fc.grad.numel() and a_n > 0 and b_n > 0
-    assert seen[2][0] == (fa.grad.data_ptr(), fa.grad.numel())
+    # actor and temperature gradients travel as ONE piece: the joint buffer [actor | alpha]
+    fal = agent._flat["alpha"]
+    assert len(seen[2]) == 1 and seen[2][0] == (fa.grad.data_ptr(), fa.grad.numel() + fal.grad.numel())
+    assert fal.grad.data_ptr() == fa.grad.data_ptr() + 4 * fa.grad.numel() and agent.log_alpha.grad.data_ptr() == fal.grad.data_ptr()
 
 
 def _rccl_worker(rank, port, graphs, exchange, out):
