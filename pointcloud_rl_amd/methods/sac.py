@@ -622,7 +622,8 @@ class SAC(BaseAgent):
                 except StopIteration as done:
                     stats = done.value
                     names = list(stats.keys())
-                    out = torch.stack([stats[k].reshape(()).float() for k in names])
+                    packed = getattr(stats, "packed", None)        # the fused step already gathered the metrics into one tensor
+                    out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
                     if getattr(stats, "host", None) is not None:
                         self._graph_flag[(do_actor, polyak, True)] = (stats.host.numpy().view(np.uint32), len(names))
             kind, pieces = exchange
