@@ -173,6 +173,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist_on = True
     if dist_on:
+        if rank != 0:       # only rank 0 reports; RCCL's banners (C stdio, flushed at exit) of the other ranks must not follow its line
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
         torch.distributed.init_process_group(args.backend, rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     assert wl["B"] % world == 0, "batch must divide over the ranks"
     b_rank = wl["B"] // world
@@ -369,10 +371,17 @@ def main():
             out["experimental_f32split"] = {"value": n2 / dt2, "unit": "gradient steps/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
                                             "note": "encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); "
                                                     "opt-in, not the reported value"}
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # The JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio, which a pipe buffers
+        # until exit -- after a Python print.  Flush C stdio first, then print.
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
