@@ -206,7 +206,9 @@ def test_bench_single_rank_exchange_over_rccl(cuda):
            "--no-cpu-baseline", "--replay-capacity", "512"]
     out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{"), lines[-3:]        # RCCL's banner (C stdio) must not follow the JSON line
+    d = json.loads(lines[-1])
     assert d["n_gpus"] == 1 and "debug" in d and d["value"] > 0
     assert "ms_per_step_nocomm" in d and "comm_ms_per_step" in d
     assert d["config"]["graph_variants"] >= 2 if "graph_variants" in d["config"] else True
