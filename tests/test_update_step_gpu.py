@@ -229,21 +229,28 @@ def test_checkpoint_resume_continues_bit_for_bit(cuda, tmp_path):
         assert torch.equal(p, q), n
 
 
-def test_graph_replay_honours_a_changed_learning_rate(cuda):
+@pytest.mark.parametrize("device_replay", [False, True], ids=["fixed-batch", "device-replay"])
+def test_graph_replay_honours_a_changed_learning_rate(cuda, device_replay):
     """lr / betas / eps are kernel arguments of the fused Adam launch; graphs captured with the old values must be
-    dropped when a scheduler (or load_state_dict) changes param_groups.  With lr = 0 nothing an optimizer owns may move."""
+    dropped when a scheduler (or load_state_dict) changes param_groups.  With lr = 0 nothing an optimizer owns may move.
+    With a DeviceReplay the steady-state path of update_parameters (SAC._replay_fast) is the one that has to notice."""
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent
-    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    from pointcloud_rl_amd.synthetic import SyntheticReplay, make_batch_np
     cfg = configs.sac_dmc(6, 6, 16, head_hidden=64)
     cfg["env_params"] = configs.env_params({"xyz": [3, 96], "rgb": [3, 96]}, 6)
     torch.manual_seed(0)
     agent = build_agent(cfg).to(cuda)
     agent.enable_graphs(warmup=1)
-    mem = SyntheticReplay(16, 96, 6, seed=5, device=cuda)
+    if device_replay:
+        from pointcloud_rl_amd.replay import DeviceReplay
+        mem = DeviceReplay(64, device=cuda, seed=5)
+        mem.push_batch(make_batch_np(64, 96, 6, seed=5))
+    else:
+        mem = SyntheticReplay(16, 96, 6, seed=5, device=cuda)
     for u in range(1, 7):
         agent.update_parameters(mem, u)
-    assert len(agent._graphs) == 2
+    assert len(agent._graphs) == 2 and (agent._fast is not None) == device_replay
     for opt in (agent.critic_optim, agent.actor_optim, agent.alpha_optim):
         for g in opt.param_groups:
             g["lr"] = 0.0
