@@ -14,7 +14,6 @@ Parameters live in one flat dict keyed by the reference's own `named_parameters(
 (e.g. "actor.backbone.visual_nn.conv.mlp.conv0.weight"), see SURVEY.md section 5.
 """
 import math
-import re
 
 import torch
 import torch.nn.functional as F

@@ -9,7 +9,6 @@ one launch), fused squashed-Gaussian / TD-target / loss kernels and fused Adam+P
 drq.py:46-165) are unchanged and checked against golden vectors in tests/test_update_step_gpu.py.
 """
 import torch
-import torch.nn as nn
 
 from .. import hip
 from ..networks.mlp import LinearMLP

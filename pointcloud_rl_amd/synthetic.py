@@ -4,7 +4,6 @@ optional pos_encoding u8 / seg bool / agent f32), actions, rewards, dones.  Stan
 `ReplayMemory.sample(...).to_torch(...)` (pyrl/env/replay_buffer.py:297-322) -- the replay buffer
 itself is outside the hot path."""
 import numpy as np
-import torch
 
 from .utils.torch_utils import to_torch
 

@@ -7,7 +7,6 @@ backward; the 1/world factor is folded into the fused optimizer kernel's `grad_s
 """
 import os
 
-import torch
 import torch.distributed as dist
 
 

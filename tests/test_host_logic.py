@@ -1,6 +1,5 @@
 """CPU tests of the host side: registries, configs, parameter naming, optimizer construction, Polyak
 rules, augmentations' parameter draws, flat buffers.  No kernel is launched here."""
-import glob
 import os
 
 import numpy as np
