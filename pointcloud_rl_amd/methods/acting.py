@@ -41,6 +41,63 @@ class FusedActor:
     def __init__(self, actor):
         self.actor = actor
         self.bufs = {}
+        # hipGraph replay of the whole call (`use_graphs`, switched on by agent.enable_graphs()): per (mode, observation
+        # signature) the observation is copied into static tensors, one graph launch replaces the five launches and their
+        # Python / ctypes cost, the action is returned as a fresh tensor.  The graph starts with the encoder re-pack, so
+        # parameters updated in place between two calls are always the ones used.
+        self.use_graphs = False
+        self.graphs, self._seen = {}, {}
+
+    def _graph_key(self, obs, mode):
+        """None when the call cannot be replayed: nested / non-tensor / pending-augmentation observations, host tensors."""
+        if not isinstance(obs, dict) or getattr(obs, "aug", None) or getattr(obs, "repeat", 1) != 1 or self.actor.head.noise_override:
+            return None
+        sig = []
+        for k in sorted(obs):
+            v = obs[k]
+            if not (torch.is_tensor(v) and v.is_cuda):
+                return None
+            sig.append((k, tuple(v.shape), v.dtype))
+        bb = self.actor.backbone
+        # storage of the parameters the graph reads: a re-homed parameter (flat buffers of the first update, .to(), a loaded
+        # checkpoint that replaced tensors) must not be read through a stale graph
+        ptrs = (bb.visual_nn.conv.mlp.conv0.weight.data_ptr(), bb.visual_nn.final_mlp[0].weight.data_ptr(),
+                bb.final_mlp.linears[0].weight.data_ptr(), bb.final_mlp.linears[2].bias.data_ptr())
+        return (mode in SAMPLE_MODES, tuple(sig), ptrs)
+
+    def _replay(self, key, obs, mode):
+        entry = self.graphs.get(key)
+        if entry is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < 2:                                   # eager warm-up: buffers and lazy initialisation outside the capture
+                return None
+            if len(self.graphs) >= 8:                   # stale parameter storages / many shapes: start over
+                self.graphs.clear()
+            static = {k: v.clone() for k, v in obs.items()}
+            self.actor.backbone.visual_nn.invalidate_packed()        # the capture records the re-pack as the first node
+            torch.cuda.synchronize()
+            from .sac import _no_gc                     # no Python garbage collection inside a stream capture
+            graph = torch.cuda.CUDAGraph()
+            with _no_gc(), torch.cuda.graph(graph):
+                out = self._run(static, mode)
+            entry = self.graphs[key] = (graph, static, out)
+        graph, static, out = entry
+        for k, v in obs.items():
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out.clone()
+
+    @torch.no_grad()
+    def __call__(self, obs, mode="explore"):
+        """obs: observation dict on the device; returns the action tensor [B, A]."""
+        if self.use_graphs:
+            key = self._graph_key(obs, mode)
+            if key is not None:
+                act = self._replay(key, obs, mode)
+                if act is not None:
+                    return act
+        return self._run(obs, mode)
 
     def _buf(self, name, *shape):
         key = (name,) + shape
@@ -50,8 +107,7 @@ class FusedActor:
         return self.bufs[key]
 
     @torch.no_grad()
-    def __call__(self, obs, mode="explore"):
-        """obs: observation dict on the device; returns the action tensor [B, A]."""
+    def _run(self, obs, mode="explore"):
         actor = self.actor
         bb, head = actor.backbone, actor.head
         enc, lin = bb.visual_nn, bb.final_mlp.linears

@@ -200,7 +200,8 @@ class SAC(BaseAgent):
     @torch.no_grad()
     def forward(self, obs, **kwargs):
         """BaseAgent.forward (module_utils.py:147-159).  On the MI355X and with the shipped actor topology the action comes from
-        the fused acting path (methods/acting.py: seven launches); anything else goes through the module tree."""
+        the fused acting path (methods/acting.py: five launches, one hipGraph launch after enable_graphs()); anything else goes
+        through the module tree."""
         from ..utils.torch_utils import to_torch
         from .acting import MEAN_MODES, SAMPLE_MODES, FusedActor
         mode = kwargs.get("mode", "explore")
@@ -209,6 +210,7 @@ class SAC(BaseAgent):
         if fast is None and self.device.type == "cuda" and not extra and mode in SAMPLE_MODES + MEAN_MODES and FusedActor.supported(self.actor) \
                 and getattr(self, "use_fused_acting", True):
             fast = self.__dict__["_fused_actor"] = FusedActor(self.actor)
+            fast.use_graphs = bool(getattr(self, "_use_graphs", False))
         if fast is None or extra or mode not in SAMPLE_MODES + MEAN_MODES or self.device.type != "cuda" or kwargs.get("num_samples", 1) != 1:
             return super().forward(obs, **kwargs)
         obs = to_torch(obs, device=self.device, non_blocking=True)
@@ -472,6 +474,8 @@ class SAC(BaseAgent):
         one graph launch and one device->host copy.  Requires device-resident state only, which is why
         alpha, the Adam step counts and the Philox offsets live in device memory."""
         self._use_graphs, self._graph_warmup = enabled, warmup
+        if self.__dict__.get("_fused_actor") is not None:      # the acting path replays its own graphs under the same switch
+            self._fused_actor.use_graphs, self._fused_actor.graphs, self._fused_actor._seen = bool(enabled), {}, {}
         self._graphs, self._graph_seen, self._static_batch = {}, {}, None
         self._graph_sampler, self._graph_flag, self._fast = {}, {}, None
 

@@ -503,3 +503,49 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
         assert ra == rb
     for (n, p), (_, q) in zip(eager.named_parameters(), graph.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def test_graph_replayed_acting_equals_the_eager_launches_and_follows_the_parameters(cuda):
+    """After agent.enable_graphs() the acting path replays one hipGraph per (mode, observation signature): the mean action equals
+    the eager launches bit for bit, also after the parameters were updated in place by training steps (the graph re-packs the
+    encoder weights itself), every call returns its own tensor, sampled actions differ from call to call, and an observation of
+    another shape gets its own graph."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 8, 96, 6
+    cfg = configs.sac_dmc(6, A, B, head_hidden=256)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    mem = DeviceReplay(64, device=cuda, seed=1)
+    mem.push_batch(make_batch_np(64, N, A, seed=2))
+    agent.update_parameters(mem, 1)                       # parameters now live in the flat buffers
+    agent.enable_graphs(warmup=1)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in make_obs(3, N, seed=5).items()}
+    obs5 = {k: torch.from_numpy(v).to(cuda) for k, v in make_obs(5, N, seed=6).items()}
+
+    def eager(o, mode="eval"):
+        fa = agent._fused_actor
+        fa.use_graphs = False
+        try:
+            return agent(o, mode=mode)
+        finally:
+            fa.use_graphs = True
+
+    outs = [agent(obs, mode="eval") for _ in range(5)]
+    fa = agent._fused_actor
+    assert fa.use_graphs and len(fa.graphs) == 1
+    ref = eager(obs)
+    assert all(torch.equal(o, ref) for o in outs) and len({o.data_ptr() for o in outs}) == len(outs)
+    for u in range(2, 8):                                 # training moves encoder, feature head and policy weights in place
+        agent.update_parameters(mem, u)
+    after = agent(obs, mode="eval")
+    assert torch.equal(after, eager(obs)) and not torch.equal(after, ref)
+    for _ in range(4):
+        got5 = agent(obs5, mode="eval")
+    assert len(fa.graphs) == 2 and torch.equal(got5, eager(obs5)) and torch.equal(agent(obs, mode="eval"), after)
+    samples = [agent(obs, mode="explore") for _ in range(6)]
+    assert len(fa.graphs) == 3 and all(not torch.equal(samples[i], samples[i + 1]) for i in range(3, 5))
+    assert all(bool(torch.isfinite(s_).all()) and float(s_.abs().max()) <= 1.0 + 1e-6 for s_ in samples)

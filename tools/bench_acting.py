@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 CASES = [("K0 dmc_walker layout: N=1536, C=9 (xyz+rgb+frame one-hot), A=6", dict(N=1536, pos_encoding=3), 9, 6, 0, "sac_dmc"),
          ("K1 shape: N=1024, C=6, A=6", dict(N=1024), 6, 6, 0, "sac_dmc"),
          ("ManiSkill shape: N=1200, C=7, S=68, A=22", dict(N=1200, seg=1, agent=68), 7, 22, 68, "sac_maniskill")]
-print(f"{'case':62s} {'B':>3s} {'mode':>8s} {'fused us':>9s} {'modules us':>10s}")
+print(f"{'case':62s} {'B':>3s} {'mode':>8s} {'graph us':>9s} {'fused us':>9s} {'modules us':>10s}")
 for name, kw, C, A, S, cfgname in CASES:
     kw = dict(kw)
     N = kw.pop("N")
@@ -24,9 +24,10 @@ for name, kw, C, A, S, cfgname in CASES:
         obs = {k: torch.from_numpy(v).to(dev) for k, v in make_obs_np(g, B, N, **kw).items()}
         for mode in ("eval", "explore"):
             res = []
-            for fused in (True, False):
+            for fused, graphs in ((True, True), (True, False), (False, False)):
                 agent.use_fused_acting = fused
                 agent.__dict__.pop("_fused_actor", None)
+                agent._use_graphs = graphs
                 for _ in range(20):
                     agent(obs, mode=mode)
                 torch.cuda.synchronize()
@@ -36,4 +37,4 @@ for name, kw, C, A, S, cfgname in CASES:
                     a = agent(obs, mode=mode)
                 torch.cuda.synchronize()
                 res.append((time.perf_counter() - t0) / n * 1e6)
-            print(f"{name:62s} {B:3d} {mode:>8s} {res[0]:9.1f} {res[1]:10.1f}")
+            print(f"{name:62s} {B:3d} {mode:>8s} {res[0]:9.1f} {res[1]:9.1f} {res[2]:10.1f}")
