@@ -628,8 +628,10 @@ __device__ unsigned long long g_bwd_stamps[16384][8];
 #endif
 constexpr int kTileTabBytes = 256 + 4 * 256;       // per wave: slot bytes + dx floats of the tile's cloud (c3 <= 256)
 constexpr int kMaxTileModeClouds = 2048;          // tile mode keeps the clouds' tile prefix in LDS
-template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false>
-__global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdParams p) {
+// NW: waves per workgroup.  8 (two per SIMD, 256 registers each, ~110 of them spilled) is the throughput build; 4 (one per SIMD,
+// 512 registers: nothing spills) serves batches whose tiles fit one per SIMD anyway -- the per-GPU shares of a multi-GPU run.
+template <int T0, int C1, int kC2, int kC3, bool BF16, bool SPLIT = false, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const BwdParams p) {
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, MB3 = kC3 / 32;
     constexpr OpsLayout OL{C1 / 32, kC2 / 32, kC3 / 32};
@@ -649,11 +651,11 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     {
         const f32x4* g = reinterpret_cast<const f32x4*>(p.packed + (SPLIT ? L.w2s(0) : BF16 ? L.w2b() : L.w2()));
         f32x4* s = reinterpret_cast<f32x4*>(s_w2);
-        stage_to_lds<512, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
-        for (int i = tid; i < MB1 * T0 * 64; i += 512) s_w0[i] = p.packed[L.w0() + i];
-        for (int i = tid; i < C1; i += 512) s_b0[i] = p.packed[L.b0() + i];
-        for (int i = tid; i < 2 * kC2; i += 512) s_ln1[i] = p.packed[L.ln1() + i];
-        for (int i = tid; i < 2 * kC3; i += 512) s_ln2[i] = p.packed[L.ln2() + i];
+        stage_to_lds<64 * NW, BF16 ? kC3 * kC2 / 8 : kC3 * kC2 / 4>(s, g, tid);
+        for (int i = tid; i < MB1 * T0 * 64; i += 64 * NW) s_w0[i] = p.packed[L.w0() + i];
+        for (int i = tid; i < C1; i += 64 * NW) s_b0[i] = p.packed[L.b0() + i];
+        for (int i = tid; i < 2 * kC2; i += 64 * NW) s_ln1[i] = p.packed[L.ln1() + i];
+        for (int i = tid; i < 2 * kC3; i += 64 * NW) s_ln2[i] = p.packed[L.ln2() + i];
         if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
         if (wave == 0) {          // exclusive prefix of the clouds' tile counts: 64 clouds per wave-wide scan step
             int run = 0;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_kernel(const BwdPar
     // `grid` items go to wave 0 of every workgroup (one tile per SIMD before any SIMD gets a second one).  With B < #CUs
     // there are at most 8 * B <= 8 * grid items: one per wave at most; a larger batch makes further rounds of the same deal.
     const int n_items = s_tstart[p.cl.B];
-    for (int item = wave * (int)gridDim.x + (int)blockIdx.x; item < n_items; item += 8 * (int)gridDim.x) {
+    for (int item = wave * (int)gridDim.x + (int)blockIdx.x; item < n_items; item += NW * (int)gridDim.x) {
         int b, tile, n_act;
         {
             int lo = 0, hi = p.cl.B;             // largest b with s_tstart[b] <= item
@@ -1138,9 +1140,18 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
         hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(256), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
         PCRL_CHECK_LAUNCH("encoder_bwd_prep_kernel");
         const size_t lds = bwd_lds_bytes_tile(T0, C1, C2, C3);
-        auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT>;
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
-        hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, stream, p);
+        // at most C3 / 32 tiles per cloud: when even that many fit one per SIMD, take the four-wave build (no register spills)
+        static const int nw_forced = [] { const char* e = getenv("PCRL_BWD_TILE_WAVES"); return e ? atoi(e) : 0; }();
+        const bool four = !BF16 && !SPLIT && (nw_forced ? nw_forced == 4 : (long long)p.cl.B * (C3 / 32) <= 4ll * num_cus());
+        if (four) {
+            auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT, (BF16 || SPLIT) ? 8 : 4>;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(num_cus()), dim3((BF16 || SPLIT) ? 512 : 256), lds, stream, p);
+        } else {
+            auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT>;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, stream, p);
+        }
         PCRL_CHECK_LAUNCH("encoder_bwd_points_kernel");
     } else {
         const size_t lds = bwd_lds_bytes_cloud(T0, C1, C2, C3);
