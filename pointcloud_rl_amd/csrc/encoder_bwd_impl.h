@@ -27,8 +27,8 @@
 //     results are bit-reproducible run to run.
 #include "encoder_common.h"
 
-// This file is compiled three times (encoder_bwd_{f32,bf16,split}.hip define PCRL_BWD_MODE 0 / 1 / 2): each translation unit
-// instantiates the kernels of ONE arithmetic mode for the twelve supported shapes, so the three compile in parallel; the
+// This file is compiled four times (encoder_bwd_{f32,bf16,split,f32_nw4}.hip define PCRL_BWD_MODE 0 / 1 / 2 / 3): each translation
+// unit instantiates the kernels of ONE arithmetic mode (3: only the four-wave fp32 tile kernel) for the twelve supported shapes, so they compile in parallel; the
 // C entry points, the reduce kernel and the host-side helpers live in the mode-0 unit.
 #ifndef PCRL_BWD_MODE
 #error "include through encoder_bwd_{f32,bf16,split}.hip"
@@ -1130,6 +1130,8 @@ static size_t bwd_lds_bytes_tile(int T0, int C1, int kC2, int kC3) {
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + (size_t)kC3 * kC2);
 }
 
+int encoder_bwd_points_nw4_f32(int T0, int c1, int c2, int c3, const BwdParams& p, size_t lds, hipStream_t stream);
+
 template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
     if (p.tile_mode) {
@@ -1143,10 +1145,8 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
         // at most C3 / 32 tiles per cloud: when even that many fit one per SIMD, take the four-wave build (no register spills)
         static const int nw_forced = [] { const char* e = getenv("PCRL_BWD_TILE_WAVES"); return e ? atoi(e) : 0; }();
         const bool four = !BF16 && !SPLIT && (nw_forced ? nw_forced == 4 : (long long)p.cl.B * (C3 / 32) <= 4ll * num_cus());
-        if (four) {
-            auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT, (BF16 || SPLIT) ? 8 : 4>;
-            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
-            hipLaunchKernelGGL(kern, dim3(num_cus()), dim3((BF16 || SPLIT) ? 512 : 256), lds, stream, p);
+        if (four) {            // instantiated in its own translation unit (encoder_bwd_f32_nw4.hip) so that the two builds compile in parallel
+            if (int rc = encoder_bwd_points_nw4_f32(T0, C1, C2, C3, p, lds, stream)) return rc;
         } else {
             auto kern = encoder_bwd_points_kernel<T0, C1, C2, C3, BF16, SPLIT>;
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
@@ -1190,6 +1190,23 @@ static BwdWorkspace bwd_workspace(int B, int C, int C1, int kC2, int kC3) {
     return w;
 }
 
+#if PCRL_BWD_MODE == 3
+// Mode 3 = this unit only: the four-wave (spill-free) fp32 tile kernel for every supported shape.
+int encoder_bwd_points_nw4_f32(int T0, int c1, int c2, int c3, const BwdParams& p, size_t lds, hipStream_t stream) {
+    int rc = PCRL_E_ARG;
+#define PCRL_BWD_CASE(T0_, C1_, C2_, C3_)                                                                     \
+    if (T0 == T0_ && c1 == C1_ && c2 == C2_ && c3 == C3_) {                                                  \
+        auto kern = encoder_bwd_points_kernel<T0_, C1_, C2_, C3_, false, false, 4>;                          \
+        rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);                                   \
+        if (rc == PCRL_OK) hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(256), lds, stream, p);             \
+    }
+    PCRL_BWD_CASE(2, 64, 128, 256) PCRL_BWD_CASE(3, 64, 128, 256) PCRL_BWD_CASE(4, 64, 128, 256) PCRL_BWD_CASE(5, 64, 128, 256)
+    PCRL_BWD_CASE(2, 128, 128, 256) PCRL_BWD_CASE(3, 128, 128, 256) PCRL_BWD_CASE(4, 128, 128, 256) PCRL_BWD_CASE(5, 128, 128, 256)
+    PCRL_BWD_CASE(2, 32, 64, 128) PCRL_BWD_CASE(3, 32, 64, 128) PCRL_BWD_CASE(4, 32, 64, 128) PCRL_BWD_CASE(5, 32, 64, 128)
+#undef PCRL_BWD_CASE
+    return rc;
+}
+#else
 // The kernels of this unit's mode for every supported shape.
 int PCRL_BWD_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st) {
     constexpr bool kBf16 = PCRL_BWD_MODE == 1, kSplit = PCRL_BWD_MODE == 2;
@@ -1202,6 +1219,7 @@ int PCRL_BWD_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, int
 #undef PCRL_BWD_CASE
     return rc;
 }
+#endif
 
 int encoder_bwd_launch_f32(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st);
 int encoder_bwd_launch_bf16(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st);
