@@ -12,7 +12,9 @@ adjust_saturation, adjust_hue, _rgb2hsv, _hsv2rgb}) with plain torch ops, in the
 
 PARITY UNPINNED against torchvision itself (it cannot be imported in this container, so no fixture could be generated
 from it); anchored on the reference's call site above: one parameter draw per call shared by the whole batch, a
-per-cloud grayscale mean for the contrast step, uint8 truncation after every step.
+per-cloud grayscale mean for the contrast step, uint8 truncation after every step -- and held to hand-derived known
+answers of the published algorithm (tests/test_color_jitter_oracle.py: brightness clamp / truncation, grayscale weights,
+saturation and contrast end points, per-cloud contrast mean, hue rotations of the primaries, step order, draw ranges).
 """
 import torch
 

@@ -1,0 +1,86 @@
+"""Known-answer checks of oracle/color_jitter_ref.py, the CPU restatement of torchvision 0.14's uint8 ColorJitter that the HIP
+ColorJitterPoints kernels are compared with.  torchvision cannot be imported in this environment, so the restatement is held to
+answers worked out by hand from the published algorithm (functional_tensor.py: _blend, rgb_to_grayscale, adjust_*, _rgb2hsv,
+_hsv2rgb) -- the oracle stays "unpinned" in the strict sense (no vector produced by torchvision itself).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import color_jitter_ref as cj
+
+
+def _img(pixels):
+    """[P, 3] uint8 values -> rgb [1, 3, P]"""
+    return torch.tensor(pixels, dtype=torch.uint8).t().reshape(1, 3, -1)
+
+
+def _run(pixels, op, factor):
+    factors = [None] * 4
+    factors[op] = factor
+    return cj.color_jitter(_img(pixels), [op], factors)[0].t().tolist()
+
+
+def test_brightness_is_a_clamped_truncated_scale():
+    # _blend(img, 0, f) = clamp(f * img, 0, 255).to(uint8): truncation, not rounding
+    assert _run([[100, 200, 3], [0, 255, 51]], 0, 1.5) == [[150, 255, 4], [0, 255, 76]]      # 3 * 1.5 = 4.5 -> 4, 51 * 1.5 = 76.5 -> 76
+    assert _run([[100, 200, 3]], 0, 0.0) == [[0, 0, 0]]
+    assert _run([[100, 200, 3]], 0, 1.0) == [[100, 200, 3]]
+
+
+def test_grayscale_weights_and_saturation_end_points():
+    # rgb_to_grayscale: (0.2989 r + 0.587 g + 0.114 b).to(uint8)
+    px = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 20, 30]]
+    gray = [int(0.2989 * r + 0.587 * g + 0.114 * b) for r, g, b in px]
+    assert gray == [76, 149, 29, 18]
+    assert _run(px, 2, 0.0) == [[g, g, g] for g in gray]              # saturation 0: the grayscale image in every channel
+    assert _run(px, 2, 1.0) == px                                     # saturation 1: identity
+    # saturation 2: clamp(2 * x - gray): pure red -> (255, 0, 0) stays, (10, 20, 30) -> (2, 22, 42)
+    assert _run(px, 2, 2.0)[3] == [2, 22, 42] and _run(px, 2, 2.0)[0] == [255, 0, 0]
+
+
+def test_contrast_blends_with_the_clouds_mean_gray():
+    px = [[10, 20, 30], [200, 100, 50], [0, 0, 0], [255, 255, 255]]
+    gray = [int(0.2989 * r + 0.587 * g + 0.114 * b) for r, g, b in px]           # [18, 124, 0, 254]
+    mean = float(np.mean(np.array(gray, dtype=np.float32)))                       # one mean per cloud, over the uint8 grayscale image
+    assert _run(px, 1, 0.0) == [[int(mean)] * 3] * 4                             # contrast 0: every value is the (truncated) mean
+    assert _run(px, 1, 1.0) == px
+    want = [[int(min(max(1.5 * v + (1 - 1.5) * mean, 0.0), 255.0)) for v in p] for p in px]
+    assert _run(px, 1, 1.5) == want
+    two = cj.color_jitter(torch.cat([_img(px), _img([[50, 50, 50]] * 4)]), [1], [None, 0.0, None, None])
+    # the mean is per cloud, not per batch -- and the gray of (50, 50, 50) is 49: the three weights sum to 0.9999 and .to(uint8) truncates
+    assert two[1].t().tolist() == [[49, 49, 49]] * 4 and two[0].t().tolist() == [[int(mean)] * 3] * 4
+
+
+def test_hue_rotations_of_the_primaries():
+    px = [[255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128], [0, 0, 0]]
+    # +120 degrees: red -> green -> blue -> red; +180 degrees: the complements.  Within 1: the float HSV arithmetic lands a hair
+    # below an integer for some hues (h * 6 = 1.0000001 -> q = 0.9999999 -> 254.99997 -> 254 after the uint8 truncation)
+    assert np.abs(np.array(_run(px, 3, 1.0 / 3.0)[:3]) - np.array([[0, 255, 0], [0, 0, 255], [255, 0, 0]])).max() <= 1
+    assert np.abs(np.array(_run(px, 3, 0.5)[:3]) - np.array([[0, 255, 255], [255, 0, 255], [255, 255, 0]])).max() <= 1
+    assert _run(px, 3, 0.5)[0] == [0, 255, 255]
+    assert _run(px, 3, 0.25)[3:] == [[128, 128, 128], [0, 0, 0]]                        # achromatic pixels have no hue to rotate
+    out = np.array(_run([[10, 200, 90], [250, 3, 77], [1, 2, 3]], 3, 0.0))              # hue 0: the HSV round trip moves a value by < 1
+    assert np.abs(out - np.array([[10, 200, 90], [250, 3, 77], [1, 2, 3]])).max() <= 1
+
+
+def test_steps_apply_in_the_drawn_order_with_truncation_in_between():
+    px = [[100, 50, 25]]
+    a = cj.color_jitter(_img(px), [0, 2], [3.0, None, 0.0, None])[0].t().tolist()       # brighten (red clamps at 255), then desaturate
+    b = cj.color_jitter(_img(px), [2, 0], [3.0, None, 0.0, None])[0].t().tolist()       # desaturate, then brighten
+    g_after = int(0.2989 * 255 + 0.587 * 150 + 0.114 * 75)                               # 172
+    g_before = int(0.2989 * 100 + 0.587 * 50 + 0.114 * 25)                               # 62
+    assert a == [[g_after] * 3] and b == [[3 * g_before] * 3] and a != b
+
+
+def test_parameter_draw_ranges_and_order():
+    torch.manual_seed(0)
+    seen_orders = set()
+    for _ in range(200):
+        order, fac = cj.draw_params(0.4, 0.3, 0.2, 0.1)
+        assert sorted(order) == [0, 1, 2, 3]
+        seen_orders.add(tuple(order))
+        assert 0.6 <= fac[0] <= 1.4 and 0.7 <= fac[1] <= 1.3 and 0.8 <= fac[2] <= 1.2 and -0.1 <= fac[3] <= 0.1
+    assert len(seen_orders) > 12                                       # randperm(4): 24 orders
+    order, fac = cj.draw_params(0.0, 0.0, 0.5, 0.0)
+    assert fac[0] is None and fac[1] is None and fac[3] is None and 0.5 <= fac[2] <= 1.5
+    order, fac = cj.draw_params(1.5, 0, 0, 0)
+    assert 0.0 <= fac[0] <= 2.5                                        # the lower end is clipped at 0
