@@ -81,6 +81,11 @@ def parse():
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16", "f32split"], help="override the workload's encoder arithmetic; "
                     "f32split = the EXPERIMENTAL three-term bf16 split of the fp32 contractions (~1e-6 of fp32, not bit-comparable): the JSON "
                     "line then says dtype f32split and is not the headline configuration")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the short extra run of BASELINE config 4 (K3: B=1024, N=1200, C=7, the "
+                    "shape north_star's strong-scaling target is stated for) that every default k1 line carries as `config4_k3`")
+    ap.add_argument("--extra-steps", type=int, default=100)
+    ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
     return ap.parse_args()
 
 
@@ -102,6 +107,76 @@ def build_agent(wl, batch_per_rank, device, encoder_dtype=None):
     return _build(cfg).to(device), C
 
 
+def device_ring(wl, capacity, rank, device):
+    """Device-resident replay (pointcloud_rl_amd/replay.py): every rank owns a ring of synthetic transitions and each step
+    samples its share of the batch from it (uniform with replacement, as OneStepTransition does) -- sampling is part of the
+    timed step, the ring is resident in HBM before the timed region."""
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    memory = DeviceReplay(capacity, device=device, seed=1 + rank)
+    for lo in range(0, capacity, 512):
+        memory.push_batch(make_batch_np(min(512, capacity - lo), wl["N"], wl["A"], seed=1 + 1000 * rank + lo, agent=wl["S"], **wl["obs_kw"]))
+    return memory
+
+
+def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True):
+    """A short, separately reported run of another workload (or of another encoder arithmetic) with the same protocol as the
+    headline -- device ring, hipGraph replay, barrier + synchronize on both sides, MAX over ranks -- for the extra objects of the
+    JSON line.  Never the reported `value`."""
+    wl = WORKLOADS[name]
+    assert wl["B"] % world == 0
+    b_rank = wl["B"] // world
+    agent, _ = build_agent(wl, b_rank, device, encoder_dtype)
+    if dist_on:
+        agent.to_ddp(device_ids=["cuda"])
+    if memory is None:
+        memory = device_ring(wl, wl.get("capacity", 2048), rank, device)
+    agent.train()
+    if graphs:
+        agent.enable_graphs()
+
+    def sync():
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    u = 0
+    for _ in range(warmup):
+        u += 1
+        agent.update_parameters(memory, u)
+    for _ in range(12):
+        if not graphs or len(getattr(agent, "_graphs", {})) >= 2:
+            break
+        u += 1
+        agent.update_parameters(memory, u)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        u += 1
+        agent.update_parameters(memory, u)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    out = {"value": steps / dt, "unit": "gradient steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+           "global_batch": wl["B"], "batch_per_gpu": b_rank, "points": wl["N"], "n_gpus": world, "scaling": "strong",
+           "exchange": exchange_mode(agent, dist_on)}
+    del agent, memory
+    torch.cuda.empty_cache()
+    return out
+
+
+def exchange_mode(agent, dist_on):
+    """How the data-parallel step ran its all-reduces: nodes of the step's one hipGraph, or eager between per-segment graphs."""
+    if not dist_on:
+        return None
+    graphs = getattr(agent, "_graphs", None) or {}
+    if not graphs:
+        return "eager step, asynchronous all-reduces"
+    return "captured in the step's hipGraph" if all(len(segs) == 1 for segs, _, _ in graphs.values()) else "eager all-reduces between per-segment hipGraphs"
+
+
 def usable_cpus():
     """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box shows 256 logical
     CPUs but grants e.g. cpu.max = 1600000/100000 = 16; torch's default of 128 threads on 16 CPUs only adds contention)."""
@@ -115,11 +190,13 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0):
+def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0, warmup_batch=0):
     """The reference's update step restated op for op (six encoder passes, permute LayerNorm, per-tensor
     Adam groups), timed on the host: 1 warm-up + `steps` timed steps.  sample_batch > 0 bounds the work: the step is
-    timed on the first `sample_batch` transitions of the batch and the rate is scaled by sample_batch / B (> 99 % of
-    the reference's step is per-cloud encoder work, BASELINE.md section 2, so the step time is linear in the batch)."""
+    timed on the first `sample_batch` transitions of the batch and the rate is scaled by sample_batch / B -- the result is then
+    tagged "extrapolated" (> 99 % of the reference's step is per-cloud encoder work, BASELINE.md section 2, but a small slice
+    runs at another cache / thread efficiency than the full batch).  warmup_batch > 0: the untimed warm-up step (lazy
+    initialisation, allocator) runs on that many transitions instead of the whole sample."""
     from oracle import torch_ref
     from pointcloud_rl_amd.synthetic import make_batch_np
     params = {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}
@@ -129,21 +206,80 @@ def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0):
                              update_coeff=agent.update_coeff["default"], mirror_redundancy=True)
     Bs = min(sample_batch, wl["B"]) if sample_batch else wl["B"]
     batch = make_batch_np(Bs, wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
-    tb = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch.items()}
+    as_t = lambda b: {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in b.items()}
+    tb = as_t(batch)
     torch.set_num_threads(threads if threads else usable_cpus())
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
-    eps = lambda: [torch.randn(Bs, wl["A"], generator=g), torch.randn(Bs, wl["A"], generator=g)]
-    ref.update_parameters(tb, 1, eps())
+    eps = lambda n: [torch.randn(n, wl["A"], generator=g), torch.randn(n, wl["A"], generator=g)]
+    if warmup_batch and warmup_batch < Bs:
+        cut = lambda v: v[:warmup_batch]
+        wb = {k: ({kk: cut(vv) for kk, vv in v.items()} if isinstance(v, dict) else cut(v)) for k, v in tb.items()}
+        ref.update_parameters(wb, 2, eps(warmup_batch))           # an even count: the actor / target branch is warmed up too
+    else:
+        ref.update_parameters(tb, 1, eps(Bs))
     t0 = time.perf_counter()
     for u in range(2, 2 + steps):
-        ref.update_parameters(tb, u, eps())
+        ref.update_parameters(tb, u, eps(Bs))
     dt = (time.perf_counter() - t0) / steps * (wl["B"] / Bs)
-    what = f"{steps} full update steps (B={wl['B']}, N={wl['N']})" if Bs == wl["B"] else \
+    what = f"{steps} full update step(s) (B={wl['B']}, N={wl['N']})" if Bs == wl["B"] else \
         f"{steps} update steps on a {Bs}-transition slice of the B={wl['B']}, N={wl['N']} batch, time scaled by {wl['B']}/{Bs}"
-    return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port",
-            "sample": f"{what} after 1 warm-up, torch {torch.__version__} CPU, {cores} threads "
+    warm = f"1 warm-up step on {warmup_batch} transitions" if (warmup_batch and warmup_batch < Bs) else "1 warm-up"
+    return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port", "extrapolated": Bs != wl["B"],
+            "sample": f"{what} after {warm}, torch {torch.__version__} CPU, {cores} threads "
                       f"(box grants {usable_cpus()} of {os.cpu_count()} logical CPUs)"}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process -- one per GPU, each
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment, exactly what torch.distributed.run
+    hands them -- wait for all of them, forward rank 0's JSON line as the last line of stdout and return non-zero when any rank
+    failed.  The parent makes no HIP call (importing torch does not initialise the device), and nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n = args.gpus
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    base.setdefault("OMP_NUM_THREADS", "1")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline, failed = time.time() + args.launch_timeout, []
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):      # a rank died: its peers would wait in a collective until RCCL's timeout
+            break
+        if time.time() > deadline:
+            failed.append(f"no result after {args.launch_timeout:.0f} s")
+            break
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        if p.poll() is None:              # still alive after a peer failed / after the deadline: stop exactly this child
+            p.kill()
+            p.wait()
+            failed.append(f"rank {r} stopped")
+        elif p.returncode != 0:
+            failed.append(f"rank {r} rc {p.returncode}")
+    reader.join(timeout=10)
+    out0 = chunks[0] if chunks else ""
+    lines = [l for l in out0.splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith("{")]
+    for l in lines:
+        if not l.startswith("{"):
+            print(l)
+    if failed or len(json_lines) != 1:
+        print(f"bench.py launcher: {n} ranks failed: {failed or 'rank 0 printed no result line'}", file=sys.stderr)
+        return 1
+    print(json_lines[0], flush=True)
+    return 0
 
 
 def main():
@@ -156,9 +292,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (the reference spawns its own ranks the same
+        # way, pyrl/apis/run_rl.py:495-502) -- it never touches the GPU, the ranks are its children
+        raise SystemExit(launch_ranks(args))
     if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
@@ -185,14 +323,7 @@ def main():
     if dist_on:
         agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
-        # device-resident replay (pointcloud_rl_amd/replay.py): every rank owns a ring of synthetic transitions and each
-        # step samples its share of the batch from it (uniform with replacement, as OneStepTransition does) -- sampling is
-        # part of the timed step, the ring is resident in HBM before the timed region
-        from pointcloud_rl_amd.replay import DeviceReplay
-        from pointcloud_rl_amd.synthetic import make_batch_np
-        memory = DeviceReplay(args.replay_capacity, device=device, seed=1 + rank)
-        for lo in range(0, args.replay_capacity, 512):
-            memory.push_batch(make_batch_np(min(512, args.replay_capacity - lo), wl["N"], wl["A"], seed=1 + 1000 * rank + lo, agent=wl["S"], **wl["obs_kw"]))
+        memory = device_ring(wl, args.replay_capacity, rank, device)
     elif args.replay == "host":
         # the reference's arrangement: the sampled batch sits in host memory and crosses PCIe inside update_parameters
         # (`memory.sample(...).to_torch(device=..., non_blocking=True)`, sac.py:104); pinned here, pageable in the reference
@@ -255,6 +386,7 @@ def main():
         agent.update_parameters(memory, updates)
     sync()
     elapsed = time.perf_counter() - t0
+    exch_mode = exchange_mode(agent, dist_on)
     nocomm_ms = None
     if dist_on:
         # the same step with the gradient exchange switched off (every rank trains on its shard alone): what is left of
@@ -323,6 +455,8 @@ def main():
             "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32"), "data": "synthetic",
             "config": {"workload": wl["desc"], "global_batch": wl["B"], "points": wl["N"], "channels": C, "action_dim": wl["A"],
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
+                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist_on else None,
+                       "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1, "exchange": exch_mode,
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -344,34 +478,50 @@ def main():
             all_cores_b = wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points))
             out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps, args.cpu_threads, sample_batch=all_cores_b)
             if not args.cpu_threads:
-                one_b = max(4, int(wl["B"] * 24_000 / points))
-                out["cpu_baseline_1thread"] = cpu_baseline(agent, wl, 2, 1, sample_batch=one_b)
-        if (not dist_on and not args.batch and args.encoder_dtype is None and not args.no_experimental and out["dtype"] == "f32"
-                and args.replay == "device"):
-            # Not the headline: the same step with the EXPERIMENTAL split-precision encoder forward (three-term bf16 split of the
-            # fp32 contractions, within ~3e-6 of the exact kernel, argmax exact on the reference fixtures)
-            del agent
-            torch.cuda.empty_cache()
-            agent2, _ = build_agent(wl, b_rank, device, "f32split")
-            agent2.train()
-            if not args.no_graphs:
-                agent2.enable_graphs()
-            u2 = 0
-            for _ in range(max(args.warmup // 2, 30)):
-                u2 += 1
-                agent2.update_parameters(memory, u2)
-            n2 = max(args.steps // 2, 10)
-            sync()
-            t2 = time.perf_counter()
-            for _ in range(n2):
-                u2 += 1
-                agent2.update_parameters(memory, u2)
-            sync()
-            dt2 = time.perf_counter() - t2
-            out["experimental_f32split"] = {"value": n2 / dt2, "unit": "gradient steps/s", "ms_per_step": dt2 / n2 * 1e3, "steps": n2,
-                                            "note": "encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); "
-                                                    "opt-in, not the reported value"}
+                # the reference's shipped setting (one thread): ONE timed step on the same sample as the all-cores leg -- for K1 the
+                # full batch (8-9 s), no slice scaling
+                out["cpu_baseline_1thread"] = cpu_baseline(agent, wl, 1, 1, sample_batch=all_cores_b, warmup_batch=4)
         line = json.dumps(out)
+    # ---- extra objects (never the reported value), every rank takes part: the collectives of a data-parallel run are inside ----
+    plain_k1 = args.workload == "k1" and not args.batch and args.encoder_dtype is None and args.replay == "device" and not args.single_rank_exchange
+    extras = {}
+    # The extras must never cost the headline line: if they do not finish in time (a collective that hangs in a shape the headline
+    # did not exercise), every rank leaves on its own timer and rank 0 prints the line it already has.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            import ctypes
+            d = json.loads(line)
+            d["extras_error"] = f"extra workloads did not finish within {args.extra_timeout:.0f} s; skipped"
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(d), flush=True)
+        os._exit(0)
+    timer_x = threading.Timer(args.extra_timeout, give_up)
+    timer_x.daemon = True
+    timer_x.start()
+    if plain_k1 and not dist_on and not args.no_experimental:
+        # the same step with the EXPERIMENTAL split-precision encoder forward (three-term bf16 split of the fp32 contractions,
+        # within ~3e-6 of the exact kernel, argmax exact on the reference fixtures)
+        del agent
+        torch.cuda.empty_cache()
+        extras["experimental_f32split"] = dict(
+            side_rate("k1", rank, world, device, dist_on, max(args.steps // 2, 10), max(args.warmup // 2, 30), "f32split", memory=memory, graphs=not args.no_graphs),
+            note="encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); opt-in, not the reported value")
+        agent = None
+    if plain_k1 and not args.no_extra_workloads and WORKLOADS["k3"]["B"] % world == 0:
+        # BASELINE config 4 on the same ranks: the shape the >= 6x strong-scaling target of north_star is stated for.  Each
+        # `--gpus N` line carries it, so the scaling of K3 can be read off the driver's own N = 1, 2, 4, 8 runs.
+        agent = memory = None
+        torch.cuda.empty_cache()
+        extras["config4_k3"] = dict(side_rate("k3", rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs),
+                                    workload=WORKLOADS["k3"]["desc"])
+    timer_x.cancel()
+    if rank == 0:
+        if extras:
+            out.update(extras)
+            line = json.dumps(out)
     if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -418,7 +418,11 @@ int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_segs, int32
  * it by one), state[1] = size (the host stores len(buffer) there after every push), state[2] and state[3 .. 3 + B) =
  * workgroup tickets (0 between launches; `state` holds 3 + B words).  Same rows as pcrl_replay_sample_gather(..., size = state[1], draw = state[0], ...). */
 int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t capacity, uint64_t seed,
-                                    uint64_t* state, int32_t* idx_out, void* stream);
+                                    uint64_t* state, int64_t state_words, int32_t* idx_out, void* stream);
+/* state_words = the number of 8-byte words `state` holds: PCRL_E_ARG when it is below 3 + B (the kernel would write tickets
+ * past the end).  PRECONDITION: every ticket word (state[2 .. 3 + B)) is zero on entry; a launch leaves them zero when it
+ * completes, an aborted one may not -- zero them (hipMemsetAsync of state + 2) before sampling again, or the draw count
+ * never advances and the same rows are drawn forever. */
 
 /* dst[i][0] = take_exp[i] ? exp(src[i][0]) : src[i][0] for up to 16 device scalars in one launch: the metrics
  * update_parameters returns (sac.py:150-159,199-204) and alpha = exp(log_alpha) (sac.py:196).  Up to 4 deferred optimizer

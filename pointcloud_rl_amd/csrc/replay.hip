@@ -102,8 +102,10 @@ extern "C" int pcrl_replay_sample_gather(const pcrl_gather_seg* segs, int32_t n_
 }
 
 extern "C" int pcrl_replay_sample_gather_state(const pcrl_gather_seg* segs, int32_t n_segs, int32_t B, int64_t capacity, uint64_t seed,
-                                               uint64_t* state, int32_t* idx_out, void* stream) {
+                                               uint64_t* state, int64_t state_words, int32_t* idx_out, void* stream) {
     if (!state) return fail(PCRL_E_ARG, "NULL argument");
+    if (B < 0 || state_words < 3 + (int64_t)B) return fail(PCRL_E_ARG, "replay sample: state holds %lld words, 3 + B = %lld needed",
+                                                           (long long)state_words, 3ll + B);
     if (capacity < 1 || capacity > 0xFFFFFFFFll) return fail(PCRL_E_ARG, "replay sample: 1 <= capacity < 2^32");
     GatherParams p{};
     p.idx = nullptr; p.B = B; p.capacity = capacity; p.idx_out = idx_out; p.size = 1;

@@ -519,7 +519,7 @@ def replay_sample_gather_state(segs, B, capacity, seed, state, idx_out=None):
     assert state.is_cuda and state.dtype == torch.int64 and state.numel() >= 3 + B and state.is_contiguous()
     with _span("replay_gather"):
         check(lib().pcrl_replay_sample_gather_state(segs, len(segs), B, ctypes.c_int64(capacity), ctypes.c_uint64(seed & (2 ** 64 - 1)),
-                                                    _ptr(state), _ptr(idx_out), _stream()))
+                                                    _ptr(state), ctypes.c_int64(state.numel()), _ptr(idx_out), _stream()))
 
 
 def gather_scalars(entries, pending=(), host_out=None):

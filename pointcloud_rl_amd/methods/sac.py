@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.dist import Exchange, allreduce_sum_, exchange_active, world_size
+from ..utils.dist import Exchange, allreduce_sum_, capture_exchange, exchange_active, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -496,6 +496,18 @@ class SAC(BaseAgent):
                     d_.copy_(s_, non_blocking=True)
         return self._static_batch
 
+    def _aliases_static(self, batch):
+        """True when every leaf of `batch` that the step reads IS the matching leaf of the static batch (same address)."""
+        for k in ("obs", "next_obs", "actions", "rewards", "dones"):
+            src, dst = batch[k], self._static_batch[k]
+            if isinstance(src, dict) != isinstance(dst, dict):
+                return False
+            for kk in (src if isinstance(src, dict) else [None]):
+                s_, d_ = (src[kk], dst.get(kk)) if kk is not None else (src, dst)
+                if d_ is None or s_.data_ptr() != d_.data_ptr() or s_.shape != d_.shape:
+                    return False
+        return True
+
     def _fused_args(self, batch, do_actor, polyak):
         return (batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), {}
 
@@ -504,7 +516,9 @@ class SAC(BaseAgent):
         from, and when that replay's sampling is one host-free launch (`DeviceReplay.graph_sampling`) the launch becomes the
         first node of the captured step: replays call `fetch(launch=False)` (bookkeeping only)."""
         fetch = batch if callable(batch) else (lambda launch=True: batch)
-        if not (callable(batch) and getattr(sampler, "graph_sampling", False) and os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1"):
+        # a pre-processor produces fresh tensors outside the graph: its output cannot be the captured step's input in place
+        if not (callable(batch) and getattr(sampler, "graph_sampling", False) and os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1"
+                and self.obs_processor is None):
             sampler = None
         do_actor = updates % self.actor_update_interval == 0
         polyak = self._polyak_now(updates)
@@ -531,15 +545,43 @@ class SAC(BaseAgent):
                 return self._finish(self._step_body(self._to_static(fetch()), do_actor, polyak), updates)
             for enc in {id(e): e for owners in self._packed_owners.values() for e in owners}.values():
                 enc.invalidate_packed()            # every replay starts by re-packing the (updated) weights
-            batch = self._to_static(fetch(launch=False) if sampler is not None else fetch())
+            if sampler is not None:
+                # The captured sampling launch writes the replay's staging tensors, the captured step reads _static_batch: they
+                # must be the SAME memory.  They are not when the static batch was made from another replay object or from a
+                # non-persistent batch (clones) -- the graphs captured so far then read buffers this replay never fills.
+                staged = fetch(launch=False)
+                if self._static_batch is not None and not self._aliases_static(staged):
+                    self._graphs, self._graph_seen, self._fast = {}, {k: self._graph_warmup for k in self._graph_seen}, None
+                    self._graph_sampler, self._graph_flag, self._static_batch = {}, {}, None
+                if not getattr(staged, "persistent", False):
+                    sampler = None                     # would be cloned: copy a freshly sampled batch in on every step instead
+            batch = self._to_static(staged if sampler is not None else fetch())
+            if sampler is not None:
+                assert self._aliases_static(staged), "captured sampling must write the tensors the captured step reads"
             pre = (lambda: sampler.launch_sample(self.batch_size)) if sampler is not None else None
             torch.cuda.synchronize()
             self._graph_sampler[key] = sampler
-            self._graphs[key] = self._capture_segments(batch, do_actor, polyak, pre) if exchanging else self._capture_whole(batch, do_actor, polyak, pre)
-            self._refresh_fast()
-            if exchanging:                          # capturing a segmented step also executed it
-                segments, names, out = self._graphs[key]
+            captured = None
+            if not exchanging:
+                captured = self._capture_whole(batch, do_actor, polyak, pre)
+            elif capture_exchange():
+                # data-parallel, RCCL: the all-reduces are nodes of the step's graph (forked onto RCCL's stream by the process
+                # group, joined before each optimizer pass) -- one graph launch per step, no host work between the segments
+                try:
+                    captured = self._capture_whole(batch, do_actor, polyak, pre, exchanging=True)
+                except RuntimeError as err:          # a stack that refuses collectives under capture: every rank fails alike
+                    import warnings
+                    warnings.warn(f"capturing the gradient exchange failed ({str(err).splitlines()[0]}); cutting the step into segments instead")
+                    os.environ["PCRL_CAPTURE_EXCHANGE"] = "0"
+                    torch.cuda.synchronize()
+            if captured is None:
+                captured = self._capture_segments(batch, do_actor, polyak, pre)
+                self._graphs[key] = captured
+                self._refresh_fast()
+                segments, names, out = captured       # capturing a segmented step also executed it
                 return self._finish(dict(zip(names, out.unbind(0))), updates)
+            self._graphs[key] = captured
+            self._refresh_fast()
         elif self._graph_sampler.get(key) is not None:
             fetch(launch=False)                     # the graph holds the sampling launch; the staging tensors are its inputs
         else:
@@ -548,13 +590,14 @@ class SAC(BaseAgent):
         flag = self._graph_flag.get(key)
         if flag is not None:
             flag[0][:flag[1]] = 0xFFFFFFFF          # sentinel in every slot of the pinned metrics mirror (the step's last kernel fills them)
-        ex = Exchange()
+        ex = Exchange(enabled=exchanging)
         for graph, (kind, pieces) in segments:
             graph.replay()
             for t in pieces:
                 ex.start(t)
             if kind == "finish":
                 ex.finish()
+        self._invalidate_packed_after_replay()
         if flag is not None:
             return self._finish(dict.fromkeys(names), updates, host_values=self._await_flag(*flag))
         if out.device.type == "cpu":        # pinned host copy made by the graph's last node: wait for the graph, read it
@@ -565,27 +608,47 @@ class SAC(BaseAgent):
             return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
         return self._finish(dict(zip(names, out.unbind(0))), updates)
 
+    def _invalidate_packed_after_replay(self):
+        """A replayed step updated the encoder weights through raw pointers (no autograd version bump) and re-packs only
+        inside the graph: eager users of the encoder (module-tree forward, the acting warm-up, DrQ's inference augmentation)
+        must not trust the packed MFMA image they cached."""
+        for owners in self._packed_owners.values():
+            for enc in owners:
+                enc._packed_key = None
+
     @staticmethod
     def _await_flag(view, n):
         """Spin until the step's last kernel has stored all n metrics into the pinned mirror (slots pre-filled with the sentinel
         0xFFFFFFFF; `view` is the mirror as uint32): no stream synchronisation, no copy node.  If the stream drains without the
         slots changing, the launch failed and the error is raised from the synchronisation."""
-        slots, spins = view[:n], 0
+        slots, spins, t0 = view[:n], 0, None
         while (slots == 0xFFFFFFFF).any():
             spins += 1
-            if spins & 0xFFFF == 0 and torch.cuda.current_stream().query():
-                torch.cuda.synchronize()
-                if (slots == 0xFFFFFFFF).any():
-                    raise RuntimeError("update step finished without publishing its metrics")
+            if spins & 0xFFFF == 0:
+                if torch.cuda.current_stream().query():
+                    torch.cuda.synchronize()
+                    if (slots == 0xFFFFFFFF).any():
+                        raise RuntimeError("update step finished without publishing its metrics")
+                import time
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > float(os.environ.get("PCRL_STEP_TIMEOUT_S", "120")):
+                    # a hung kernel or a collective whose peer is gone: hand over to a blocking synchronisation, which the
+                    # process group's watchdog / the driver's timeout can see, instead of spinning forever
+                    torch.cuda.synchronize()
+                    raise RuntimeError("update step did not publish its metrics within PCRL_STEP_TIMEOUT_S")
         return slots.view(np.float32).tolist()
 
-    def _capture_whole(self, batch, do_actor, polyak, pre=None):
+    def _capture_whole(self, batch, do_actor, polyak, pre=None, exchanging=False):
+        """exchanging: the step's all-reduces (FusedStep.run -> Exchange) are captured with it.  torch's ProcessGroupNCCL
+        launches a collective on its own stream behind an event of the current one and `wait()` joins it back: under capture
+        that is a forked branch of the graph, so the Q-head range still travels under the encoder backward."""
         graph = torch.cuda.CUDAGraph()
         host = None
         pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
-        key = (do_actor, polyak, False)
+        key = (do_actor, polyak, exchanging)
         self._graph_flag.pop(key, None)
-        with _no_gc(), torch.cuda.graph(graph):
+        # thread_local: the process group's watchdog thread may touch the HIP runtime while this thread captures
+        with _no_gc(), torch.cuda.graph(graph, **(dict(capture_error_mode="thread_local") if exchanging else {})):
             if pre is not None:
                 pre()                       # the replay's sampling launch: first node of the step
             stats = self._step_body(batch, do_actor, polyak)
@@ -700,7 +763,7 @@ class SAC(BaseAgent):
         memory.sample(self.batch_size, launch=False)
         view[:n] = 0xFFFFFFFF
         if exchanging:
-            ex = Exchange()
+            ex = Exchange(enabled=True)
             for graph, (kind, pieces) in segments:
                 graph.replay()
                 for t in pieces:
@@ -710,4 +773,5 @@ class SAC(BaseAgent):
         else:
             for graph, _ in segments:
                 graph.replay()
+        self._invalidate_packed_after_replay()
         return self._ret_from_values(names, self._await_flag(view, n))

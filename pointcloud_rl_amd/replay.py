@@ -77,7 +77,7 @@ class DeviceReplay:
     def reset(self):
         self.position = self.running_count = 0
         self.items, self.item_index = None, 0
-        self.state[1:2].fill_(0)
+        self.state[1:].fill_(0)          # size, and every ticket word (an aborted sampling launch may have left some non-zero)
 
     @property
     def graph_sampling(self):

@@ -28,6 +28,15 @@ def exchange_active():
     return dist.get_world_size() > 1 or os.environ.get("PCRL_EXCHANGE_SINGLE_RANK", "0") == "1"
 
 
+def capture_exchange():
+    """True when the gradient all-reduces may be captured into the step's hipGraph: the process group runs on RCCL
+    (backend "nccl": device-side collectives on a stream; gloo reduces on host threads and cannot be captured) and
+    PCRL_CAPTURE_EXCHANGE is not "0" (which restores the segmented schedule: eager all-reduces between per-segment graphs)."""
+    if os.environ.get("PCRL_CAPTURE_EXCHANGE", "1") == "0" or not exchange_active():
+        return False
+    return str(dist.get_backend()).lower() == "nccl"
+
+
 def allreduce_sum_(flat_grad, enabled=True):
     """In-place SUM all-reduce of a flat gradient buffer.  Returns the scale (1/world) the caller must
     apply to obtain the mean, 1.0 when nothing was exchanged."""

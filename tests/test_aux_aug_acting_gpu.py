@@ -505,6 +505,95 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
         assert torch.equal(p, q), n
 
 
+def _swap_agent_and_rings(cuda, B, N, A):
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    rings = []
+    for seed in (3, 4):
+        mem = DeviceReplay(64, device=cuda, seed=seed)
+        mem.push_batch(make_batch_np(64, N, A, seed=10 + seed))
+        rings.append(mem)
+    return agent, rings
+
+
+def _consumed_rows_match(agent, mem, B):
+    """The observations the captured step reads are the rows the replay's latest sampling launch drew."""
+    idx = mem.last_indices(B).long()
+    xyz = agent._static_batch["obs"]["xyz"]
+    return torch.equal(xyz, mem.storage["obs/xyz"][idx]) and torch.equal(agent._static_batch["rewards"], mem.storage["rewards"][idx])
+
+
+def test_swapping_the_device_replay_recaptures_on_the_new_staging_tensors(cuda):
+    """An agent captured with DeviceReplay A and then fed DeviceReplay B must read B's staging tensors (the captured sampling
+    launch writes those): every step after the swap consumes the rows B drew, q_target keeps varying, and the run equals an eager
+    agent fed the same sequence bit for bit."""
+    B, N, A = 8, 64, 4
+    schedule = [0] * 6 + [1] * 8 + [0] * 4
+
+    def run(graphs):
+        agent, rings = _swap_agent_and_rings(cuda, B, N, A)
+        if graphs:
+            agent.enable_graphs(warmup=1)
+        rets = []
+        for u, which in enumerate(schedule, 1):
+            rets.append(agent.update_parameters(rings[which], u))
+            if graphs and agent._graphs:
+                torch.cuda.synchronize()
+                assert _consumed_rows_match(agent, rings[which], B), u
+        return agent, rings, rets
+
+    eager, _, rets_e = run(False)
+    graph, rings_g, rets_g = run(True)
+    assert [r_["sac/q_target"] for r_ in rets_e] == [r_["sac/q_target"] for r_ in rets_g]
+    assert len({r_["sac/q_target"] for r_ in rets_g[6:14]}) == 8           # not one frozen batch
+    assert rings_g[0].draws == 10 and rings_g[1].draws == 8
+    for (n, p), (_, q) in zip(eager.named_parameters(), graph.named_parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_synthetic_then_device_replay_does_not_freeze_the_batch(cuda):
+    """First calls with a non-persistent memory (the static batch is made of clones), then a DeviceReplay: the variants captured
+    later must not put the sampling launch in front of a step that reads the clones -- either the static batch is re-made from the
+    replay's staging tensors or the batch is copied in every step; both ways the consumed rows are the drawn rows."""
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A = 8, 64, 4
+    agent, rings = _swap_agent_and_rings(cuda, B, N, A)
+    agent.enable_graphs(warmup=1)
+    syn = SyntheticReplay(B, N, A, seed=9, device=cuda)
+    for u in range(1, 4):                                  # eager warm-up + the first capture, on clones
+        agent.update_parameters(syn, u)
+    seen = []
+    for u in range(4, 16):
+        seen.append(agent.update_parameters(rings[0], u)["sac/q_target"])
+        torch.cuda.synchronize()
+        assert _consumed_rows_match(agent, rings[0], B), u
+    assert len(set(seen)) == len(seen)
+
+
+def test_sampling_state_shorter_than_the_batch_is_refused(cuda):
+    """pcrl_replay_sample_gather_state is told how many words `state` holds and returns PCRL_E_ARG below 3 + B."""
+    import ctypes
+    from pointcloud_rl_amd import _lib, hip
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    mem = DeviceReplay(32, device=cuda, seed=1)
+    mem.push_batch(make_batch_np(32, 16, 4, seed=2))
+    B = 8
+    _, _, idx, _, segs = mem._stage(B)
+    lib = _lib.lib()
+    rc = lib.pcrl_replay_sample_gather_state(segs, len(segs), B, ctypes.c_int64(32), ctypes.c_uint64(1), ctypes.c_void_p(mem.state.data_ptr()),
+                                             ctypes.c_int64(3 + B - 1), ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(hip.raw_stream()))
+    assert rc == -1 and b"state" in lib.pcrl_last_error()          # PCRL_E_ARG
+    torch.cuda.synchronize()
+    assert mem.state[0].item() == 0
+
+
 def test_graph_replayed_acting_equals_the_eager_launches_and_follows_the_parameters(cuda):
     """After agent.enable_graphs() the acting path replays one hipGraph per (mode, observation signature): the mean action equals
     the eager launches bit for bit, also after the parameters were updated in place by training steps (the graph re-packs the

@@ -96,25 +96,34 @@ def test_segmented_graph_replay_keeps_replicas_identical(cuda):
         assert torch.isfinite(p0[n]).all()
 
 
-def test_bench_two_ranks_prints_the_contract_line(cuda):
-    """The driver's multi-GPU invocation of bench.py (torch.distributed.run, one rank per GPU), here with two ranks sharing the
-    test box's GPU over gloo: rank 0 prints exactly one JSON line with the contract's keys, strong scaling at global B=256."""
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_two_ranks_prints_the_contract_line(cuda, launcher):
+    """The driver's multi-GPU invocations of bench.py, here with two ranks sharing the test box's GPU over gloo: the plain
+    `python bench.py --gpus 2` form (bench.py starts its own ranks, as the reference's run_rl.py:495-502 does) and the
+    torch.distributed.run form.  Rank 0 prints exactly one JSON line with the contract's keys, strong scaling at global B=256."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "5",
-           "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--replay-capacity", "512"]
-    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    tail = ["--gpus", "2", "--steps", "6", "--warmup", "5", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--replay-capacity", "512",
+            "--no-extra-workloads"]
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.stdout.strip().splitlines()[-1].startswith("{")        # the result is the LAST line of stdout
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 128
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] - 1e3) < 1e-3 * 1e3
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
@@ -149,9 +158,10 @@ def test_overlapped_exchange_pieces_cover_the_flat_buffer_once(cuda):
     assert fal.grad.data_ptr() == fa.grad.data_ptr() + 4 * fa.grad.numel() and agent.log_alpha.grad.data_ptr() == fal.grad.data_ptr()
 
 
-def _rccl_worker(rank, port, graphs, exchange, out):
+def _rccl_worker(rank, port, graphs, exchange, out, capture="1"):
     """One rank; with `exchange` the data-parallel schedule runs over a one-rank RCCL group (PCRL_EXCHANGE_SINGLE_RANK)."""
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PCRL_EXCHANGE_SINGLE_RANK="1" if exchange else "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PCRL_EXCHANGE_SINGLE_RANK="1" if exchange else "0",
+                      PCRL_CAPTURE_EXCHANGE=capture)
     torch.cuda.set_device(0)
     if exchange:
         dist.init_process_group("nccl", rank=0, world_size=1)       # "nccl" is RCCL on ROCm
@@ -167,7 +177,10 @@ def _rccl_worker(rank, port, graphs, exchange, out):
         if not graphs:
             agent.actor.head.noise_override = [e.to("cuda:0") for e in _eps(u)][:2 if u % 2 == 0 else 1]
         rets.append(agent.update_parameters(mem, u))
-    if graphs and exchange:
+    if graphs and exchange and capture == "1":
+        assert all(len(segs) == 1 for segs, _, _ in agent._graphs.values())      # the all-reduces are nodes of the step's one graph
+        assert all(k[2] for k in agent._graphs)                                  # ... of the exchanging variants
+    if graphs and exchange and capture == "0":
         assert all(len(segs) >= 2 for segs, _, _ in agent._graphs.values())      # cut at every exchange
     if graphs and not exchange:
         assert all(len(segs) == 1 for segs, _, _ in agent._graphs.values())
@@ -177,15 +190,17 @@ def _rccl_worker(rank, port, graphs, exchange, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "graphs"])
-def test_rccl_single_rank_exchange_equals_plain_step(cuda, graphs):
+@pytest.mark.parametrize("graphs,capture", [(False, "1"), (True, "1"), (True, "0")], ids=["eager", "graph-with-collectives", "segmented-graphs"])
+def test_rccl_single_rank_exchange_equals_plain_step(cuda, graphs, capture):
     """RCCL itself (backend "nccl"), which refuses two ranks on the one GPU of the test box, driven with ONE rank: the step runs the
-    data-parallel schedule -- segmented hipGraphs, the Q-head range all-reduced asynchronously on RCCL's stream under the encoder
-    backward, the waits before each optimizer pass -- and, a one-rank sum being the identity, must equal the plain step bit for bit."""
+    data-parallel schedule -- the Q-head range all-reduced asynchronously on RCCL's stream under the encoder backward, the waits
+    before each optimizer pass; replayed either as ONE hipGraph that holds the collectives (the default over RCCL) or as
+    per-segment graphs with eager collectives between them (PCRL_CAPTURE_EXCHANGE=0) -- and, a one-rank sum being the identity,
+    must equal the plain step bit for bit."""
     import tempfile
     with tempfile.TemporaryDirectory() as out:
         for exchange in (True, False):
-            mp.spawn(_rccl_worker, args=(_free_port(), graphs, exchange, out), nprocs=1, join=True)
+            mp.spawn(_rccl_worker, args=(_free_port(), graphs, exchange, out, capture), nprocs=1, join=True)
         a, b = torch.load(os.path.join(out, "x1.pt")), torch.load(os.path.join(out, "x0.pt"))
     for n in a["params"]:
         assert torch.equal(a["params"][n], b["params"][n]), n

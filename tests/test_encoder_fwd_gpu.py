@@ -229,6 +229,33 @@ def test_virtual_repeat_equals_materialised_repeat(cuda):
     assert not torch.equal(a[0][0], a[0][1])          # the two augmentations of a sample differ (their jitter rows do)
 
 
+def _fixture_launch(cuda, fixture, **mode):
+    import os
+    from pointcloud_rl_amd import hip
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + ".npz"))
+    obs = {k[4:]: torch.from_numpy(d[k]).to(cuda) for k in d.files if k.startswith("obs/")}
+    g = lambda k: torch.from_numpy(np.ascontiguousarray(d["w/" + k])).to(cuda)
+    w0, w1, w2 = g("conv.mlp.conv0.weight")[..., 0].contiguous(), g("conv.mlp.conv1.weight")[..., 0].contiguous(), g("conv.mlp.conv2.weight")[..., 0].contiguous()
+    ew, keep = hip.make_encoder_weights(w0, g("conv.mlp.conv0.bias"), w1, g("conv.mlp.norm1.weight"), g("conv.mlp.norm1.bias"), w2,
+                                        g("conv.mlp.norm2.weight"), g("conv.mlp.norm2.bias"), 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep2 = hip.make_cloud_desc(obs)
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, **mode)
+    torch.cuda.synchronize()
+    return d, pooled.cpu().numpy(), argmax.cpu().numpy()
+
+
+@pytest.mark.parametrize("fixture", ["encoder_dmc_c6", "encoder_dmc_c9_posenc", "encoder_maniskill_c7", "encoder_dmc_motivating_c6"])
+def test_fwd_f32_on_the_reference_fixtures(cuda, fixture):
+    """The DEFAULT exact-fp32 kernel (pcrl_encoder_fwd_f32) directly against what the reference itself computed (fixtures captured
+    from /root/reference by tools/gen_golden.py: pointnet.py:148-151 `self.conv(feature)` + `feature.max(-1)` on torch CPU): argmax
+    bit-exact on every (cloud, channel), pooled values within north_star's 1e-5."""
+    d, pooled, argmax = _fixture_launch(cuda, fixture)
+    assert np.array_equal(argmax, d["argmax"]), f"{(argmax != d['argmax']).sum()} of {argmax.size} argmax entries differ"
+    np.testing.assert_allclose(pooled, d["pooled"], rtol=0, atol=1e-5)
+
+
 @pytest.mark.parametrize("fixture", ["encoder_dmc_c6", "encoder_dmc_c9_posenc", "encoder_maniskill_c7", "encoder_dmc_motivating_c6"])
 def test_split_precision_forward_on_the_reference_fixtures(cuda, fixture):
     """EXPERIMENTAL pcrl_encoder_fwd_f32split (three-term bf16 split of the fp32 contractions) on the encoder fixtures captured
