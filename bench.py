@@ -234,51 +234,65 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process -- one per GPU, each
     with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment, exactly what torch.distributed.run
     hands them -- wait for all of them, forward rank 0's JSON line as the last line of stdout and return non-zero when any rank
-    failed.  The parent makes no HIP call (importing torch does not initialise the device), and nothing is exec'ed."""
+    failed.  The parent makes no HIP call (importing torch does not initialise the device), and nothing is exec'ed.
+    If the ranks fail with the gradient all-reduces captured in the step's hipGraph (the default over RCCL), they are started
+    once more with PCRL_CAPTURE_EXCHANGE=0 (eager all-reduces between per-segment graphs); the line then says so."""
     import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import threading
     n = args.gpus
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    base.setdefault("OMP_NUM_THREADS", "1")
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    import threading
-    chunks = []
-    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    deadline, failed = time.time() + args.launch_timeout, []
-    while any(p.poll() is None for p in procs):
-        if any(p.poll() not in (None, 0) for p in procs):      # a rank died: its peers would wait in a collective until RCCL's timeout
-            break
-        if time.time() > deadline:
-            failed.append(f"no result after {args.launch_timeout:.0f} s")
-            break
-        time.sleep(0.05)
-    for r, p in enumerate(procs):
-        if p.poll() is None:              # still alive after a peer failed / after the deadline: stop exactly this child
-            p.kill()
-            p.wait()
-            failed.append(f"rank {r} stopped")
-        elif p.returncode != 0:
-            failed.append(f"rank {r} rc {p.returncode}")
-    reader.join(timeout=10)
-    out0 = chunks[0] if chunks else ""
-    lines = [l for l in out0.splitlines() if l.strip()]
-    json_lines = [l for l in lines if l.startswith("{")]
-    for l in lines:
-        if not l.startswith("{"):
-            print(l)
-    if failed or len(json_lines) != 1:
-        print(f"bench.py launcher: {n} ranks failed: {failed or 'rank 0 printed no result line'}", file=sys.stderr)
+
+    def attempt(extra_env):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
+        base.setdefault("OMP_NUM_THREADS", "1")
+        procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)) for r in range(n)]
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline, failed = time.time() + args.launch_timeout, []
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):      # a rank died: its peers would wait in a collective until RCCL's timeout
+                break
+            if time.time() > deadline:
+                failed.append(f"no result after {args.launch_timeout:.0f} s")
+                break
+            time.sleep(0.05)
+        for r, p in enumerate(procs):
+            if p.poll() is None:              # still alive after a peer failed / after the deadline: stop exactly this child
+                p.kill()
+                p.wait()
+                failed.append(f"rank {r} stopped")
+            elif p.returncode != 0:
+                failed.append(f"rank {r} rc {p.returncode}")
+        reader.join(timeout=10)
+        lines = [l for l in (chunks[0] if chunks else "").splitlines() if l.strip()]
+        json_lines = [l for l in lines if l.startswith("{")]
+        if not failed and len(json_lines) != 1:
+            failed.append("rank 0 printed no result line")
+        return failed, [l for l in lines if not l.startswith("{")], (json_lines[-1] if json_lines else None)
+
+    failed, chatter, line = attempt({})
+    note = None
+    if failed and args.backend == "nccl" and os.environ.get("PCRL_CAPTURE_EXCHANGE", "1") != "0":
+        print(f"bench.py launcher: {n} ranks failed with captured all-reduces ({failed}); once more with PCRL_CAPTURE_EXCHANGE=0", file=sys.stderr)
+        note = f"first attempt (all-reduces captured in the step's hipGraph) failed: {failed}; this line is the PCRL_CAPTURE_EXCHANGE=0 run"
+        failed, chatter, line = attempt({"PCRL_CAPTURE_EXCHANGE": "0"})
+    for l in chatter:
+        print(l)
+    if failed:
+        print(f"bench.py launcher: {n} ranks failed: {failed}", file=sys.stderr)
         return 1
-    print(json_lines[0], flush=True)
+    if note:
+        d = json.loads(line)
+        d["launcher_note"] = note
+        line = json.dumps(d)
+    print(line, flush=True)
     return 0
 
 

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from .. import hip
 from ..augmentations import build_data_augmentations
 from ..networks import build_actor_critic, build_target_network
-from ..utils.dist import Exchange, allreduce_sum_, capture_exchange, exchange_active, world_size
+from ..utils.dist import Exchange, allreduce_sum_, capture_exchange, exchange_active, quiesce_before_capture, world_size
 from ..utils.torch_utils import BaseAgent, build_optimizer, regex_match, select_optimizer_params, soft_update
 from .builder import MFRL
 
@@ -560,6 +560,7 @@ class SAC(BaseAgent):
                 assert self._aliases_static(staged), "captured sampling must write the tensors the captured step reads"
             pre = (lambda: sampler.launch_sample(self.batch_size)) if sampler is not None else None
             torch.cuda.synchronize()
+            quiesce_before_capture()               # RCCL's watchdog must have no eager work left to poll while this thread captures
             self._graph_sampler[key] = sampler
             captured = None
             if not exchanging:
@@ -673,6 +674,8 @@ class SAC(BaseAgent):
         ex = Exchange()
         kind = None
         while names is None:
+            ex.finish()
+            quiesce_before_capture()               # the previous segment's eager all-reduces are still on the watchdog's list
             graph = torch.cuda.CUDAGraph()
             exchange = ("finish", [])
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures

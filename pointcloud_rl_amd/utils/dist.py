@@ -37,6 +37,20 @@ def capture_exchange():
     return str(dist.get_backend()).lower() == "nccl"
 
 
+def quiesce_before_capture():
+    """Call before a stream capture in a process whose RCCL process group has issued eager collectives.  torch's
+    ProcessGroupNCCL watchdog thread polls the completion events of eager work with hipEventQuery, and on ROCm an event query
+    from another thread while this thread captures fails with hipErrorStreamCaptureUnsupported -- the watchdog rethrows and the
+    process aborts (seen with eager all-reduces between per-segment captures).  Finished work leaves the watchdog's list on its
+    next poll (every 100 ms): drain the device, then give it three polls."""
+    if not (dist.is_available() and dist.is_initialized()) or str(dist.get_backend()).lower() != "nccl":
+        return
+    import time
+    import torch
+    torch.cuda.synchronize()
+    time.sleep(0.35)
+
+
 def allreduce_sum_(flat_grad, enabled=True):
     """In-place SUM all-reduce of a flat gradient buffer.  Returns the scale (1/world) the caller must
     apply to obtain the mean, 1.0 when nothing was exchanged."""
