@@ -55,12 +55,88 @@ def pointnet_prepool(P, obs, prefix=ENC, ln_eps=1e-6):
     return x
 
 
-def pointnet_forward(P, obs, prefix=ENC, ln_eps=1e-6):
-    """PointNet.forward (pointnet.py:148-153): shared MLP, max over points, Linear + LayerNorm(eps=1e-5)."""
-    feat = pointnet_prepool(P, obs, prefix, ln_eps).max(-1)[0]
+def pointnet_forward(P, obs, prefix=ENC, ln_eps=1e-6, route=None, keep=None):
+    """PointNet.forward (pointnet.py:148-153): shared MLP, max over points, Linear + LayerNorm(eps=1e-5).
+
+    route (tests only): int64 [B, c3] -- the point each (cloud, channel) sends its value and gradient through, instead of
+    torch's own argmax (two points whose fp32 values differ by an ulp are ordered by the summation order; the caller checks
+    that the routed point holds the maximum to rounding).  keep (tests only): dict that receives the pooled tensor
+    (`retain_grad`: its .grad after backward is dL/dpooled) and the observation, for encoder_cloud_grads below."""
+    pre = pointnet_prepool(P, obs, prefix, ln_eps)
+    feat = pre.max(-1)[0] if route is None else pre.gather(-1, route[..., None])[..., 0]
+    if keep is not None:
+        feat.retain_grad()
+        keep["pooled"], keep["obs"] = feat, obs
+        with torch.no_grad():       # how far the routing is from torch's own: entries that differ, and the value gap there
+            top, own = pre.max(-1)
+            keep["route_differs"] = int((own != route).sum()) if route is not None else 0
+            keep["route_gap"] = float((top - feat).abs().max())
     f = prefix + "final_mlp."
     feat = F.linear(feat, P[f + "0.weight"], P[f + "0.bias"])
     return F.layer_norm(feat, (feat.shape[-1],), P[f + "1.weight"], P[f + "1.bias"], 1e-5)
+
+
+ENC_TENSORS = ("conv0.weight", "conv0.bias", "conv1.weight", "norm1.weight", "norm1.bias", "conv2.weight", "norm2.weight", "norm2.bias")
+
+
+class CloudEncoder:
+    """One cloud's part of the encoder gradient, restricted to the points that receive gradient (tests only).
+
+    The max-pool hands dL/dpooled[c] to ONE point per channel, so a cloud's contribution to the gradient of the eight
+    `visual_nn.conv.mlp.*` tensors is a function of its <= c3 routed points.  This class evaluates that function with the
+    ReLU branch decisions as explicit 0/1 masks (h = pre-activation * mask): with the restatement's own decisions it
+    reproduces the cloud's share of `backward()`; with ONE decision flipped it gives the gradient another fp32
+    implementation produces when its summation order puts that pre-activation -- which must be rounding-sized -- on the
+    other side of zero.  tests/test_fullsize_parity_gpu.py uses the difference to locate such events."""
+
+    def __init__(self, P, obs_b, route_b, gpool_b, prefix=ENC, ln_eps=1e-6):
+        c = prefix + "conv.mlp."
+        self.W = {n: P[c + n].detach().clone().requires_grad_(True) for n in ENC_TENSORS}
+        self.eps, self.gpool = ln_eps, gpool_b
+        pts, self.slot = torch.unique(route_b, return_inverse=True)            # active points (ascending), slot of every channel
+        self.points = pts
+        self.x = preprocess({k: v[None, :, pts] for k, v in obs_b.items()})     # [1, C, n_act]
+        with torch.no_grad():
+            z0, y1, y2 = self._pre(None, None)
+        self.z0, self.y1 = z0[0], y1[0]                                       # [c1, n_act], [c2, n_act]
+        self.y2 = y2[0].gather(-1, self.slot[:, None])[:, 0]                  # [c3]: the routed entry of every channel
+        self.base = (self.z0 > 0, self.y1 > 0, self.y2 > 0)
+
+    def _pre(self, m0, m1):
+        W = self.W
+        z0 = F.conv1d(self.x, W["conv0.weight"], W["conv0.bias"])
+        h0 = F.relu(z0) if m0 is None else z0 * m0[None]
+        y1 = layer_norm_1d(F.conv1d(h0, W["conv1.weight"]), W["norm1.weight"], W["norm1.bias"], self.eps)
+        h1 = F.relu(y1) if m1 is None else y1 * m1[None]
+        y2 = layer_norm_1d(F.conv1d(h1, W["conv2.weight"]), W["norm2.weight"], W["norm2.bias"], self.eps)
+        return z0, y1, y2
+
+    def candidates(self, tau):
+        """[(layer, channel, active-point slot or -1, |pre-activation|)] of the decisions within tau of zero."""
+        out = []
+        for layer, z in ((0, self.z0), (1, self.y1)):
+            for ch, sl in (z.abs() <= tau).nonzero().tolist():
+                out.append((layer, ch, sl, float(z[ch, sl].abs())))
+        for (ch,) in (self.y2.abs() <= tau).nonzero().tolist():
+            out.append((2, ch, -1, float(self.y2[ch].abs())))
+        return out
+
+    def grads(self, flip=None):
+        """{tensor name: gradient} of sum_c gpool[c] * pooled[c] for this cloud; flip = (layer, channel, slot) inverts one
+        decision."""
+        m = [t.clone().float() for t in self.base]
+        if flip is not None:
+            layer, ch, sl = flip
+            if layer == 2:
+                m[2][ch] = 1.0 - m[2][ch]
+            else:
+                m[layer][ch, sl] = 1.0 - m[layer][ch, sl]
+        for w in self.W.values():
+            w.grad = None
+        _, _, y2 = self._pre(m[0], m[1])
+        pooled = y2[0].gather(-1, self.slot[:, None])[:, 0] * m[2]
+        (pooled * self.gpool).sum().backward()
+        return {n: (w.grad.detach().clone() if w.grad is not None else torch.zeros_like(w)) for n, w in self.W.items()}
 
 
 def linear_mlp(P, prefix, x, masks=None, flips=None):
@@ -167,6 +243,9 @@ class RefAgent:
         self.encoder_passes = [0]
         self.last_grads = {}
         self.flips = []          # (count, max |pre-activation|) per masked hidden layer, see linear_mlp
+        self.route = None        # tests only: argmax routing of the gradient-carrying encoder pass (pointnet_forward(route=))
+        self.keep = None         # tests only: dict receiving that pass's pooled tensor / observation
+        self.critic_grad_hook = None   # tests only: called with self after the critic's backward, before its optimizer step
 
     # -- modules ---------------------------------------------------------------------------
     def actor(self, obs, eps, detach_visual=False, masks=None):
@@ -184,7 +263,9 @@ class RefAgent:
             vf = visual_feature
             if vf is None and not self.mirror_redundancy:
                 if shared is None:
-                    shared = pointnet_forward(self.P, {k: v for k, v in obs.items() if k not in ("state", "agent")})
+                    grad_pass = which == "critic" and torch.is_grad_enabled()
+                    shared = pointnet_forward(self.P, {k: v for k, v in obs.items() if k not in ("state", "agent")},
+                                              route=self.route if grad_pass else None, keep=self.keep if grad_pass else None)
                     self.encoder_passes[0] += 1
                 vf = shared
             q, _ = visuomotor(self.P, f"{which}.values.{h}.backbone.final_mlp.mlp.", obs, actions=actions, visual_feature=vf, count=self.encoder_passes,
@@ -260,6 +341,8 @@ class RefAgent:
             abs_err = torch.abs(q - q_target).max().item()
         self.critic_optim.zero_grad()
         critic_loss.backward()
+        if self.critic_grad_hook is not None:
+            self.critic_grad_hook(self)
         self.last_grads = {"critic": {k: P[k].grad.detach().clone() for k in self.critic_names if P[k].grad is not None}}
         self.critic_optim.step()
         critic_grad = self.grad_norm([P[k] for k in self.critic_names])

@@ -1,0 +1,107 @@
+"""BASELINE config 3 (K2) at its FULL launch geometry -- 256 samples x 2 augmentations = 512 clouds of N = 1200 points, C = 7,
+nets [128, 128, 256], bf16 conv1 / conv2 with fp32 accumulation, jitter fused into the load -- through size-independent
+properties (the rounding emulation of tests/test_encoder_{fwd,bwd}_gpu.py is checked on a slice; 512 x 1200 x 256 activations do
+not fit a CPU test):
+  * batch-order invariance: a cloud's result does not depend on which workgroup / wave / tile position computed it;
+  * point-permutation invariance: the pooled VALUES are bitwise those of the permuted cloud, the argmax follows the permutation;
+  * the virtual repeat (row_div) with per-row jitter equals the materialised repeat;
+  * a slice of the launch equals the same clouds launched alone, and that slice is within the emulation's tolerance;
+  * backward at the same geometry: bitwise reproducible, linear in the upstream gradient, equal on a slice to the slice's own
+    launch (per-cloud partial sums are independent) and within 3e-2 of autograd through the emulation there."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_encoder_weights, make_obs
+from test_encoder_bwd_gpu import NAMES, _bf16_reference_grads
+from test_encoder_fwd_gpu import _bf16_reference
+
+pytestmark = pytest.mark.gpu
+
+B, REP, N, C1 = 256, 2, 1200, 128
+
+
+def _setup(cuda):
+    from pointcloud_rl_amd import hip
+    obs_np = make_obs(B, N, seed=77, seg=1)
+    w_np = make_encoder_weights(7, C1, 128, 256, seed=8)
+    w = {k: torch.from_numpy(v).to(cuda) for k, v in w_np.items()}
+    ew, keep = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    noise = torch.empty(B * REP, 3, N, device=cuda).uniform_(-0.01, 0.01, generator=torch.Generator(device=cuda).manual_seed(3))
+    return hip, obs_np, w_np, ew, packed, noise, (keep, w)
+
+
+def _fwd(hip, obs, ew, packed, noise, repeat=1):
+    from pointcloud_rl_amd.networks.pointnet import AugmentedObs
+    o = AugmentedObs(obs)
+    o.repeat = repeat
+    desc, keep = hip.make_cloud_desc(o)
+    aug = hip.make_aug_desc(jitter_noise=noise) if noise is not None else None
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed, aug=aug, bf16=True)
+    return pooled, argmax, desc, aug, keep
+
+
+def test_k2_forward_full_size_properties(cuda):
+    hip, obs_np, w_np, ew, packed, noise, keep_w = _setup(cuda)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    pooled, argmax, *_ = _fwd(hip, obs, ew, packed, noise, repeat=REP)            # the K2 launch: 512 virtual clouds
+    assert pooled.shape == (B * REP, 256) and bool(torch.isfinite(pooled).all())
+    assert int(argmax.min()) >= 0 and int(argmax.max()) < N
+    # the materialised repeat (what the reference does, drq.py:52-60) gives the same bits
+    mat = {k: torch.repeat_interleave(v, REP, dim=0) for k, v in obs.items()}
+    p_mat, a_mat, *_ = _fwd(hip, mat, ew, packed, noise)
+    assert torch.equal(pooled, p_mat) and torch.equal(argmax, a_mat)
+    # batch order: reverse the clouds (every cloud lands on another workgroup / launch position)
+    rev = {k: v.flip(0).contiguous() for k, v in mat.items()}
+    p_rev, a_rev, *_ = _fwd(hip, rev, ew, packed, noise.flip(0).contiguous())
+    assert torch.equal(p_rev.flip(0), pooled) and torch.equal(a_rev.flip(0), argmax)
+    # point permutation: same values bitwise; the reported point is the permuted position of a point holding the maximum
+    perm = torch.from_numpy(np.random.RandomState(4).permutation(N)).to(cuda)
+    per = {k: v[:, :, perm].contiguous() for k, v in mat.items()}
+    p_per, a_per, *_ = _fwd(hip, per, ew, packed, noise[:, :, perm].contiguous())
+    assert torch.equal(p_per, pooled)
+    same_point = perm[a_per.long()] == argmax.long()
+    assert float(same_point.float().mean()) >= 0.999           # exact ties (first index wins) are the only admissible difference
+    # a slice of the launch == the slice launched alone, and the slice is within the rounding emulation's tolerance
+    sel = slice(40, 46)
+    sl = {k: v[sel].contiguous() for k, v in mat.items()}
+    p_sl, a_sl, *_ = _fwd(hip, sl, ew, packed, noise[sel].contiguous())
+    assert torch.equal(p_sl, pooled[sel]) and torch.equal(a_sl, argmax[sel])
+    obs_sl = {k: np.repeat(v, REP, axis=0)[sel] for k, v in obs_np.items()}
+    obs_sl["xyz"] = obs_sl["xyz"] + noise[sel].cpu().numpy()
+    val, idx, h2 = _bf16_reference(obs_sl, w_np)
+    np.testing.assert_allclose(p_sl.cpu().numpy(), val, atol=3e-2, rtol=0)
+    assert (a_sl.cpu().numpy() == idx).mean() >= 0.95
+
+
+def test_k2_backward_full_size_properties(cuda):
+    hip, obs_np, w_np, ew, packed, noise, keep_w = _setup(cuda)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    pooled, argmax, desc, aug, keep = _fwd(hip, obs, ew, packed, noise, repeat=REP)
+    g = torch.Generator(device=cuda).manual_seed(9)
+    g1, g2 = (torch.randn(B * REP, 256, device=cuda, generator=g) for _ in range(2))
+    run = lambda gp: hip.encoder_bwd(desc, ew, packed, argmax, gp, aug=aug, pooled=pooled, bf16=True).clone()
+    a, a_again, b, c = run(g1), run(g1), run(g2), run(g1 + g2)
+    assert torch.equal(a, a_again)                                              # fixed-order reductions: bitwise run to run
+    assert bool(torch.isfinite(a).all())
+    for name, v in hip.encoder_grad_views(c, ew).items():
+        lin = hip.encoder_grad_views(a, ew)[name] + hip.encoder_grad_views(b, ew)[name]
+        assert float((lin - v).abs().max()) <= 1e-4 * float(v.abs().max()), name   # linear in the upstream gradient (fp32 sums of 512 clouds)
+    # a slice: its own launch, against autograd through the rounding emulation
+    sel = slice(100, 104)
+    mat = {k: torch.repeat_interleave(v, REP, dim=0)[sel].contiguous() for k, v in obs.items()}
+    p_sl, a_sl, d_sl, aug_sl, keep_sl = _fwd(hip, mat, ew, packed, noise[sel].contiguous())
+    assert torch.equal(p_sl, pooled[sel]) and torch.equal(a_sl, argmax[sel])
+    flat = hip.encoder_bwd(d_sl, ew, packed, a_sl, g1[sel].contiguous(), aug=aug_sl, pooled=p_sl, bf16=True)
+    got = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
+    obs_sl = {k: np.repeat(v, REP, axis=0)[sel] for k, v in obs_np.items()}
+    obs_sl["xyz"] = obs_sl["xyz"] + noise[sel].cpu().numpy()
+    t, h2 = _bf16_reference_grads(obs_sl, w_np, None)
+    picked = torch.gather(h2, 2, a_sl.cpu().long()[:, :, None])[:, :, 0]
+    (picked * g1[sel].cpu()).sum().backward()
+    for name, k in NAMES.items():
+        r = t[k].grad.numpy().reshape(-1)
+        err = np.abs(got[name].reshape(-1) - r).max() / max(np.abs(r).max(), 1e-6)
+        assert err < 3e-2, f"{name}: {err:.3e}"
