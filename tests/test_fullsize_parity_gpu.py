@@ -108,37 +108,64 @@ def _flat_grads(agent, which):
     return {n: g.detach().cpu().numpy().copy() for n, g in zip(fb.names, fb.views(fb.grad))}
 
 
+EVENT_MIN_SHIFT = 3e-6      # a candidate whose flip moves no gradient entry by more than this (of the tensor's largest) is immaterial
+
+
 def _locate_encoder_events(ref, hip_enc_grads, report):
-    """Called by the restatement between its critic backward and its optimizer step.  hip_enc_grads: {tensor: HIP gradient}."""
+    """Called by the restatement between its critic backward and its optimizer step.  hip_enc_grads: {tensor: HIP gradient}.
+
+    Every near-zero decision of a gradient-carrying point is a candidate with a direction d = (gradient with the decision
+    flipped) - (gradient as is).  Best-first: the candidate whose removal shrinks the residual most is accepted if the residual
+    contains it about once (projection coefficient in [0.5, 1.5] -- a direction that merely correlates with a LARGER event
+    still in the residual has a coefficient far above 1 and is not an event), the residual is updated, and the search repeats
+    until no candidate qualifies."""
     from oracle import torch_ref
     P, keep, route = ref.P, ref.keep, ref.route
     pre = torch_ref.ENC + "conv.mlp."
+    names = torch_ref.ENC_TENSORS
     report["argmax_differs"] += int(keep["route_differs"])
     report["argmax_gap"] = max(report["argmax_gap"], float(keep["route_gap"]))
     gpool, obs = keep["pooled"].grad, keep["obs"]
-    resid = {n: hip_enc_grads[n] - P[pre + n].grad for n in torch_ref.ENC_TENSORS}
-    scale = {n: max(float(P[pre + n].grad.abs().max()), 1e-12) for n in torch_ref.ENC_TENSORS}
+    scale = {n: max(float(P[pre + n].grad.abs().max()), 1e-12) for n in names}
+    flat = lambda d: torch.cat([(d[n] / scale[n]).reshape(-1) for n in names])          # every tensor in units of its largest entry
+    resid = flat({n: hip_enc_grads[n] - P[pre + n].grad for n in names})
+    cands, dirs = [], []
     for b in range(route.shape[0]):
         cloud = torch_ref.CloudEncoder(P, {k: v[b] for k, v in obs.items()}, route[b], gpool[b])
-        cands = cloud.candidates(EVENT_TAU)
-        if not cands:
+        found = cloud.candidates(EVENT_TAU)
+        if not found:
             continue
         base = cloud.grads()
-        for layer, ch, sl, z in cands:
+        for layer, ch, sl, z in found:
             report["encoder_candidates"] += 1
             flipped = cloud.grads(flip=(layer, ch, sl))
-            d = {n: flipped[n] - base[n] for n in torch_ref.ENC_TENSORS}
-            num = sum(float((resid[n] * d[n]).sum()) / scale[n] ** 2 for n in d)
-            den = sum(float((d[n] * d[n]).sum()) / scale[n] ** 2 for n in d)
-            if den > 0 and num / den > 0.5:        # this decision fell the other way in the HIP step
-                report["encoder_events"] += 1
-                report["event_max_preact"] = max(report["event_max_preact"], z)
-                report["events"].append(dict(cloud=b, layer=layer, channel=ch, point=int(cloud.points[sl]) if sl >= 0 else None, preact=z,
-                                             grad_shift_rel_to_max=max(float(d[n].abs().max()) / scale[n] for n in d)))
-                with torch.no_grad():
-                    for n in d:
-                        resid[n] -= d[n]
-                        P[pre + n].grad += d[n]
+            d = {n: flipped[n] - base[n] for n in names}
+            shift = max(float(d[n].abs().max()) / scale[n] for n in names)
+            if shift < EVENT_MIN_SHIFT:
+                continue
+            cands.append(dict(cloud=b, layer=layer, channel=ch, point=int(cloud.points[sl]) if sl >= 0 else None, preact=z,
+                              grad_shift_rel_to_max=shift))
+            dirs.append((flat(d), d))
+    live = list(range(len(cands)))
+    while live:
+        best, best_gain = None, 0.0
+        for i in live:
+            f = dirs[i][0]
+            num, den = float(resid @ f), float(f @ f)
+            coef = num / den
+            if 0.5 <= coef <= 1.5 and 2 * num - den > best_gain:
+                best, best_gain = i, 2 * num - den
+        if best is None:
+            break
+        live.remove(best)
+        f, d = dirs[best]
+        resid = resid - f
+        report["encoder_events"] += 1
+        report["event_max_preact"] = max(report["event_max_preact"], cands[best]["preact"])
+        report["events"].append(cands[best])
+        with torch.no_grad():
+            for n in names:
+                P[pre + n].grad += d[n]
 
 
 @pytest.mark.parametrize("name", list(CASES))

@@ -62,8 +62,10 @@ def test_k2_forward_full_size_properties(cuda):
     per = {k: v[:, :, perm].contiguous() for k, v in mat.items()}
     p_per, a_per, *_ = _fwd(hip, per, ew, packed, noise[:, :, perm].contiguous())
     assert torch.equal(p_per, pooled)
-    same_point = perm[a_per.long()] == argmax.long()
-    assert float(same_point.float().mean()) >= 0.999           # exact ties (first index wins) are the only admissible difference
+    # ... except on exact ties, where the first index wins in either order: ReLU-dead channels (every point 0 -> index 0) and
+    # channels whose maximum is attained by two points
+    same_point = (perm[a_per.long()] == argmax.long()) | (pooled == 0)
+    assert float(same_point.float().mean()) >= 0.999
     # a slice of the launch == the slice launched alone, and the slice is within the rounding emulation's tolerance
     sel = slice(40, 46)
     sl = {k: v[sel].contiguous() for k, v in mat.items()}
