@@ -25,6 +25,7 @@
 //   reduce
 //     fixed-order sum of the per-cloud partials -> one flat gradient buffer.  No float atomics:
 //     results are bit-reproducible run to run.
+#include <algorithm>
 #include "encoder_common.h"
 
 // This file is compiled four times (encoder_bwd_{f32,bf16,split,f32_nw4}.hip define PCRL_BWD_MODE 0 / 1 / 2 / 3): each translation
@@ -88,6 +89,15 @@ struct BwdParams {
     float* n1part;           // [B][8][kC2][2] norm1 (dgamma, dbeta) partial sums per tile
     int tile_mode;           // 1: B < #CUs, work items are single tiles found through a prefix sum of the clouds' tile counts
     int parts;               // kernel B: workgroups per cloud (1, 2, 4 or 8; > 1 only for small batches)
+    // Gram form of the backward (encoder_bwd_gram.h)
+    const float* w2;         // conv2.weight as the optimizer holds it: [C3][C2] row-major
+    unsigned* own;           // [B][kC3] per active slot: first entry of its channels in own_chan (low 16 bits) | their number (high 16)
+    unsigned char* own_chan; // [B][kC3] the channels grouped by the slot of their argmax point, ascending within a slot
+    float4* ptc;             // [B][kC3] per active slot: (a = rstd2^2 m2, rstd2 m1, a mu2, 0) -- coefficients of G, v, u
+    float* chc;              // [B][kC3] per channel: rstd2 dL/dxhat2 at its argmax point (the sparse rows of dW2)
+    float* gvu;              // [C2*C2 + 2*C2] sums over the clouds of G, v, u
+    float* mimg;             // [C2*C2 + C2] M = W2^T W2 in A-operand order, then s = W2^T 1 (built by the prep launch)
+    int pw_stride;           // floats per cloud in pw (GradLayout.total() [+ C2*C2 + 2*C2 in the Gram form])
 };
 
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
@@ -201,7 +211,7 @@ __device__ __forceinline__ void bwd_prep_cloud(const BwdParams& p, int b, int ti
     const bool use_pooled = have_pooled && s_flag == 0;
     if (tid_all == 0) { p.n_act[b] = n_act; p.flag[b] = use_pooled ? 1 : 0; }
     if (use_pooled && chan) {
-        float* pw = p.pw + (long long)b * GL.total();
+        float* pw = p.pw + (long long)b * p.pw_stride;
         pw[GL.g2() + tid] = dyl * xh;                               // norm2.weight / norm2.bias gradients of this cloud
         pw[GL.be2() + tid] = dyl;
         if (tid < n_act) {
@@ -374,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
         }
         __syncthreads();
 
-        float* pw = p.pw + (long long)b * GL.total();
+        float* pw = p.pw + (long long)b * p.pw_stride;
         const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(p.ops + (long long)b * OL.total(), 4u * (unsigned)OL.total());
         const __amdgpu_buffer_rsrc_t r_xs = make_rsrc(p.xs + (long long)b * kXsFloats, 4u * (unsigned)kXsFloats);
         if (32 * wave < n_act) {
@@ -704,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
         n_act = __builtin_amdgcn_readfirstlane(n_act);
         const float* g_row = p.gpool + (long long)b * kC3;
 
-        float* pw = p.pw + (long long)b * GL.total();
+        float* pw = p.pw + (long long)b * p.pw_stride;
         const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(p.ops + (long long)b * OL.total(), 4u * (unsigned)OL.total());
         const __amdgpu_buffer_rsrc_t r_xs = make_rsrc(p.xs + (long long)b * kXsFloats, 4u * (unsigned)kXsFloats);
         {
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
 // out[32 x 32 block (mb, nb)] = sum over slots of A[32mb + i][slot] * Bm[32nb + j][slot]
 // b_block_stride: distance between two column blocks of the B operand in 16-byte units (32 * 64 in the global workspace,
 // n_oct * 64 in the compact LDS copy).
-template <int NB, class BPtr>
+template <int NB, class BPtr, int D = 3>
 __device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, BPtr b4_base, int b_block_stride, int mb, int nb0,
                                              int n_oct, int lane, f32x16 (&acc)[NB]) {
 #pragma unroll
@@ -952,7 +962,6 @@ __device__ __forceinline__ void wgrad_blocks(const float* __restrict__ A, BPtr b
     const auto b4 = b4_base + lane;
     // the operands of octets q + 1 .. q + D are in flight while the 4 * NB MFMAs of octet q issue: an L2 round trip is longer
     // than one octet's MFMAs (16 x 64 cycles), so a single octet of look-ahead left the matrix pipe waiting every iteration
-    constexpr int D = 3;
     f32x4 ar[D], br[D][NB];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_wgrad_kernel(const BwdPara
     for (int item = blockIdx.x; item < p.cl.B * P; item += gridDim.x) {
         const int b = item / P, part = item - b * P;
         const float* ops = p.ops + (long long)b * OL.total();
-        float* pw = p.pw + (long long)b * GL.total();
+        float* pw = p.pw + (long long)b * p.pw_stride;
         const int n_tiles = (p.n_act[b] + 31) / 32, n_oct = n_tiles * 4;
         if (p.tile_mode && part == 0 && tid < 2 * kC2) {   // norm1 gradients: fixed-order sum over the cloud's tiles (one partial per tile)
             const float* n1 = p.n1part + (long long)b * 8 * kC2 * 2;
@@ -1206,6 +1215,8 @@ int encoder_bwd_points_nw4_f32(int T0, int c1, int c2, int c3, const BwdParams& 
 #undef PCRL_BWD_CASE
     return rc;
 }
+#elif PCRL_BWD_MODE == 4
+// Mode 4 = encoder_bwd_gram_f32.hip: only the declarations above; the Gram-form kernels follow in encoder_bwd_gram.h.
 #else
 // The kernels of this unit's mode for every supported shape.
 int PCRL_BWD_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, int grid, hipStream_t st) {
@@ -1228,6 +1239,7 @@ int encoder_bwd_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p,
 }  // namespace pcrl
 
 #if PCRL_BWD_MODE == 0
+#include "encoder_bwd_gram.h"
 using namespace pcrl;
 
 extern "C" int pcrl_encoder_num_grads(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* n) {
@@ -1242,7 +1254,7 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     size_t dummy;
     if (int rc = pcrl_encoder_packed_bytes(c_in, c1, c2, c3, &dummy)) return rc;
     if (!bytes || B < 0) return fail(PCRL_E_ARG, "bad arguments");
-    *bytes = bwd_workspace(B, c_in, c1, c2, c3).total;
+    *bytes = std::max(bwd_workspace(B, c_in, c1, c2, c3).total, bwdg_workspace(B, c_in, c1, c2, c3).total);
     return PCRL_OK;
 }
 
@@ -1263,9 +1275,42 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         return PCRL_OK;
     }
     const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
-    if (!workspace || workspace_bytes < ws.total) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws.total);
+    const BwdgWorkspace wg = bwdg_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
+    const size_t ws_need = std::max(ws.total, wg.total);
+    if (!workspace || workspace_bytes < ws_need) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws_need);
     char* base = static_cast<char*>(workspace);
     p.eps = w->eps; p.packed = static_cast<const float*>(packed); p.argmax = argmax; p.gpool = grad_pooled; p.pooled = pooled;
+    p.grads = grads;
+    p.pw_stride = GL.total();
+    if (p.cl.N > 32 * kBitmapMaxWords) return fail(PCRL_E_ARG, "encoder backward: N = %d > %d points per cloud", p.cl.N, 32 * kBitmapMaxWords);
+    {
+        // Gram form (encoder_bwd_gram.h): fp32 and split-precision arithmetic, every batch the tile list covers, when the forward's
+        // pooled values are given (the agents always pass them).  The bf16 mode and PCRL_BWD_ALGO=0 keep the round-2 kernels.
+        static const int algo = [] { const char* e = getenv("PCRL_BWD_ALGO"); return e ? atoi(e) : 1; }();
+        if (mode != 1 && algo != 0 && p.cl.B <= kMaxTileModeClouds && w->w2 && pooled) {
+            p.ops = reinterpret_cast<float*>(base + wg.ops); p.xs = reinterpret_cast<float*>(base + wg.xs);
+            p.pw = reinterpret_cast<float*>(base + wg.pw); p.n_act = reinterpret_cast<int*>(base + wg.nact);
+            p.flag = reinterpret_cast<int*>(base + wg.flag); p.act = reinterpret_cast<int*>(base + wg.act);
+            p.slot = reinterpret_cast<unsigned char*>(base + wg.slot); p.own = reinterpret_cast<unsigned*>(base + wg.own);
+            p.own_chan = reinterpret_cast<unsigned char*>(base + wg.own_chan); p.ptc = reinterpret_cast<float4*>(base + wg.ptc);
+            p.chc = reinterpret_cast<float*>(base + wg.chc); p.n1part = reinterpret_cast<float*>(base + wg.n1part);
+            p.gvu = reinterpret_cast<float*>(base + wg.gvu); p.mimg = reinterpret_cast<float*>(base + wg.mimg);
+            p.w2 = w->w2;
+            p.pw_stride = GL.total() + GramExtra{w->c2}.total();
+            p.tile_mode = 1;
+            p.parts = 1;
+            while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;
+            static const int nw_forced = [] { const char* e = getenv("PCRL_BWD_TILE_WAVES"); return e ? atoi(e) : 0; }();
+            const int nw = nw_forced ? nw_forced : ((long long)p.cl.B * (w->c3 / 32) <= 4ll * num_cus() ? 4 : 8);
+            const int T0g = (p.cl.C + 1) / 2;
+            const int rcg = mode == 2 ? encoder_bwdg_launch_split(T0g, w->c1, w->c2, w->c3, p, nw, st)
+                                      : encoder_bwdg_launch_f32(T0g, w->c1, w->c2, w->c3, p, nw, st);
+            if (rcg == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
+            if (rcg) return rcg;
+            if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
+            return PCRL_OK;
+        }
+    }
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);
     p.flag = reinterpret_cast<int*>(base + ws.flag); p.act = reinterpret_cast<int*>(base + ws.act);

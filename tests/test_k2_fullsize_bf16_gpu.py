@@ -90,7 +90,9 @@ def test_k2_backward_full_size_properties(cuda):
     assert bool(torch.isfinite(a).all())
     for name, v in hip.encoder_grad_views(c, ew).items():
         lin = hip.encoder_grad_views(a, ew)[name] + hip.encoder_grad_views(b, ew)[name]
-        assert float((lin - v).abs().max()) <= 1e-4 * float(v.abs().max()), name   # linear in the upstream gradient (fp32 sums of 512 clouds)
+        # linear in the upstream gradient up to the bf16 roundings inside the data-gradient GEMMs (the round-2 kernels round the
+        # upstream gradient as it enters W2^T dz2; the Gram form has no such rounding and is linear to fp32 accuracy)
+        assert float((lin - v).abs().max()) <= 2e-2 * float(v.abs().max()), name
     # a slice: its own launch, against autograd through the rounding emulation
     sel = slice(100, 104)
     mat = {k: torch.repeat_interleave(v, REP, dim=0)[sel].contiguous() for k, v in obs.items()}
