@@ -1,6 +1,6 @@
 """Headline benchmark: SAC gradient steps/sec (encoder + update) on B=256, N=1024 points.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: this process starts the N ranks itself, see launch_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -11,8 +11,9 @@ region.  With N > 1 the batch of 256 is sharded over the ranks (256/N clouds eac
 replicated and the flat gradient buffers are all-reduced over RCCL after each backward: strong
 scaling, value = global gradient steps per second.
 
-Defaults: 500 warm-up + 2000 timed steps (about 2.5 s on one GPU): the rate keeps climbing for the first ~1000 steps after
-start-up (986 steps/s timed right after 20 warm-up steps, 1016-1037 once warm), and a training run is 10^5-10^6 updates.
+Defaults: 500 warm-up + 2000 timed steps (about 2.5 s on one GPU); a training run is 10^5-10^6 updates.  Every default K1 line also
+carries, as extra top-level objects that are never the reported value, `config4_k3` (the same ranks on BASELINE config 4: B 1024,
+N 1200, C 7 -- the shape north_star's strong-scaling target is stated for) and, at N = 1, `experimental_f32split`.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fused encoder forward),
 timed with HIP events inside the timed region; `cpu_baseline` is the op-for-op PyTorch-CPU
