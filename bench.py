@@ -86,7 +86,7 @@ def parse():
                     "shape north_star's strong-scaling target is stated for) that every default k1 line carries as `config4_k3`")
     ap.add_argument("--extra-steps", type=int, default=100)
     ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
     return ap.parse_args()
 
 
@@ -251,6 +251,7 @@ def launch_ranks(args):
         base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                     HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
         base.setdefault("OMP_NUM_THREADS", "1")
+        base.setdefault("PCRL_STEP_TIMEOUT_S", "90")          # a step that publishes no metrics for 90 s ends its rank (and so the attempt)
         procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)) for r in range(n)]
         chunks = []
@@ -550,4 +551,14 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # a rank that failed must END (its peers wait for it in a collective, the launcher watches exit codes): no interpreter /
+        # process-group teardown that could itself wait for a wedged stream
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -173,10 +173,13 @@ int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t c1, int32_
  * at most c3 points per cloud (argmax), so only those points are recomputed and back-propagated.
  * `clouds`/`aug` must describe the same inputs (and the same noise) as the forward call that
  * produced `argmax`.  grads [pcrl_encoder_num_grads] f32 is overwritten; n_active [B] int32 (optional)
- * receives the number of distinct argmax points per cloud.  Deterministic (no float atomics).
- * pooled [B, c3] (optional, may be NULL): the forward's output for the same inputs.  With it the LayerNorm-2 / max-pool
- * backward sums are formed per channel from pooled (y at the argmax point; xhat = (y - beta) / gamma) instead of by searching
- * every point's registers for the channels it owns -- same gradients to ~1e-7 relative, about 8 % less kernel time. */
+ * receives the number of points per cloud that received gradient.  Deterministic (no float atomics).
+ * pooled [B, c3] (optional, may be NULL): the forward's output for the same inputs.  With it (and for batches of up to 2 048
+ * clouds) the backward runs in Gram form (csrc/encoder_bwd_gram.h): the forward's own values decide each channel's ReLU, channels
+ * the forward left at zero are dropped up front (n_active then counts the distinct argmax points of the remaining channels),
+ * and the last layer's recompute and W2^T dz2 GEMM are replaced by one C2 -> C2 layer with M = W2^T W2 -- same gradients to
+ * ~5e-7 of each tensor's largest entry, 25-35 % less time.  Without it the round-2 kernels run (n_active = all distinct argmax
+ * points).  The f32split entry point takes the same path; the bf16 one always runs the round-2 kernels. */
 int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
                          const int32_t* argmax, const float* grad_pooled, const float* pooled,

@@ -633,10 +633,10 @@ class SAC(BaseAgent):
                 import time
                 t0 = t0 or time.monotonic()
                 if time.monotonic() - t0 > float(os.environ.get("PCRL_STEP_TIMEOUT_S", "120")):
-                    # a hung kernel or a collective whose peer is gone: hand over to a blocking synchronisation, which the
-                    # process group's watchdog / the driver's timeout can see, instead of spinning forever
-                    torch.cuda.synchronize()
-                    raise RuntimeError("update step did not publish its metrics within PCRL_STEP_TIMEOUT_S")
+                    # a hung kernel or a collective whose peer is gone: stop spinning and say so (no synchronisation here: it would
+                    # block on the same wedged stream)
+                    raise RuntimeError("update step did not publish its metrics within PCRL_STEP_TIMEOUT_S "
+                                       f"({os.environ.get('PCRL_STEP_TIMEOUT_S', '120')} s): a kernel hangs or a peer of a collective is gone")
         return slots.view(np.float32).tolist()
 
     def _capture_whole(self, batch, do_actor, polyak, pre=None, exchanging=False):

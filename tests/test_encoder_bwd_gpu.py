@@ -187,6 +187,28 @@ def test_bwd_zero_gamma_falls_back_to_the_dense_path(cuda):
     assert_grads_close(got, ref)
 
 
+def test_bwd_cloud_whose_channels_are_all_dead(cuda):
+    """norm2.bias far below zero on every channel: the forward leaves every channel at zero (argmax = point 0, torch's first index),
+    no point receives gradient -- every gradient is exactly zero, n_active = 0 -- and a batch that mixes such a cloud (a cloud of
+    identical points has zero variance, LayerNorm outputs = beta) with ordinary ones still matches autograd."""
+    obs = make_obs(3, 90, seed=51)
+    w = make_encoder_weights(6, 64, 128, 256, seed=8)
+    w_dead = dict(w, be2=np.full(256, -10.0, np.float32))
+    gpool = np.random.RandomState(7).randn(3, 256).astype(np.float32)
+    got, idx, pooled, n_act = hip_grads(obs, w_dead, gpool, cuda)
+    assert (pooled == 0).all() and (idx == 0).all() and (n_act == 0).all()
+    for name, g in got.items():
+        assert np.isfinite(g).all() and (g == 0).all(), name
+    # one degenerate cloud among ordinary ones: all its points identical -> xhat = 0 everywhere -> y = beta per channel
+    obs2 = {k: v.copy() for k, v in obs.items()}
+    for k in obs2:
+        obs2[k][1] = obs2[k][1][:, :1]
+    ref, idx_ref, _ = torch_reference_grads(obs2, w, gpool)
+    got2, idx2, _, _ = hip_grads(obs2, w, gpool, cuda)
+    assert np.array_equal(idx2, idx_ref) and (idx2[1] == 0).all()
+    assert_grads_close(got2, ref)
+
+
 def test_bwd_small_gamma_large_beta_stays_accurate(cuda):
     """norm2 with |beta| >> |gamma| (xhat = (y - beta) / gamma would lose its digits by cancellation) and with tiny gamma:
     the per-channel shortcut must not be taken; gradients still match autograd at the usual tolerance."""
