@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void encoder_bwdg_prep_kernel(const BwdParams 
                 p.chc[(long long)b * kC3 + tid] = 0.0f;
             }
         }
-        if (tid == 0) { p.n_act[b] = n_act; p.flag[b] = 1; }
+        if (tid == 0) p.n_act[b] = n_act;
         __syncthreads();
         // thread = slot: the channels that name it (256-bit membership mask from a branch-free sweep over the slot bytes), their
         // number, an exclusive scan of the numbers over the slots, and the channels written out in ascending order
@@ -242,8 +242,11 @@ __device__ unsigned long long g_bwdg_wstamps[4096][8];
 // W1^T dz1 GEMM use that mode's MFMA chains exactly as encoder_bwd_impl.h does; conv2 is fp32-accurate in either mode, so the
 // algebra above applies unchanged.  (The mixed-precision bf16 mode keeps the round-2 kernels: with conv2 and W2^T dz2 on the bf16
 // matrix cores they cost less than this form's fp32 M h1 -- measured 157 vs 163 us at B = 256.)
-template <int T0, int C1, int kC2, int kC3, bool SPLIT, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const BwdParams p) {
+// Four waves per workgroup = one per SIMD (512 registers each: nothing spills and xhat1 stays in registers).
+constexpr int kBwdgWaves = 4;
+template <int T0, int C1, int kC2, int kC3, bool SPLIT>
+__global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel(const BwdParams p) {
+    constexpr int NW = kBwdgWaves;
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32;
     constexpr OpsLayoutG OL{C1 / 32, kC2 / 32};
@@ -302,7 +305,6 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const B
         const float* g_row = p.gpool + (long long)b * kC3;
         float* pw = p.pw + (long long)b * p.pw_stride;
         const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(p.ops + (long long)b * OL.total(), 4u * (unsigned)OL.total());
-        const __amdgpu_buffer_rsrc_t r_xs = make_rsrc(p.xs + (long long)b * kXsFloats, 4u * (unsigned)kXsFloats);
 
         const int s = 32 * tile + l31;
         const bool valid = s < n_act;
@@ -310,7 +312,6 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const B
         const unsigned own_w = valid ? p.own[(long long)b * kC3 + s] : 0u;
         // lane-dependent byte offset of an operand element: octet q = s >> 3, k-lane (s >> 2) & 1, k-slot s & 3
         const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
-        const unsigned xs_off = 4u * (unsigned)(tile * 64 * 64 + lane);
 
         PCRL_GSTAMP(0);
         const f32x16 x = load_point<T0>(p.cl, s_desc, b, pidx);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const B
             }
         }
         PCRL_GSTAMP(1);
-        // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
+        // ---- conv1 + LN: xhat1 and h1 stay in registers ---------------------------------------
         f32x16 a1[MB2];
         if (SPLIT)      // the split-precision forward's arithmetic: the recompute is bit-identical to that forward
             dense_layer_split<MB2, C1 / 16>(
@@ -361,8 +362,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const B
             for (int r = 0; r < 16; ++r) gbv[r] = reinterpret_cast<const float2*>(s_ln1)[acc_chan(mb * 16 + r, 0) + 4 * half];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (NW == 4) xh1[mb][r] = a1[mb][r];          // one wave per SIMD: 512 registers, xhat1 stays
-                else buf_store_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64), a1[mb][r]);
+                xh1[mb][r] = a1[mb][r];                       // xhat1 stays in registers for LayerNorm-1's backward
                 a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
                 buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
             }
@@ -458,12 +458,6 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwdg_points_kernel(const B
         PCRL_GSTAMP(6);
         // ---- ReLU + LN1 backward (as in encoder_bwd_impl.h) ------------------------------------------------------------------
         float s1 = 0.0f, s2 = 0.0f, lo, hi;
-        if (NW != 4) {
-#pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)           // all reloads of xhat1 in flight at once
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xh1[mb][r] = buf_load_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64));
-        }
 #pragma unroll
         for (int mb = 0; mb < MB2; ++mb) {
             float2 gbv[16]; float tg[16], tb[16];
@@ -615,6 +609,7 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
         float* s_r2 = reinterpret_cast<float*>(s_u4 + 2 * n_oct);      // [8 n_oct] rstd2 of every slot
         float* s_co = s_r2 + 8 * n_oct;                                // [kC3] the channel's row scale (without rstd2), then with it
         int* s_sl = reinterpret_cast<int*>(s_co + kC3);                // [kC3] the channel's slot
+        int* s_cnt = s_sl + kC3;                                       // ticket counter of the LDS-only chunks (v / u, S rows)
         {
             const f32x4* h1g = reinterpret_cast<const f32x4*>(ops + OL.h1());
             const int per_blk = n_oct * 64;            // <= 2048 = 4 x 512
@@ -641,6 +636,7 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
                 s_co[tid] = p.chc[(long long)b * kC3 + tid];
                 s_sl[tid] = (int)p.slot[(long long)b * kC3 + tid];
             }
+            if (tid == 0) *s_cnt = 0;
         }
         __syncthreads();
         if (tid < kC3) {       // the factor rstd2 of the channel's point, left out by the points kernel: row scale and norm2.weight
@@ -653,6 +649,7 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
                 pw[GL.g2() + tid] = raw != 0.0f ? raw * r2 : 0.0f;
             }
         }
+        __syncthreads();       // the scaled row coefficients are read by whichever wave takes the channel's S chunk
         PCRL_WSTAMP(1);
         // MFMA tasks, dealt kind by kind over the 8 P waves of the cloud's P workgroups so that every wave gets its share of each
         // kind (at the K1 shape: one dW1 block, one pair of G blocks, a dW0 block for two of them) instead of whole rounds of one kind:
@@ -678,33 +675,44 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
         PCRL_WSTAMP(3);
         for (int t = g0; t < nW0; t += G8) wgrad_conv0_pipelined(p, ops, pw, GL, OL.dz0(), OL.xb(), t, n_oct, lane);
         PCRL_WSTAMP(4);
-        // sparse rows of dW2: S[c][j] = (rstd2 dx)_c h1[slot(c)][j], everything from LDS; 512 / C2 channels per pass
-        __syncthreads();
+        // What needs only the LDS copy -- v, u (2 C2 dot products over the active slots; as MFMA blocks they cost C2 / 32 blocks for two
+        // useful rows) and the sparse rows of dW2, S[c][j] = (rstd2 dx)_c h1[slot(c)][j] -- is cut into 1 024-element chunks that the
+        // waves draw from a ticket counter as they finish their MFMA blocks: the waves with the lighter block lists (no dW0 block,
+        // LDS-fed blocks only) absorb them instead of waiting at a barrier for the others.  A chunk's result does not depend on
+        // who computes it.
         PCRL_WSTAMP(5);
-        if (part == P - 1 && tid < 2 * kC2) {
-            // v[j] = sum_slots (rstd2 m1)_slot h1[j][slot], u[j] = sum_slots (a mu)_slot h1[j][slot]: 2 C2 dot products over the active
-            // slots, straight from the LDS copy (as MFMA blocks they cost C2 / 32 blocks for two useful rows)
-            const int j = tid % kC2, which = tid / kC2;
-            const f32x4* hj = s_h1 + (j >> 5) * n_oct * 64 + (j & 31);
-            const f32x4* co = which ? s_u4 : s_v4;
-            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
-            for (int q2 = 0; q2 < 2 * n_oct; ++q2)         // (octet, k-lane) pairs in slot order
-                acc4 = __builtin_elementwise_fma(hj[(q2 >> 1) * 64 + 32 * (q2 & 1)], co[q2], acc4);
-            px[(which ? GX.u() : GX.v()) + j] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-        }
         {
-            constexpr int CPB = 512 / kC2;
+            constexpr int CH_ROWS = 1024 / kC2;                              // channels per S chunk
+            const int n_vu = part == P - 1 ? (2 * kC2 + 63) / 64 : 0, n_s = (kC3 / P) / CH_ROWS;
             const float* s_h1f = reinterpret_cast<const float*>(s_h1);
-            const int j = tid % kC2, cofs = tid / kC2;
-            const int jbase = ((j >> 5) * n_oct * 64 + (j & 31)) * 4;
+            for (;;) {
+                int ticket = 0;
+                if (lane == 0) ticket = atomicAdd(s_cnt, 1);
+                ticket = __builtin_amdgcn_readfirstlane(ticket);
+                if (ticket >= n_vu + n_s) break;
+                if (ticket < n_vu) {
+                    const int d = ticket * 64 + lane;                         // dot product d: j = d % C2 of v (d < C2) or u
+                    if (d < 2 * kC2) {
+                        const int j = d % kC2, which = d / kC2;
+                        const f32x4* hj = s_h1 + (j >> 5) * n_oct * 64 + (j & 31);
+                        const f32x4* co = which ? s_u4 : s_v4;
+                        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+                        for (int q2 = 0; q2 < 2 * n_oct; ++q2)         // (octet, k-lane) pairs in slot order
+                            acc4 = __builtin_elementwise_fma(hj[(q2 >> 1) * 64 + 32 * (q2 & 1)], co[q2], acc4);
+                        px[(which ? GX.u() : GX.v()) + j] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                    }
+                } else {
+                    const int c_base = part * (kC3 / P) + (ticket - n_vu) * CH_ROWS;
 #pragma unroll 4
-            for (int c0 = part * CPB; c0 < kC3; c0 += CPB * P) {
-                const int c = c0 + cofs;
-                const float co = s_co[c];
-                const int sl = s_sl[c];
-                // piece element of (channel j, slot sl): block j >> 5, octet sl >> 3, lane (j & 31) + 32 ((sl >> 2) & 1), k-slot sl & 3
-                const float h = s_h1f[jbase + ((sl >> 3) * 64 + 32 * ((sl >> 2) & 1)) * 4 + (sl & 3)];
-                pw[GL.w2() + c * kC2 + j] = co != 0.0f ? co * h : 0.0f;
+                    for (int e = 0; e < 16; ++e) {
+                        const int flat = e * 64 + lane, c = c_base + flat / kC2, j = flat % kC2;
+                        const float co = s_co[c];
+                        const int sl = s_sl[c];
+                        // piece element of (channel j, slot sl): block j >> 5, octet sl >> 3, lane (j & 31) + 32 ((sl >> 2) & 1), k-slot sl & 3
+                        const float h = s_h1f[(((j >> 5) * n_oct + (sl >> 3)) * 64 + (j & 31) + 32 * ((sl >> 2) & 1)) * 4 + (sl & 3)];
+                        pw[GL.w2() + c * kC2 + j] = co != 0.0f ? co * h : 0.0f;
+                    }
+                }
             }
         }
         PCRL_WSTAMP(6);
@@ -777,7 +785,7 @@ static size_t bwdg_lds_bytes_points(int T0, int C1, int kC2, int kC3) {
 }
 
 struct BwdgWorkspace {
-    size_t ops, xs, pw, nact, flag, act, slot, own, own_chan, ptc, chc, n1part, gvu, mimg, total;
+    size_t ops, pw, nact, act, slot, own, own_chan, ptc, chc, n1part, gvu, mimg, total;
 };
 static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     const OpsLayoutG OL{C1 / 32, kC2 / 32};
@@ -786,11 +794,9 @@ static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     BwdgWorkspace w;
     w.ops = 0;
-    w.xs = al(w.ops + sizeof(float) * (size_t)B * OL.total());
-    w.pw = al(w.xs + sizeof(float) * (size_t)B * kXsFloats);
+    w.pw = al(w.ops + sizeof(float) * (size_t)B * OL.total());
     w.nact = al(w.pw + sizeof(float) * (size_t)B * (GL.total() + GX.total()));
-    w.flag = al(w.nact + sizeof(int) * (size_t)B);
-    w.act = al(w.flag + sizeof(int) * (size_t)B);
+    w.act = al(w.nact + sizeof(int) * (size_t)B);
     w.slot = al(w.act + sizeof(int) * (size_t)B * kC3);
     w.own = al(w.slot + (size_t)B * kC3);
     w.own_chan = al(w.own + sizeof(unsigned) * (size_t)B * kC3);
@@ -803,8 +809,8 @@ static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     return w;
 }
 
-int encoder_bwdg_launch_f32(int T0, int c1, int c2, int c3, const BwdParams& p, int nw, hipStream_t st);
-int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p, int nw, hipStream_t st);
+int encoder_bwdg_launch_f32(int T0, int c1, int c2, int c3, const BwdParams& p, hipStream_t st);
+int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p, hipStream_t st);
 
 #if PCRL_BWD_MODE == 4
 // PCRL_BWDG_SYNC=1 (development): synchronise after every launch so that a faulting kernel is named.
@@ -820,7 +826,7 @@ int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p
     } while (0)
 
 template <int T0, int C1, int C2, int C3>
-static int launch_bwdg(const BwdParams& p, int nw, hipStream_t stream) {
+static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     constexpr bool kSplit = PCRL_BWDG_ARITH == 2;
     const int nW = (p.cl.N + 31) / 32;
     auto prep = encoder_bwdg_prep_kernel<C1, C2, C3>;
@@ -829,16 +835,15 @@ static int launch_bwdg(const BwdParams& p, int nw, hipStream_t stream) {
     hipLaunchKernelGGL(prep, dim3(p.cl.B + (C2 / 16) * (C2 / 16)), dim3(256), prep_lds, stream, p);   // behind the clouds: the Gram image's 16 x 16 tiles
     PCRL_BWDG_AFTER("encoder_bwdg_prep_kernel");
     const size_t lds = bwdg_lds_bytes_points(T0, C1, C2, C3);
-    {   // four waves per workgroup = one per SIMD: 512 registers, nothing spills, xhat1 stays in registers.  (The eight-wave build
-        // -- two tiles in flight per SIMD -- spilled ~150 registers and measured slower at every batch size: B 256 175 vs 164 us,
-        // K3's 1024 clouds 864 vs 785 us, 512 x 8192 388 vs 339 us.)
-        auto kern = encoder_bwdg_points_kernel<T0, C1, C2, C3, kSplit, 4>;
+    {   // (an eight-wave build -- two tiles in flight per SIMD, 256 registers each -- spilled ~150 registers and measured slower at
+        // every batch size: B 256 175 vs 164 us, K3's 1024 clouds 864 vs 785 us, 512 x 8192 388 vs 339 us)
+        auto kern = encoder_bwdg_points_kernel<T0, C1, C2, C3, kSplit>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
-        hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(64 * kBwdgWaves), lds, stream, p);
     }
     PCRL_BWDG_AFTER("encoder_bwdg_points_kernel");
     // h1 of one cloud (C2 / 32 blocks x up to 32 KB) + the per-slot coefficients + the per-channel tables
-    constexpr size_t wgrad_lds = (size_t)(C2 / 32) * 32 * 64 * sizeof(f32x4) + 3 * 64 * sizeof(f32x4) + 256 * 4 + (size_t)C3 * 8;
+    constexpr size_t wgrad_lds = (size_t)(C2 / 32) * 32 * 64 * sizeof(f32x4) + 3 * 64 * sizeof(f32x4) + 256 * 4 + (size_t)C3 * 8 + 16;
     auto wgrad = encoder_bwdg_wgrad_kernel<C1, C2, C3>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad), wgrad_lds)) return rc;
     hipLaunchKernelGGL(wgrad, dim3(min(p.cl.B, num_cus()) * p.parts), dim3(512), wgrad_lds, stream, p);
@@ -859,10 +864,10 @@ static int launch_bwdg(const BwdParams& p, int nw, hipStream_t stream) {
     return PCRL_OK;
 }
 
-int PCRL_BWDG_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, int nw, hipStream_t st) {
+int PCRL_BWDG_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, hipStream_t st) {
     int rc = PCRL_E_ARG;
 #define PCRL_BWDG_CASE(T0_, C1_, C2_, C3_) \
-    if (T0 == T0_ && c1 == C1_ && c2 == C2_ && c3 == C3_) rc = launch_bwdg<T0_, C1_, C2_, C3_>(p, nw, st);
+    if (T0 == T0_ && c1 == C1_ && c2 == C2_ && c3 == C3_) rc = launch_bwdg<T0_, C1_, C2_, C3_>(p, st);
     PCRL_BWDG_CASE(3, 64, 128, 256) PCRL_BWDG_CASE(4, 128, 128, 256)
 #ifndef PCRL_BWDG_FEWER
     PCRL_BWDG_CASE(2, 64, 128, 256) PCRL_BWDG_CASE(4, 64, 128, 256) PCRL_BWDG_CASE(5, 64, 128, 256)

@@ -1288,9 +1288,8 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         // pooled values are given (the agents always pass them).  The bf16 mode and PCRL_BWD_ALGO=0 keep the round-2 kernels.
         static const int algo = [] { const char* e = getenv("PCRL_BWD_ALGO"); return e ? atoi(e) : 1; }();
         if (mode != 1 && algo != 0 && p.cl.B <= kMaxTileModeClouds && w->w2 && pooled) {
-            p.ops = reinterpret_cast<float*>(base + wg.ops); p.xs = reinterpret_cast<float*>(base + wg.xs);
-            p.pw = reinterpret_cast<float*>(base + wg.pw); p.n_act = reinterpret_cast<int*>(base + wg.nact);
-            p.flag = reinterpret_cast<int*>(base + wg.flag); p.act = reinterpret_cast<int*>(base + wg.act);
+            p.ops = reinterpret_cast<float*>(base + wg.ops); p.pw = reinterpret_cast<float*>(base + wg.pw);
+            p.n_act = reinterpret_cast<int*>(base + wg.nact); p.act = reinterpret_cast<int*>(base + wg.act);
             p.slot = reinterpret_cast<unsigned char*>(base + wg.slot); p.own = reinterpret_cast<unsigned*>(base + wg.own);
             p.own_chan = reinterpret_cast<unsigned char*>(base + wg.own_chan); p.ptc = reinterpret_cast<float4*>(base + wg.ptc);
             p.chc = reinterpret_cast<float*>(base + wg.chc); p.n1part = reinterpret_cast<float*>(base + wg.n1part);
@@ -1300,11 +1299,9 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             p.tile_mode = 1;
             p.parts = 1;
             while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;
-            static const int nw_forced = [] { const char* e = getenv("PCRL_BWD_TILE_WAVES"); return e ? atoi(e) : 0; }();
-            const int nw = nw_forced ? nw_forced : ((long long)p.cl.B * (w->c3 / 32) <= 4ll * num_cus() ? 4 : 8);
             const int T0g = (p.cl.C + 1) / 2;
-            const int rcg = mode == 2 ? encoder_bwdg_launch_split(T0g, w->c1, w->c2, w->c3, p, nw, st)
-                                      : encoder_bwdg_launch_f32(T0g, w->c1, w->c2, w->c3, p, nw, st);
+            const int rcg = mode == 2 ? encoder_bwdg_launch_split(T0g, w->c1, w->c2, w->c3, p, st)
+                                      : encoder_bwdg_launch_f32(T0g, w->c1, w->c2, w->c3, p, st);
             if (rcg == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
             if (rcg) return rcg;
             if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
