@@ -148,6 +148,16 @@ __host__ __device__ constexpr int fwd_w1_lds_blocks(int T0, int C1, int C2, int 
     return fit < C2 / 32 ? fit : C2 / 32;
 }
 
+#ifdef PCRL_FWD_STAMPS
+// Development build only (-DPCRL_FWD_STAMPS): shader-clock stamps at the phase boundaries of the tile loop (first work item of
+// every workgroup), read back with pcrl_debug_fwd_stamps (tools/fwd_stamps.py; profiles/r03_fwd_stamps.md).
+__device__ unsigned long long g_fwd_stamps[256 * 8 * 8][8];
+#define PCRL_FSTAMP(k) do { if (lane == 0 && work == (int)blockIdx.x && blockIdx.x < 256 && (tile - t_begin) / nwaves < 8) \
+    g_fwd_stamps[(blockIdx.x * 8 + wave) * 8 + (tile - t_begin) / nwaves][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PCRL_FSTAMP(k) do { } while (0)
+#endif
+
 template <int T0, int C1, int C2, int C3, bool BF16, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) {
     constexpr PackedLayout L{T0, C1, C2, C3};
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
             const bool valid = pidx < p.cl.N;
             const int pc = valid ? pidx : p.cl.N - 1;
 
+            PCRL_FSTAMP(0);
             // ---- preprocess (+ augmentation) ---------------------------------------------
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
 
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 for (int r = 0; r < 16; ++r) a0[mb][r] = relu_nan(a0[mb][r]);
             }
 
+            PCRL_FSTAMP(1);
             // ---- conv1 + LN + ReLU --------------------------------------------------------
             f32x16 a1[MB2];
             if (SPLIT)
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                         return mb < W1L ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane]
                                         : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
+            PCRL_FSTAMP(2);
             // ReLU as an integer max (one instruction per register instead of compare + select); a NaN of either sign is restored
             // below: a point with any NaN channel has a NaN variance, and LayerNorm then makes ALL its channels NaN
             const bool nan_pt1 = ln_relu_acc<C2, true>(a1, s_ln1, half, p.eps);
@@ -254,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                         if (nan_pt1) a1[mb][r] = u2f(0x7FC00000u);
             }
 
+            PCRL_FSTAMP(3);
             // ---- conv2 + LN + ReLU --------------------------------------------------------
             f32x16 a2[MB3];
             if (SPLIT)
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 dense_layer_mfma<MB3, C2 / 8, 2>(
                     a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
+            PCRL_FSTAMP(4);
             // No ReLU instructions after LayerNorm-2: the pool compares the raw bits as SIGNED integers, where every value <= 0
             // (and -0, and a NaN with the sign bit) sorts below the smallest positive float, i.e. below max(key, 1) -- exactly the
             // lanes the ReLU would have zeroed.  What reaches a key is positive, so the keys' unsigned order is unchanged.
@@ -284,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                         if (nan_pt) a2[mb][r] = u2f(0x7FFFFFFFu);
             }
 
+            PCRL_FSTAMP(5);
             // ---- symmetric max-pool with first-index argmax --------------------------------
             // lanes past N hold a copy of point N - 1 and report that index, so no validity test is needed below
             const unsigned inv_idx = ~(unsigned)pc;
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                     }
                 }
             }
+            PCRL_FSTAMP(6);
         }
         __syncthreads();
         for (int c = tid; c < C3; c += nthreads) {
@@ -725,3 +742,11 @@ extern "C" int pcrl_encoder_fwd_f32split(const pcrl_cloud_desc* clouds, const pc
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return encoder_fwd_impl(2, clouds, aug, w, packed, pooled, argmax, workspace, workspace_bytes, stream);
 }
+
+#ifdef PCRL_FWD_STAMPS
+extern "C" int pcrl_debug_fwd_stamps(unsigned long long* out, int n_rows) {
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcrl::g_fwd_stamps), sizeof(unsigned long long) * 8 * (size_t)n_rows) != hipSuccess) return -3;
+    return 0;
+}
+#endif
