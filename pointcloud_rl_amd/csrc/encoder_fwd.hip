@@ -352,9 +352,14 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned v = f2u(a2[mb][r]);
-                        if ((int)v >= imax_((int)cur[r], 1)) {       // key values are >= 0 as integers (positive floats, or the NaN marker)
-                            const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
-                            atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                        const bool upd = (int)v >= imax_((int)cur[r], 1);   // key values are >= 0 as integers (positive floats, or the NaN marker)
+                        // wave-uniform early-out: in a cloud's later tiles no lane of the wave reaches the key for most registers, and
+                        // then nothing but the compare is issued (no exec-mask round trip, no predicated-off ds_max_u64)
+                        if (__builtin_expect(__ballot(upd) != 0ull, 0)) {
+                            if (upd) {
+                                const int ch = acc_chan(mb * 16 + r, 0) + 4 * half;
+                                atomicMax(&s_keys[ch], ((unsigned long long)v << 32) | inv_idx);
+                            }
                         }
                     }
                 }
