@@ -47,16 +47,98 @@ def _flatten(items, prefix=""):
             yield prefix + k, v
 
 
+class TStepIndex:
+    """Host-side bookkeeping of the reference's TStepTransition (pyrl/env/sampling_strategy.py:105-246): which runs of `horizon`
+    consecutive ring positions of one worker's episode are valid sampling units (horizon = -1: whole episodes), kept up to
+    date as transitions are pushed and as the ring overwrites old ones.  Only `episode_dones`, `is_truncated` and
+    `worker_indices` of a push are looked at; the transitions themselves stay in HBM."""
+
+    def __init__(self, capacity, horizon):
+        self.capacity, self.horizon = int(capacity), int(horizon)
+        self.reset()
+
+    def reset(self):
+        self.position = self.running_count = 0
+        self.worker_indices = np.zeros(self.capacity, dtype=np.int16) - 1
+        self.num_procs = 0
+        self.current_episode, self.valid_seq = [], []
+
+    def __len__(self):
+        return int(np.sum([len(v) for v in self.valid_seq])) if self.valid_seq else 0
+
+    def push(self, worker, done):
+        """One transition lands on ring position self.position (sampling_strategy.py:147-209)."""
+        if worker + 1 > self.num_procs:
+            for _ in range(worker + 1 - self.num_procs):
+                self.current_episode.append([])
+                self.valid_seq.append([])
+            self.num_procs = worker + 1
+        if self.worker_indices[self.position] >= 0:           # the ring overwrites an old transition: retire what started there
+            last = self.worker_indices[self.position]
+            if len(self.current_episode[last]) > 0 and self.position == self.current_episode[last][0]:
+                self.current_episode[last].pop(0)
+            if self.valid_seq[last] and self.position == self.valid_seq[last][0][0]:
+                if self.horizon > 0:
+                    self.valid_seq[last].pop(0)
+                else:
+                    self.valid_seq[last][0].pop(0)
+                    if len(self.valid_seq[last][0]) == 0:
+                        self.valid_seq[last].pop(0)
+        self.current_episode[worker].append(self.position)
+        self.worker_indices[self.position] = worker
+        if self.horizon > 0:
+            if len(self.current_episode[worker]) >= self.horizon:
+                self.valid_seq[worker].append(self.current_episode[worker][-self.horizon:])
+        elif done:
+            self.valid_seq[worker].append(self.current_episode[worker])
+        if done:
+            self.current_episode[worker] = []
+        self.running_count += 1
+        self.position = (self.position + 1) % self.capacity
+
+    def blocks(self, index):
+        """index: unit numbers drawn by the sampler -> (int32 [B, H] ring positions, bool [B, H, 1] validity), short units
+        (whole-episode mode) padded with their first position (sampling_strategy.py:228-246)."""
+        query = np.cumsum([len(v) for v in self.valid_seq])
+        ret = []
+        for i in index:
+            j = int(np.searchsorted(query, i, side="right"))
+            ret.append(self.valid_seq[j][i - (0 if j == 0 else query[j - 1])])
+        width = max(len(r) for r in ret)
+        mask = np.zeros([len(ret), width, 1], dtype=np.bool_)
+        for i, r in enumerate(ret):
+            mask[i, :len(r)] = True
+            ret[i] = list(r) + [r[0]] * (width - len(r))
+        return np.asarray(ret, dtype=np.int32), mask
+
+
 class DeviceReplay:
     MAX_BATCH = 16384         # rows per sample() the launch's ticket words are sized for
 
-    def __init__(self, capacity, device="cuda", seed=None, with_replacement=True, host_rng=False):
+    def __init__(self, capacity, device="cuda", seed=None, with_replacement=True, host_rng=False, horizon=1, sampling_cfg=None):
+        """sampling_cfg: the reference's `ReplayMemory(capacity, sampling_cfg=dict(type="OneStepTransition" | "TStepTransition",
+        horizon=, with_replacement=, seed=))` spelling of the same choices (replay_buffer.py:151-170)."""
+        if sampling_cfg is not None:
+            cfg = dict(sampling_cfg)
+            kind = cfg.pop("type", "OneStepTransition")
+            assert kind in ("OneStepTransition", "TStepTransition"), f"unknown sampling strategy {kind}"
+            horizon = cfg.pop("horizon", 1) if kind == "TStepTransition" else 1
+            with_replacement = cfg.pop("with_replacement", with_replacement)
+            seed = cfg.pop("seed", seed)
+            cfg.pop("capacity", None)
+            assert not cfg, f"unsupported sampling options {sorted(cfg)}"
+            if kind == "TStepTransition":
+                host_rng = True
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("DeviceReplay keeps the ring in MI355X HBM: device must be a CUDA/HIP device")
         self.with_replacement = bool(with_replacement)
-        if not with_replacement:
-            host_rng = True            # the shuffled epoch order is drawn on the host exactly as the reference draws it
+        self.horizon = int(horizon)
+        # T-step sampling (horizon != 1, or asked for by name): [B, H] index blocks of consecutive transitions of one episode,
+        # drawn on the host from the bookkeeping above exactly as the reference does; the gather stays one launch
+        self.tstep = TStepIndex(capacity, self.horizon) if (self.horizon != 1 or (sampling_cfg or {}).get("type") == "TStepTransition") else None
+        if not with_replacement or self.tstep is not None:
+            host_rng = True            # the shuffled epoch order / the unit numbers are drawn on the host exactly as the reference draws them
         self.capacity, self.device = int(capacity), device
         self.seed = np.random.randint(0, 2 ** 32 - 1) if seed is None else seed
         self.np_random = np.random.RandomState(self.seed)          # sampling_strategy.py:18-19
@@ -77,6 +159,8 @@ class DeviceReplay:
     def reset(self):
         self.position = self.running_count = 0
         self.items, self.item_index = None, 0
+        if self.tstep is not None:
+            self.tstep.reset()
         self.state[1:].fill_(0)          # size, and every ticket word (an aborted sampling launch may have left some non-zero)
 
     @property
@@ -97,6 +181,11 @@ class DeviceReplay:
         flat.setdefault("is_truncated", np.zeros([n, 1], dtype=np.bool_))
         if n > self.capacity:
             flat, n = {k: v[:self.capacity] for k, v in flat.items()}, self.capacity
+        if self.tstep is not None:      # episode bookkeeping from the three flag columns (host values), one transition at a time
+            host = lambda v: v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            ed, tr, wi = host(flat["episode_dones"]), host(flat["is_truncated"]), host(flat["worker_indices"])
+            for i in range(n):
+                self.tstep.push(int(wi[i].reshape(-1)[0]), bool(ed[i].reshape(-1)[0]) or bool(tr[i].reshape(-1)[0]))
         flat = {k: self._as_tensor(v) for k, v in flat.items()}
         if self.storage is None:
             self.storage = {k: torch.zeros((self.capacity,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.device) for k, v in flat.items()}
@@ -149,10 +238,11 @@ class DeviceReplay:
             self._staging[batch_size] = (flat, _DeviceSample(self._nest(flat)), idx, pinned, segs)
         return self._staging[batch_size]
 
-    def sample_indices(self, batch_size, drop_last=True, auto_restart=True):
+    def sample_indices(self, batch_size, drop_last=True, auto_restart=True, capacity=None):
         """SamplingStrategy.get_index (sampling_strategy.py:26-48): uniform with replacement, or consecutive slices of a
-        shuffled epoch order that is re-drawn after a push or when exhausted (None when exhausted and not auto_restart)."""
-        capacity = len(self)
+        shuffled epoch order that is re-drawn after a push or when exhausted (None when exhausted and not auto_restart).
+        capacity: the number of sampling units (T-step: valid index blocks) when it is not the number of transitions."""
+        capacity = len(self) if capacity is None else capacity
         if self.with_replacement:
             return self.np_random.randint(low=0, high=capacity, size=batch_size)
         if self.items is None or self.need_update:
@@ -187,6 +277,8 @@ class DeviceReplay:
         size = len(self)
         if size == 0:
             raise RuntimeError("sampling from an empty replay buffer")
+        if self.tstep is not None:
+            return self._sample_tstep(batch_size, auto_restart, drop_last)
         if self.host_rng:
             index = self.sample_indices(batch_size, drop_last, auto_restart)
             if index is None:
@@ -204,6 +296,28 @@ class DeviceReplay:
             hip.replay_sample_gather_state(segs, batch_size, self.capacity, self.seed, self.state, idx)
         self.draws += 1
         return sample
+
+    def _sample_tstep(self, batch_size, auto_restart, drop_last):
+        """TStepTransition.sample + ReplayMemory.sample (sampling_strategy.py:211-246, replay_buffer.py:297-322): every key comes
+        back as [B, H, ...], `is_valid` [B, H, 1] marks the padding of short episodes (horizon = -1)."""
+        units = len(self.tstep)
+        if units < len(self) * 0.8 and self.horizon != -1:         # the reference prints this and exit(0)s
+            raise RuntimeError(f"{len(self) - units}/{len(self)} samples would be thrown out when sampling with horizon {self.horizon}")
+        index = self.sample_indices(batch_size, drop_last, auto_restart, capacity=units)
+        if index is None:
+            return None
+        blocks, mask = self.tstep.blocks(index)
+        B, H = blocks.shape
+        flat, sample, idx, pinned, segs = self._stage(B * H)
+        host = pinned[self._flip]
+        self._flip ^= 1
+        host.numpy()[:] = blocks.reshape(-1)
+        idx.copy_(host, non_blocking=True)
+        hip.replay_gather(segs, idx, self.capacity)
+        self.draws += 1
+        out = {k: v.view((B, H) + tuple(v.shape[1:])) for k, v in flat.items() if k != "is_valid"}
+        out["is_valid"] = torch.from_numpy(mask).to(self.device, non_blocking=True)
+        return _DeviceSample(self._nest(out))
 
     def last_indices(self, batch_size):
         """Row numbers used by the latest sample(batch_size) (device int32 [B])."""

@@ -505,6 +505,40 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
         assert torch.equal(p, q), n
 
 
+@pytest.mark.parametrize("tag,kw", [("h3_with", dict(horizon=3, with_replacement=True)), ("h3_without", dict(horizon=3, with_replacement=False)),
+                                    ("episode_with", dict(horizon=-1, with_replacement=True))])
+def test_device_replay_tstep_sampling_reproduces_the_reference(cuda, tag, kw):
+    """T-step sampling (sampling_strategy.py:105-246: [B, H] blocks of consecutive transitions of one worker's episode, whole
+    episodes padded for horizon -1) on the device ring: every sampled key and the validity mask equal what the reference's
+    ReplayMemory returned for the same pushes and seed (tests/golden/ref_replay_tstep.npz)."""
+    import os
+    from pointcloud_rl_amd.replay import DeviceReplay
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_replay_tstep.npz"))
+    mem = DeviceReplay(48, device=cuda, sampling_cfg=dict(type="TStepTransition", seed=11, **kw))
+    for i in range(4):
+        items = {}
+        for k in d.files:
+            if k.startswith(f"push{i}/"):
+                parts = k.split("/")[1:]
+                node = items
+                for part in parts[:-1]:
+                    node = node.setdefault(part, {})
+                node[parts[-1]] = d[k]
+        mem.push_batch(items)
+    assert len(mem) == int(d[f"{tag}/len_units"][0]) and len(mem.tstep) == int(d[f"{tag}/len_units"][1])
+    for s_ in range(6):
+        batch = mem.sample(5).to_torch(device=cuda)
+        keys = [k[len(f"{tag}/sample{s_}/"):] for k in d.files if k.startswith(f"{tag}/sample{s_}/")]
+        assert keys
+        for k in keys:
+            node = batch
+            for part in k.split("/"):
+                node = node[part]
+            want = d[f"{tag}/sample{s_}/{k}"]
+            assert tuple(node.shape) == want.shape, (k, tuple(node.shape), want.shape)
+            assert np.array_equal(node.cpu().numpy(), want), (tag, s_, k)
+
+
 def _swap_agent_and_rings(cuda, B, N, A):
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent

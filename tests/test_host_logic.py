@@ -319,3 +319,37 @@ def test_global_rot_scale_trans_draws_the_reference_matrices(tag, kw):
         assert torch.equal(mat[:, :, 3], ref[:, :3, 3])
     got = torch.einsum("bji,bin->bjn", mat[:, :, :3], xyz) + mat[:, :, 3:]
     np.testing.assert_allclose(got.numpy(), z[f"{tag}/out_xyz"], atol=1e-6, rtol=0)
+
+
+def test_tstep_index_blocks_reproduce_the_reference_sampler():
+    """TStepIndex + the host draw (pointcloud_rl_amd/replay.py) against what the reference's ReplayMemory(sampling_cfg=dict(type=
+    "TStepTransition", ...)) returned (tests/golden/ref_replay_tstep.npz, tools/gen_golden_replay_tstep.py): same [B, H] blocks of
+    ring positions (checked through the rewards they select from a numpy copy of the ring) and the same validity mask, for
+    horizon 3 with / without replacement and for whole episodes (horizon -1, padded)."""
+    import os
+    from pointcloud_rl_amd.replay import DeviceReplay, TStepIndex
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_replay_tstep.npz"))
+    cap = 48
+    for tag, horizon, with_repl in (("h3_with", 3, True), ("h3_without", 3, False), ("episode_with", -1, True)):
+        mem = DeviceReplay.__new__(DeviceReplay)                 # host-side state only: no device is touched
+        mem.capacity, mem.with_replacement, mem.np_random = cap, with_repl, np.random.RandomState(11)
+        mem.items, mem.item_index, mem.need_update, mem.running_count = None, 0, False, 0
+        mem.tstep = TStepIndex(cap, horizon)
+        ring = np.zeros((cap, 1), np.float32)
+        pos = 0
+        for i in range(4):
+            r, ed, wi = d[f"push{i}/rewards"], d[f"push{i}/episode_dones"], d[f"push{i}/worker_indices"]
+            for k in range(len(r)):
+                ring[pos] = r[k]
+                pos = (pos + 1) % cap
+                mem.tstep.push(int(wi[k, 0]), bool(ed[k, 0]))
+            mem.running_count += len(r)
+            mem.need_update = True
+        assert [min(mem.running_count, cap), len(mem.tstep)] == d[f"{tag}/len_units"].tolist()
+        for s_ in range(6):
+            index = mem.sample_indices(5, True, True, capacity=len(mem.tstep))
+            blocks, mask = mem.tstep.blocks(index)
+            want = d[f"{tag}/sample{s_}/rewards"]
+            assert blocks.shape == want.shape[:2] and np.array_equal(mask, d[f"{tag}/sample{s_}/is_valid"]), (tag, s_)
+            assert np.array_equal(ring[blocks], want), (tag, s_)
+
