@@ -391,6 +391,163 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     }
 }
 
+// ---- wide last layer (c3 = 512 / 1024: the class default mlp_spec = [64, 128, 1024], pointnet.py:81) ------------------------------
+// One point's c3 conv2 outputs no longer fit a lane's registers (c3 / 2 accumulators per lane), and LayerNorm-2 needs all of them
+// twice (mean, then the centred sum of squares) before the first output can be formed.  The tile loop therefore runs conv2 THREE
+// times in chunks of 256 output channels (8 row blocks = 128 accumulators): pass A accumulates the sum, pass B the centred
+// squares, pass C normalises and pools.  The partial sums advance in exactly the order ln_center_rstd walks the row blocks
+// (oracle/pcrl_oracle.c::half_sum), so the result is bit-identical to the oracle's as for the narrow shapes.  conv2's weights
+// stream from the packed image in L2 (c3 x c2 fp32 = 512 KB does not fit LDS); fp32 only, no feature-head epilogue.  Three
+// times the conv2 work of a (hypothetical) register-resident kernel -- no shipped SAC / DrQ config uses this shape.
+template <int T0, int C1, int C2, int C3>
+__global__ __launch_bounds__(512, 1) void encoder_fwd_wide_kernel(const FwdParams p) {
+    constexpr PackedLayout L{T0, C1, C2, C3};
+    constexpr int MB1 = C1 / 32, MB2 = C2 / 32, NCH = C3 / 256, MBC = 8;
+    static_assert(C3 % 256 == 0 && C3 > 256, "wide kernel: c3 = 512, 768, 1024");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_desc + PCRL_MAX_CHANNELS);
+    float* s_ln1 = reinterpret_cast<float*>(s_keys + C3);
+    float* s_ln2 = s_ln1 + 2 * C2;
+    float* s_b0 = s_ln2 + 2 * C3;
+    float* s_w0 = s_b0 + C1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
+    for (int i = tid; i < MB1 * T0 * 64; i += nthreads) s_w0[i] = p.packed[L.w0() + i];
+    for (int i = tid; i < C1; i += nthreads) s_b0[i] = p.packed[L.b0() + i];
+    ln_pair_table(s_ln1, p.packed + L.ln1(), C2, tid, nthreads);
+    ln_pair_table(s_ln2, p.packed + L.ln2(), C3, tid, nthreads);
+    if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
+    const __amdgpu_buffer_rsrc_t r_packed = make_rsrc(p.packed, 4u * (unsigned)L.total());
+    const unsigned lane16 = 16u * (unsigned)lane;
+    const f32x4* s_gb2 = reinterpret_cast<const f32x4*>(s_ln2);
+    const unsigned* s_key_hi = reinterpret_cast<const unsigned*>(s_keys) + 1;
+
+    for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
+        const int b = work / p.S, seg = work - b * p.S;
+        const int t_begin = seg * p.tiles_per_seg;
+        const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
+        __syncthreads();
+        for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0x00000000FFFFFFFFull;      // {value +0.0, point 0}
+        __syncthreads();
+        for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
+            const int pidx = tile * 32 + l31;
+            const int pc = pidx < p.cl.N ? pidx : p.cl.N - 1;
+            const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
+            const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
+            f32x16 a0[MB1];
+#pragma unroll
+            for (int mb = 0; mb < MB1; ++mb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = s_b0[acc_chan(mb * 16 + r, 0) + 4 * half];
+#pragma unroll
+                for (int t = 0; t < T0; ++t) {
+                    const float bop = half_select(x[2 * t], x[2 * t + 1], half_mask);
+                    a0[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w0[(mb * T0 + t) * 64 + lane], bop, a0[mb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[mb][r] = relu_nan(a0[mb][r]);
+            }
+            f32x16 a1[MB2];
+            dense_layer_mfma<MB2, C1 / 8, 3>(
+                a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
+                [&](int t) { return a0[t >> 4][t & 15]; });
+            const bool nan_pt1 = ln_relu_acc<C2, true>(a1, s_ln1, half, p.eps);
+            if (__builtin_expect(__ballot(nan_pt1) != 0ull, 0)) {
+#pragma unroll
+                for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (nan_pt1) a1[mb][r] = u2f(0x7FC00000u);
+            }
+            // one chunk of conv2: row blocks 8 ch .. 8 ch + 7
+            auto conv2_chunk = [&](f32x16 (&a2)[MBC], int ch) {
+                const unsigned base = 4u * (unsigned)(L.w2() + ch * MBC * (C2 / 8) * 256);
+                dense_layer_mfma<MBC, C2 / 8, 3>(
+                    a2, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, base + 4u * (unsigned)((mb * (C2 / 8) + tq) * 256)); },
+                    [&](int t) { return a1[t >> 4][t & 15]; });
+            };
+            // pass A: sum over the C3 channels (two half-sums of 4 interleaved partials, combined as ln_center_rstd does)
+            f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll 1
+            for (int ch = 0; ch < NCH; ++ch) {
+                f32x16 a2[MBC];
+                conv2_chunk(a2, ch);
+#pragma unroll
+                for (int mb = 0; mb < MBC; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) { p01 = p01 + PCRL_PAIR(a2[mb], r); p23 = p23 + PCRL_PAIR(a2[mb], r + 2); }
+            }
+            float lo, hi;
+            both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
+            const float mean = (lo + hi) / (float)C3;
+            const f32x2 mean2 = {mean, mean};
+            // pass B: centred sum of squares
+            p01 = f32x2{0.f, 0.f}; p23 = f32x2{0.f, 0.f};
+#pragma unroll 1
+            for (int ch = 0; ch < NCH; ++ch) {
+                f32x16 a2[MBC];
+                conv2_chunk(a2, ch);
+#pragma unroll
+                for (int mb = 0; mb < MBC; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) {
+                        const f32x2 c01 = PCRL_PAIR(a2[mb], r) - mean2, c23 = PCRL_PAIR(a2[mb], r + 2) - mean2;
+                        p01 = __builtin_elementwise_fma(c01, c01, p01);
+                        p23 = __builtin_elementwise_fma(c23, c23, p23);
+                    }
+            }
+            both_halves((p01[0] + p01[1]) + (p23[0] + p23[1]), lo, hi);
+            const float var = (lo + hi) / (float)C3;
+            const bool nan_pt = var != var;
+            const float rstd = 1.0f / __builtin_sqrtf(var + p.eps);
+            const f32x2 rstd2 = {rstd, rstd};
+            const bool any_nan = __ballot(nan_pt) != 0ull;
+            const unsigned inv_idx = ~(unsigned)pc;
+            // pass C: normalise (no ReLU instruction: the pool orders the raw bits as signed integers) and pool against the keys
+#pragma unroll 1
+            for (int ch = 0; ch < NCH; ++ch) {
+                f32x16 a2[MBC];
+                conv2_chunk(a2, ch);
+#pragma unroll
+                for (int mb = 0; mb < MBC; ++mb) {
+                    unsigned cur[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cur[r] = s_key_hi[2 * (256 * ch + acc_chan(mb * 16 + r, 0) + 4 * half)];
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x4 g4 = s_gb2[(256 * ch + acc_chan(mb * 16 + r, 0) + 4 * half) >> 1];
+                        const f32x2 c = PCRL_PAIR(a2[mb], r) - mean2;
+                        const f32x2 y = __builtin_elementwise_fma(c * rstd2, __builtin_shufflevector(g4, g4, 0, 1), __builtin_shufflevector(g4, g4, 2, 3));
+                        a2[mb][r] = y[0]; a2[mb][r + 1] = y[1];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        unsigned v = f2u(a2[mb][r]);
+                        if (any_nan && nan_pt) v = 0x7FFFFFFFu;          // torch: a NaN wins the max, the first NaN's index is returned
+                        const bool upd = (int)v >= imax_((int)cur[r], 1);
+                        if (__builtin_expect(__ballot(upd) != 0ull, 0)) {
+                            if (upd) atomicMax(&s_keys[256 * ch + acc_chan(mb * 16 + r, 0) + 4 * half], ((unsigned long long)v << 32) | inv_idx);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C3; c += nthreads) {
+            const unsigned long long key = s_keys[c];
+            if (p.S == 1) {
+                unsigned vb = (unsigned)(key >> 32);
+                if (vb > 0x7F800000u) vb = 0x7FC00000u;
+                p.pooled[(long long)b * C3 + c] = u2f(vb);
+                p.argmax[(long long)b * C3 + c] = (int)~(unsigned)key;
+            } else {
+                p.partial[((long long)b * p.S + seg) * C3 + c] = key;
+            }
+        }
+    }
+}
+
 // Second stage of the split-cloud pool: max over the S partial keys of a cloud.
 __global__ void encoder_merge_kernel(const unsigned long long* __restrict__ partial, int B, int S, int C3,
                                      float* __restrict__ pooled, int* __restrict__ argmax) {
@@ -595,10 +752,21 @@ static int launch_fwd(const FwdParams& p, int grid, hipStream_t stream) {
 }
 
 // mlp_spec of every shipped pn_* SAC / DrQ config: [64,128,256] (dm_control), [128,128,256] (maniskill), [32,64,128]
-// (dm_control pn_motivating / pn_shift_motivating).  The class default [64,128,1024] (pointnet.py:81) is used by none of
-// them and is not built: c3 = 1024 does not fit the one-point-per-lane register layout (1024 accumulators per point).
+// (dm_control pn_motivating / pn_shift_motivating), and the class default [64,128,1024] (pointnet.py:81; used by none of them):
+// c3 = 1024 does not fit the one-point-per-lane register layout and runs on encoder_fwd_wide_kernel (fp32 only).
+bool encoder_dims_wide(int c1, int c2, int c3) { return c1 == 64 && c2 == 128 && c3 == 1024; }
 bool encoder_dims_supported(int c1, int c2, int c3) {
-    return ((c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256) || (c1 == 32 && c2 == 64 && c3 == 128);
+    return ((c1 == 64 || c1 == 128) && c2 == 128 && c3 == 256) || (c1 == 32 && c2 == 64 && c3 == 128) || encoder_dims_wide(c1, c2, c3);
+}
+
+template <int T0, int C1, int C2, int C3>
+static int launch_fwd_wide(const FwdParams& p, int grid, hipStream_t stream) {
+    const size_t lds = sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 8 * (size_t)C3 + sizeof(float) * (2 * C2 + 2 * C3 + C1 + (size_t)(C1 / 32) * T0 * 64);
+    auto kern = encoder_fwd_wide_kernel<T0, C1, C2, C3>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+    PCRL_CHECK_LAUNCH("encoder_fwd_wide_kernel");
+    return PCRL_OK;
 }
 
 }  // namespace pcrl
@@ -608,7 +776,7 @@ using namespace pcrl;
 extern "C" int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, int32_t c3, size_t* bytes) {
     if (!bytes) return fail(PCRL_E_ARG, "bytes is NULL");
     if (c_in < 1 || c_in > PCRL_MAX_CHANNELS || !encoder_dims_supported(c1, c2, c3))
-        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256] or [32,64,128])", c_in, c1, c2, c3);
+        return fail(PCRL_E_ARG, "unsupported encoder dims C=%d mlp_spec=[%d,%d,%d] (fused kernel: C<=16, [64|128,128,256], [32,64,128] or [64,128,1024])", c_in, c1, c2, c3);
     const PackedLayout L{(c_in + 1) / 2, c1, c2, c3};
     *bytes = sizeof(float) * (size_t)L.total();
     return PCRL_OK;
@@ -693,6 +861,13 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     const int T0 = (p.cl.C + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     int rc = PCRL_E_ARG;
+    if (encoder_dims_wide(w->c1, w->c2, w->c3)) {
+        if (mode != 0) return fail(PCRL_E_ARG, "mlp_spec=[%d,%d,%d]: only the fp32 kernel is built for the wide last layer", w->c1, w->c2, w->c3);
+        if (head) return fail(PCRL_E_ARG, "mlp_spec=[%d,%d,%d]: the feature-head epilogue is built for c3 <= 256", w->c1, w->c2, w->c3);
+#define PCRL_FWD_WIDE_CASE(T0_) if (T0 == T0_) rc = launch_fwd_wide<T0_, 64, 128, 1024>(p, grid, st);
+        PCRL_FWD_WIDE_CASE(2) PCRL_FWD_WIDE_CASE(3) PCRL_FWD_WIDE_CASE(4) PCRL_FWD_WIDE_CASE(5)
+#undef PCRL_FWD_WIDE_CASE
+    }
 #define PCRL_FWD_CASE(T0_, C1_, C2_, C3_)                                         \
     if (T0 == T0_ && w->c1 == C1_ && w->c2 == C2_ && w->c3 == C3_)                \
         rc = mode == 1 ? launch_fwd<T0_, C1_, C2_, C3_, true>(p, grid, st) : mode == 2 ? launch_fwd<T0_, C1_, C2_, C3_, false, true>(p, grid, st) \

@@ -300,9 +300,9 @@ class DeviceReplay:
     def _sample_tstep(self, batch_size, auto_restart, drop_last):
         """TStepTransition.sample + ReplayMemory.sample (sampling_strategy.py:211-246, replay_buffer.py:297-322): every key comes
         back as [B, H, ...], `is_valid` [B, H, 1] marks the padding of short episodes (horizon = -1)."""
-        units = len(self.tstep)
-        if units < len(self) * 0.8 and self.horizon != -1:         # the reference prints this and exit(0)s
-            raise RuntimeError(f"{len(self) - units}/{len(self)} samples would be thrown out when sampling with horizon {self.horizon}")
+        units = len(self.tstep)        # (the reference's "samples will be throwed out" guard compares this number with itself)
+        if units == 0:
+            raise RuntimeError(f"no run of {self.horizon} consecutive transitions of one episode in the buffer yet")
         index = self.sample_indices(batch_size, drop_last, auto_restart, capacity=units)
         if index is None:
             return None

@@ -109,6 +109,33 @@ def test_fwd_nan_point_wins(cuda):
     assert np.array_equal(pooled[0].view(np.uint32), pooled_ref[0].view(np.uint32))
 
 
+@pytest.mark.parametrize("B,N,C_extra", [(3, 100, dict()), (2, 1, dict()), (260, 70, dict()), (4, 300, dict(pos_encoding=3)), (2, 2100, dict())])
+def test_fwd_wide_class_default_mlp_spec_matches_oracle(cuda, B, N, C_extra):
+    """mlp_spec = [64, 128, 1024], PointNet's class default (pointnet.py:81): the wide kernel (three conv2 passes in 256-channel chunks)
+    is bit-identical to the C oracle -- values and first-index argmax -- like the narrow shapes; ragged N, a single point, B above the
+    number of CUs, C = 9, clouds split over workgroups (second-stage merge)."""
+    obs = make_obs(B, N, seed=B * 100 + N, **C_extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, 64, 128, 1024, seed=N + 3)
+    _check(obs, w, cuda)
+
+
+def test_fwd_wide_ties_dead_channels_and_nan(cuda):
+    from oracle import c_oracle
+    obs = make_obs(3, 96, seed=23)
+    for k in obs:
+        obs[k][:, :, 48:] = obs[k][:, :, :48]          # duplicate points: exact ties -> first index
+    obs["xyz"][2, 1, 20] = np.nan                      # a NaN point wins every channel of its cloud
+    w = make_encoder_weights(6, 64, 128, 1024, seed=6)
+    w["g2"][100:140] = 0.0
+    w["be2"][100:140] = -1.0                           # ReLU-dead channels: value 0, index 0
+    pooled_ref, arg_ref = c_oracle.encoder_fwd(c_oracle.preprocess(obs), w)
+    pooled, argmax = _run_hip(obs, w, cuda)
+    assert np.array_equal(argmax, arg_ref)
+    assert (arg_ref[:2] < 48).all() and (pooled_ref[:2, 100:140] == 0).all() and np.isnan(pooled[2]).all() and (argmax[2] == 20).all()
+    assert np.array_equal(pooled[:2].view(np.uint32), pooled_ref[:2].view(np.uint32))
+
+
 def test_fwd_interleaved_bnc_layout(cuda):
     # BASELINE.json's synthetic [B, N, C] f32 layout, read through strides
     from oracle import c_oracle
