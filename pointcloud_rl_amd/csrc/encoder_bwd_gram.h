@@ -39,10 +39,19 @@ struct GramExtra {      // what a cloud's pw row holds behind the reference-orde
     __host__ __device__ constexpr int total() const { return C2 * C2 + 2 * C2; }
 };
 
+// Octets (8 active points) a block array has room for, tiles per cloud, and the integer type that holds a slot / a channel number:
+// c3 <= 256 keeps round 2's sizes (32 octets, 8 tiles, one byte); the wide last layer (c3 = 1024) has up to c3 active points.
+__host__ __device__ constexpr int bwdg_np(int c3) { return c3 > 256 ? c3 / 8 : 32; }
+__host__ __device__ constexpr int bwdg_tpc(int c3) { return c3 > 256 ? c3 / 32 : 8; }
+template <int kC3> struct BwdgIdx { typedef unsigned char type; };
+template <> struct BwdgIdx<512> { typedef unsigned short type; };
+template <> struct BwdgIdx<768> { typedef unsigned short type; };
+template <> struct BwdgIdx<1024> { typedef unsigned short type; };
+
 // Operand workspace of the Gram form: no dz2 array.
 struct OpsLayoutG {
-    int MB1, MB2;
-    __host__ __device__ constexpr int blk() const { return 32 * kPiece; }
+    int MB1, MB2, NP;
+    __host__ __device__ constexpr int blk() const { return NP * kPiece; }
     __host__ __device__ constexpr int h1() const { return 0; }
     __host__ __device__ constexpr int dz1() const { return h1() + MB2 * blk(); }
     __host__ __device__ constexpr int h0() const { return dz1() + MB2 * blk(); }
@@ -50,6 +59,11 @@ struct OpsLayoutG {
     __host__ __device__ constexpr int xb() const { return dz0() + MB1 * blk(); }
     __host__ __device__ constexpr int total() const { return xb() + blk(); }
 };
+
+// Byte offset of accumulator slot (mb, r) inside an operand block array of NP octets per block, lane part excluded.
+__host__ __device__ constexpr unsigned gop_off(int arr_floats, int mb, int r, int NP) {
+    return 4u * (unsigned)(arr_floats + mb * NP * kPiece + ((r & 3) + 8 * (r >> 2)) * 4);
+}
 
 // ---- prep: active list, slots, channels grouped by slot; M = W2^T W2 and s = W2^T 1 --------------------------------------------
 // Index of M[row][col] inside the operand-ordered image [C2/32][C2/8][64][4] a C2 -> C2 dense_layer_mfma streams (the contraction
@@ -249,8 +263,9 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
     constexpr int NW = kBwdgWaves;
     constexpr PackedLayout L{T0, C1, kC2, kC3};
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32;
-    constexpr OpsLayoutG OL{C1 / 32, kC2 / 32};
+    constexpr OpsLayoutG OL{C1 / 32, kC2 / 32, bwdg_np(kC3)};
     const GradLayout GL{p.cl.C, C1, kC2, kC3};
+    typedef typename BwdgIdx<kC3>::type idx_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ChanSrc* s_desc = reinterpret_cast<ChanSrc*>(smem);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
             for (int r = 0; r < 16; ++r) {
                 a0[mb][r] = relu_nan(a0[mb][r]);
                 mask0[mb] |= (a0[mb][r] > 0.0f ? 1u : 0u) << r;
-                buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
+                buf_store_f1(r_ops, lane_off, gop_off(OL.h0(), mb, r, OL.NP), a0[mb][r]);
             }
         }
         PCRL_GSTAMP(1);
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
             for (int r = 0; r < 16; ++r) {
                 xh1[mb][r] = a1[mb][r];                       // xhat1 stays in registers for LayerNorm-1's backward
                 a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
-                buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
+                buf_store_f1(r_ops, lane_off, gop_off(OL.h1(), mb, r, OL.NP), a1[mb][r]);
             }
         }
         PCRL_GSTAMP(2);
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
         float t1 = 0.0f, t2r = 0.0f;
         {
             const int start = (int)(own_w & 0xFFFFu), cnt = (int)(own_w >> 16);
-            const unsigned char* oc = p.own_chan + (long long)b * kC3 + start;
+            const idx_t* oc = reinterpret_cast<const idx_t*>(p.own_chan) + (long long)b * kC3 + start;
             for (int i = 0; __any(i < cnt); ++i) {
                 const bool has = i < cnt;
                 const int c = has ? (int)oc[i] : 0;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
             allreduce_add32_x16(tg);
             allreduce_add32_x16(tb);
             if (l31 == 0) {        // this tile's partial sums; the wgrad kernel adds a cloud's tiles in tile order
-                float2* n1 = reinterpret_cast<float2*>(p.n1part) + ((long long)b * 8 + tile) * kC2;
+                float2* n1 = reinterpret_cast<float2*>(p.n1part) + ((long long)b * bwdg_tpc(kC3) + tile) * kC2;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) n1[acc_chan(mb * 16 + r, 0) + 4 * half] = float2{tg[r], tb[r]};
             }
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 q[mb][r] = rstd1 * ((q[mb][r] - n1) - xh1[mb][r] * n2);
-                buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), q[mb][r]);
+                buf_store_f1(r_ops, lane_off, gop_off(OL.dz1(), mb, r, OL.NP), q[mb][r]);
             }
         PCRL_GSTAMP(7);
         // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
         for (int mb = 0; mb < MB1; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
+                buf_store_f1(r_ops, lane_off, gop_off(OL.dz0(), mb, r, OL.NP), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
         PCRL_GSTAMP(8);
     }
 }
@@ -578,8 +593,9 @@ __device__ __forceinline__ void wgrad_conv0_pipelined(const BwdParams& p, const 
 template <int C1, int kC2, int kC3>
 __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdParams p) {
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32;
-    constexpr OpsLayoutG OL{C1 / 32, kC2 / 32};
+    constexpr OpsLayoutG OL{C1 / 32, kC2 / 32, bwdg_np(kC3)};
     constexpr GramExtra GX{kC2};
+    static_assert(kC3 <= 256, "the LDS-staged wgrad kernel holds a cloud's whole h1: c3 <= 256 (wide: encoder_bwdg_wgrad_wide_kernel)");
     const GradLayout GL{p.cl.C, C1, kC2, kC3};
     extern __shared__ __attribute__((aligned(16))) f32x4 s_h1[];      // [MB2][n_oct][64] pieces, then the per-slot coefficients
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -719,6 +735,187 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
     }
 }
 
+// ---- wide last layer (c3 = 1024, the class default mlp_spec): simple kernels, no shipped config runs them ------------------------------
+// The Gram form needs only M = W2^T W2 [C2 x C2] whatever c3 is, so the points kernel above is the same template (two-byte slot /
+// channel numbers, up to c3 / 32 tiles per cloud).  What is specific to c3 <= 256 are the prep kernel (thread = channel = slot with
+// 256 threads) and the wgrad kernel (a cloud's whole h1 in LDS): the versions below trade speed for plainness -- 1 024 threads per
+// cloud in the prep, every operand of the wgrad blocks streamed from L2.
+template <int kC2, int kC3>
+__global__ __launch_bounds__(256) void encoder_bwdg_mtile_kernel(const BwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float s_strip[];
+    gram_tile<kC2, kC3>(p.w2, p.mimg, (int)blockIdx.x, threadIdx.x, s_strip);
+}
+
+template <int C1, int kC2, int kC3>
+__global__ __launch_bounds__(1024) void encoder_bwdg_prep_wide_kernel(const BwdParams p) {
+    static_assert(kC3 == 1024, "one thread per channel");
+    extern __shared__ __attribute__((aligned(16))) unsigned s_words[];   // [nW] bitmap, then [nW] exclusive prefix popcounts
+    __shared__ int s_scan[32];
+    __shared__ unsigned short s_slot[kC3];
+    typedef typename BwdgIdx<kC3>::type idx_t;
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
+    const int tid = threadIdx.x, b = blockIdx.x, wv = tid >> 6;
+    const int nW = (p.cl.N + 31) >> 5;
+    unsigned* s_pre = s_words + nW;
+    int pc = p.argmax[(long long)b * kC3 + tid];
+    const bool live = p.pooled[(long long)b * kC3 + tid] > 0.0f;
+    for (int w = tid; w < nW; w += 1024) s_words[w] = 0u;
+    __syncthreads();
+    pc = pc < 0 ? 0 : (pc >= p.cl.N ? p.cl.N - 1 : pc);
+    if (live) atomicOr(&s_words[pc >> 5], 1u << (pc & 31));
+    __syncthreads();
+    // block-wide exclusive scan helper: per-thread count -> exclusive prefix, total in s_scan[16]
+    auto block_scan = [&](int local, int* total) {
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += v; }
+        __syncthreads();
+        if ((tid & 63) == 63) s_scan[wv] = incl;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { const int v = s_scan[w]; if (w < wv) base += v; tot += v; }
+        *total = tot;
+        return base + incl - local;
+    };
+    const int per = (nW + 1023) >> 10, w0 = tid * per;
+    int local = 0;
+    for (int k = 0; k < per; ++k)
+        if (w0 + k < nW) local += __popc(s_words[w0 + k]);
+    int n_act;
+    int run = block_scan(local, &n_act);
+    for (int k = 0; k < per; ++k)
+        if (w0 + k < nW) { s_pre[w0 + k] = (unsigned)run; run += __popc(s_words[w0 + k]); }
+    __syncthreads();
+    const int slot = (int)s_pre[pc >> 5] + __popc(s_words[pc >> 5] & ((1u << (pc & 31)) - 1u));
+    s_slot[tid] = live ? (unsigned short)slot : (unsigned short)0xFFFF;      // 0xFFFF never names a slot (n_act <= 1024)
+    reinterpret_cast<idx_t*>(p.slot)[(long long)b * kC3 + tid] = live ? (idx_t)slot : (idx_t)0;
+    if (live) {
+        p.act[(long long)b * kC3 + slot] = pc;
+    } else {
+        float* pw = p.pw + (long long)b * p.pw_stride;
+        pw[GL.g2() + tid] = 0.0f;
+        pw[GL.be2() + tid] = 0.0f;
+        p.chc[(long long)b * kC3 + tid] = 0.0f;
+    }
+    if (tid == 0) p.n_act[b] = n_act;
+    __syncthreads();
+    // thread = slot: its channels (ascending), counted and then written behind the slots before it
+    int cnt = 0;
+    if (tid < n_act)
+        for (int c = 0; c < kC3; ++c) cnt += s_slot[c] == (unsigned short)tid ? 1 : 0;
+    int total_own;
+    int pos = block_scan(cnt, &total_own);
+    p.own[(long long)b * kC3 + tid] = (unsigned)pos | ((unsigned)cnt << 16);
+    if (cnt > 0)
+        for (int c = 0; c < kC3; ++c)
+            if (s_slot[c] == (unsigned short)tid) reinterpret_cast<idx_t*>(p.own_chan)[(long long)b * kC3 + pos++] = (idx_t)c;
+}
+
+// One 32 x 32 block = sum over the octets of A-piece x B-piece, both streamed from L2 (four octets in flight); `scale(q, kl)` gives the
+// four per-slot factors of the A piece (octet q, k-lane kl) or ones.
+template <class ScaleFn>
+__device__ __forceinline__ void l2_block(const f32x4* a4, const f32x4* b4, int n_oct, ScaleFn scale, bool b_live, f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    constexpr int D = 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ar[D], br[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < n_oct) { ar[d] = a4[d * 64]; br[d] = b_live ? b4[d * 64] : zero4; }
+    for (int q0 = 0; q0 < n_oct; q0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int q = q0 + d;
+            if (q < n_oct) {
+                const f32x4 a = ar[d] * scale(q), bv = br[d];
+                if (q + D < n_oct) { ar[d] = a4[(q + D) * 64]; br[d] = b_live ? b4[(q + D) * 64] : zero4; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int C1, int kC2, int kC3>
+__global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_wide_kernel(const BwdParams p) {
+    constexpr int MB1 = C1 / 32, MB2 = kC2 / 32, NP = bwdg_np(kC3), TPC = bwdg_tpc(kC3);
+    constexpr OpsLayoutG OL{C1 / 32, kC2 / 32, NP};
+    constexpr GramExtra GX{kC2};
+    typedef typename BwdgIdx<kC3>::type idx_t;
+    const GradLayout GL{p.cl.C, C1, kC2, kC3};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 5;
+    for (int b = blockIdx.x; b < p.cl.B; b += gridDim.x) {
+        const float* ops = p.ops + (long long)b * OL.total();
+        float* pw = p.pw + (long long)b * p.pw_stride;
+        float* px = pw + GL.total();
+        const float4* ptc = p.ptc + (long long)b * kC3;
+        const int n_tiles = (p.n_act[b] + 31) / 32, n_oct = n_tiles * 4;
+        if (tid < 2 * kC2) {   // norm1 gradients: fixed-order sum over the cloud's tiles
+            const float* n1 = p.n1part + (long long)b * TPC * kC2 * 2;
+            float acc = 0.0f;
+            for (int t = 0; t < n_tiles; ++t) acc = acc + n1[t * kC2 * 2 + tid];
+            pw[((tid & 1) ? GL.be1() : GL.g1()) + (tid >> 1)] = acc;
+        }
+        const f32x4* h1p = reinterpret_cast<const f32x4*>(ops + OL.h1());
+        const f32x4* dz1p = reinterpret_cast<const f32x4*>(ops + OL.dz1());
+        const f32x4* h0p = reinterpret_cast<const f32x4*>(ops + OL.h0());
+        const f32x4* dz0p = reinterpret_cast<const f32x4*>(ops + OL.dz0());
+        const f32x4* xbp = reinterpret_cast<const f32x4*>(ops + OL.xb());
+        const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+        auto a_of = [&](int q) { const float4* c = ptc + 8 * q + 4 * kl; return f32x4{c[0].x, c[1].x, c[2].x, c[3].x}; };
+        auto one = [&](int) { return ones; };
+        constexpr int nG = MB2 * MB2, nW1 = MB2 * MB1, nW0 = MB1;
+        for (int t = wave; t < nG + nW1 + nW0; t += 8) {
+            f32x16 acc;
+            if (t < nG) {               // G[32 mb .., 32 nb ..] = sum_slots a h1 h1^T
+                const int mb = t / MB2, nb = t % MB2;
+                l2_block(h1p + mb * NP * 64 + lane, h1p + nb * NP * 64 + lane, n_oct, a_of, true, acc);
+                store_tile(px + GX.G(), kC2, mb, nb, kC2, acc, lane);
+            } else if (t < nG + nW1) {
+                const int u = t - nG, mb = u / MB1, nb = u % MB1;
+                l2_block(dz1p + mb * NP * 64 + lane, h0p + nb * NP * 64 + lane, n_oct, one, true, acc);
+                store_tile(pw + GL.w1(), C1, mb, nb, C1, acc, lane);
+            } else {                    // conv0.weight | conv0.bias: rows of the x|1 block beyond C were never written
+                const int mb = t - nG - nW1;
+                l2_block(dz0p + mb * NP * 64 + lane, xbp + lane, n_oct, one, (lane & 31) <= p.cl.C, acc);
+                const int col = lane & 31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (col < p.cl.C) pw[GL.w0() + row * p.cl.C + col] = acc[r];
+                    else if (col == p.cl.C) pw[GL.b0() + row] = acc[r];
+                }
+            }
+        }
+        if (tid < 2 * kC2) {   // v[j] = sum_slots (rstd2 m1) h1[j][slot], u[j] = sum_slots (a mu) h1[j][slot], slot order
+            const int j = tid % kC2, which = tid / kC2;
+            const f32x4* hj = h1p + (j >> 5) * NP * 64 + (j & 31);
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+            for (int q2 = 0; q2 < 2 * n_oct; ++q2) {
+                const float4* c = ptc + 4 * q2;
+                const f32x4 co = which ? f32x4{c[0].z, c[1].z, c[2].z, c[3].z} : f32x4{c[0].y, c[1].y, c[2].y, c[3].y};
+                acc4 = __builtin_elementwise_fma(hj[(q2 >> 1) * 64 + 32 * (q2 & 1)], co, acc4);
+            }
+            px[(which ? GX.u() : GX.v()) + j] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        }
+        {   // S rows and norm2.weight's missing factor rstd2 of the channel's point
+            const idx_t* slot = reinterpret_cast<const idx_t*>(p.slot) + (long long)b * kC3;
+            const float* chc = p.chc + (long long)b * kC3;
+            const float* h1f = ops + OL.h1();
+            const int j = tid % kC2, cofs = tid / kC2;
+            for (int c0 = 0; c0 < kC3; c0 += 512 / kC2) {
+                const int c = c0 + cofs, sl = (int)slot[c];
+                const float raw = chc[c];
+                const float r2 = raw != 0.0f ? ptc[sl].w : 0.0f;
+                const float h = raw != 0.0f ? h1f[(((j >> 5) * NP + (sl >> 3)) * 64 + (j & 31) + 32 * ((sl >> 2) & 1)) * 4 + (sl & 3)] : 0.0f;
+                pw[GL.w2() + c * kC2 + j] = raw != 0.0f ? (raw * r2) * h : 0.0f;
+                if (j == 0) { const float g = pw[GL.g2() + c]; pw[GL.g2() + c] = g != 0.0f ? g * ptc[sl].w : 0.0f; }
+            }
+        }
+    }
+}
+
 #if PCRL_BWD_MODE == 4
 // ---- reduce over the clouds (fixed order) and the finish of dW2 -----------------------------------------------------------
 template <int ARITH>      // (one instance per translation unit)
@@ -788,9 +985,10 @@ struct BwdgWorkspace {
     size_t ops, pw, nact, act, slot, own, own_chan, ptc, chc, n1part, gvu, mimg, total;
 };
 static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
-    const OpsLayoutG OL{C1 / 32, kC2 / 32};
+    const OpsLayoutG OL{C1 / 32, kC2 / 32, bwdg_np(kC3)};
     const GradLayout GL{C, C1, kC2, kC3};
     const GramExtra GX{kC2};
+    const size_t isz = kC3 > 256 ? 2 : 1;          // bytes per slot / channel number
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     BwdgWorkspace w;
     w.ops = 0;
@@ -798,12 +996,12 @@ static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     w.nact = al(w.pw + sizeof(float) * (size_t)B * (GL.total() + GX.total()));
     w.act = al(w.nact + sizeof(int) * (size_t)B);
     w.slot = al(w.act + sizeof(int) * (size_t)B * kC3);
-    w.own = al(w.slot + (size_t)B * kC3);
+    w.own = al(w.slot + isz * (size_t)B * kC3);
     w.own_chan = al(w.own + sizeof(unsigned) * (size_t)B * kC3);
-    w.ptc = al(w.own_chan + (size_t)B * kC3);
+    w.ptc = al(w.own_chan + isz * (size_t)B * kC3);
     w.chc = al(w.ptc + sizeof(float4) * (size_t)B * kC3);
     w.n1part = al(w.chc + sizeof(float) * (size_t)B * kC3);
-    w.gvu = al(w.n1part + sizeof(float) * (size_t)B * 8 * kC2 * 2);
+    w.gvu = al(w.n1part + sizeof(float) * (size_t)B * bwdg_tpc(kC3) * kC2 * 2);
     w.mimg = al(w.gvu + sizeof(float) * (size_t)GX.total());
     w.total = al(w.mimg + sizeof(float) * ((size_t)kC2 * kC2 + kC2));
     return w;
@@ -824,6 +1022,39 @@ int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p
             if (e_ != hipSuccess) return fail(PCRL_E_LAUNCH, "%s: %s", name, hipGetErrorString(e_));               \
         }                                                                                                          \
     } while (0)
+
+template <int T0, int C1, int C2, int C3>
+static int launch_bwdg_wide(const BwdParams& p, hipStream_t stream) {
+    const int nW = (p.cl.N + 31) / 32;
+    auto mt = encoder_bwdg_mtile_kernel<C2, C3>;
+    constexpr size_t mt_lds = 2 * 16 * (size_t)C3 * sizeof(float);
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mt), mt_lds)) return rc;
+    hipLaunchKernelGGL(mt, dim3((C2 / 16) * (C2 / 16)), dim3(256), mt_lds, stream, p);
+    PCRL_BWDG_AFTER("encoder_bwdg_mtile_kernel");
+    auto prep = encoder_bwdg_prep_wide_kernel<C1, C2, C3>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
+    hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(1024), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
+    PCRL_BWDG_AFTER("encoder_bwdg_prep_wide_kernel");
+    const size_t lds = bwdg_lds_bytes_points(T0, C1, C2, C3);
+    auto kern = encoder_bwdg_points_kernel<T0, C1, C2, C3, false>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(64 * kBwdgWaves), lds, stream, p);
+    PCRL_BWDG_AFTER("encoder_bwdg_points_kernel");
+    hipLaunchKernelGGL((encoder_bwdg_wgrad_wide_kernel<C1, C2, C3>), dim3(min(p.cl.B, num_cus())), dim3(512), 0, stream, p);
+    PCRL_BWDG_AFTER("encoder_bwdg_wgrad_wide_kernel");
+    const GradLayout GL{p.cl.C, C1, C2, C3};
+    const GramExtra GX{C2};
+    const int stride = GL.total() + GX.total();
+    hipLaunchKernelGGL(encoder_bwdg_reduce_kernel<PCRL_BWDG_ARITH>, dim3((stride + 63) / 64), dim3(1024), 0, stream, p.pw, p.cl.B, stride, GL.total(), p.grads, p.gvu);
+    PCRL_BWDG_AFTER("encoder_bwdg_reduce_kernel");
+    constexpr int rows = (256 / C2) * 2;
+    constexpr size_t fin_lds = sizeof(float) * ((size_t)C2 * C2 + (size_t)rows * C2);
+    auto fin = encoder_bwdg_finish_kernel<C2>;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fin), fin_lds)) return rc;
+    hipLaunchKernelGGL(fin, dim3((C3 + rows - 1) / rows), dim3(256), fin_lds, stream, p.w2, p.gvu, C3, p.grads + GL.w2());
+    PCRL_BWDG_AFTER("encoder_bwdg_finish_kernel");
+    return PCRL_OK;
+}
 
 template <int T0, int C1, int C2, int C3>
 static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
@@ -875,6 +1106,15 @@ int PCRL_BWDG_LAUNCH_NAME(int T0, int c1, int c2, int c3, const BwdParams& p, hi
     PCRL_BWDG_CASE(2, 32, 64, 128) PCRL_BWDG_CASE(3, 32, 64, 128) PCRL_BWDG_CASE(4, 32, 64, 128) PCRL_BWDG_CASE(5, 32, 64, 128)
 #endif
 #undef PCRL_BWDG_CASE
+#if PCRL_BWDG_ARITH == 0 && !defined(PCRL_BWDG_FEWER)
+    // the class default mlp_spec = [64, 128, 1024] (fp32 only)
+    if (c1 == 64 && c2 == 128 && c3 == 1024) {
+        if (T0 == 2) rc = launch_bwdg_wide<2, 64, 128, 1024>(p, st);
+        if (T0 == 3) rc = launch_bwdg_wide<3, 64, 128, 1024>(p, st);
+        if (T0 == 4) rc = launch_bwdg_wide<4, 64, 128, 1024>(p, st);
+        if (T0 == 5) rc = launch_bwdg_wide<5, 64, 128, 1024>(p, st);
+    }
+#endif
     return rc;
 }
 #endif  // PCRL_BWD_MODE == 4

@@ -1307,6 +1307,9 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
             return PCRL_OK;
         }
+        if (w->c3 > 256)
+            return fail(PCRL_E_ARG, "mlp_spec=[%d,%d,%d]: the wide last layer is built in Gram form only: fp32, the forward's pooled values "
+                                    "given, at most %d clouds", w->c1, w->c2, w->c3, kMaxTileModeClouds);
     }
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);

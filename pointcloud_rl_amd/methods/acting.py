@@ -32,6 +32,8 @@ class FusedActor:
             return False
         if actor.final_mlp is not None or bb.ac_feat is not None or bb.obs_feat is not None:
             return False
+        if enc.mlp_spec[-1] > 256:          # the feature-head epilogue of the encoder launch is built for c3 <= 256
+            return False
         lin = mlp.linears
         if len(lin) != 3 or any(l.bias is None for l in lin):
             return False

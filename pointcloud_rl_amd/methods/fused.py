@@ -134,6 +134,8 @@ class FusedStep:
             return False
         if not isinstance(enc, PointNet) or enc.final_mlp is None or not agent._dedup or not agent.detach_actor_feature:
             return False
+        if enc.mlp_spec[-1] > 256:          # the wide last layer (class default [64, 128, 1024]): encoder kernels + autograd heads
+            return False
         if not all(isinstance(getattr(agent, f"{n}_optim"), HipAdam) for n in ("critic", "actor", "alpha")):
             return False
         if not agent.automatic_alpha_tuning or agent._target_flat is None or len(agent.critic.values) != 2:

@@ -127,6 +127,8 @@ class PointNet(ExtendedModule):
         mlp_spec = [int(c) for c in mlp_spec]
         if len(mlp_spec) != 3:
             raise NotImplementedError("the fused encoder implements a 3-layer shared MLP")
+        if mlp_spec[-1] > 256 and compute_dtype != "f32":
+            raise NotImplementedError("mlp_spec with a last layer wider than 256 channels (the class default [64, 128, 1024]) runs in fp32 only")
         self.feat_dim, self.mlp_spec = int(feat_dim), mlp_spec
         self.global_feat, self.feature_transform = global_feat, feature_transform
         self.eps = float(norm_cfg.get("eps", 1e-5))

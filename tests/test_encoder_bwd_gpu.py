@@ -251,3 +251,24 @@ def test_split_precision_backward_matches_torch_autograd(cuda, B, N, extra, c1):
     got = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat, ew).items()}
     assert_grads_close(got, ref)
     assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled, split=True))
+
+
+@pytest.mark.parametrize("B,N,extra", [(3, 90, dict()), (2, 1500, dict()), (2, 40, dict(pos_encoding=3)), (260, 60, dict())])
+def test_bwd_wide_class_default_mlp_spec_matches_torch_autograd(cuda, B, N, extra):
+    """mlp_spec = [64, 128, 1024] (PointNet's class default, pointnet.py:81): the Gram-form backward needs only W2^T W2 [128 x 128]
+    whatever c3 is; up to 1 024 gradient-carrying points per cloud (32 tiles), two-byte slots.  Same tolerance as the narrow shapes."""
+    obs = make_obs(B, N, seed=31 * B + N, **extra)
+    C = sum(v.shape[1] for v in obs.values())
+    w = make_encoder_weights(C, 64, 128, 1024, seed=N + 5)
+    gpool = np.random.RandomState(N).randn(B, 1024).astype(np.float32)
+    ref, idx_ref, pooled_ref = torch_reference_grads(obs, w, gpool)
+    got, idx, pooled, n_act = hip_grads(obs, w, gpool, cuda)
+    np.testing.assert_allclose(pooled, pooled_ref, atol=1e-5, rtol=0)
+    if not np.array_equal(idx, idx_ref):
+        assert (idx != idx_ref).mean() < 1e-3
+        ref, _, _ = torch_reference_grads(obs, w, gpool, route=idx)
+    assert np.array_equal(n_act, [len(np.unique(r[m])) for r, m in zip(idx, pooled > 0)])
+    assert_grads_close(got, ref)
+    again, _, _, _ = hip_grads(obs, w, gpool, cuda)
+    for name in NAMES:
+        assert np.array_equal(got[name], again[name]), name          # bitwise run to run

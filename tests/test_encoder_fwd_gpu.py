@@ -273,7 +273,8 @@ def _fixture_launch(cuda, fixture, **mode):
     return d, pooled.cpu().numpy(), argmax.cpu().numpy()
 
 
-@pytest.mark.parametrize("fixture", ["encoder_dmc_c6", "encoder_dmc_c9_posenc", "encoder_maniskill_c7", "encoder_dmc_motivating_c6"])
+@pytest.mark.parametrize("fixture", ["encoder_dmc_c6", "encoder_dmc_c9_posenc", "encoder_maniskill_c7", "encoder_dmc_motivating_c6",
+                                     "encoder_classdefault_c6"])
 def test_fwd_f32_on_the_reference_fixtures(cuda, fixture):
     """The DEFAULT exact-fp32 kernel (pcrl_encoder_fwd_f32) directly against what the reference itself computed (fixtures captured
     from /root/reference by tools/gen_golden.py: pointnet.py:148-151 `self.conv(feature)` + `feature.max(-1)` on torch CPU): argmax

@@ -238,3 +238,9 @@ if __name__ == "__main__":
     gen_encoder("encoder_dmc_motivating_c6", {}, [32, 64, 128], 50, B=3, N=90, seed=4)
     gen_step("sac_dmc_motivating_small", f"{REF}/configs/mfrl/sac/dm_control/pn_motivating.py", small_heads, {}, B=8, N=80, A=4,
              n_updates=4, seed=5)
+    # PointNet's class default mlp_spec = [64, 128, 1024] (pointnet.py:81; no shipped SAC / DrQ config uses it): encoder fixture and a
+    # whole SAC step of the dm_control config with the encoder's spec overridden
+    gen_encoder("encoder_classdefault_c6", {}, [64, 128, 1024], 50, B=3, N=80, seed=5)
+    gen_step("sac_dmc_classdefault_small", f"{REF}/configs/mfrl/sac/dm_control/pn.py",
+             dict(small_heads, **{"agent_cfg.actor_cfg.nn_cfg.visual_nn_cfg.mlp_spec": [64, 128, 1024]}), {}, B=4, N=72, A=6, n_updates=2, seed=8)
+
