@@ -104,7 +104,10 @@ typedef struct pcrl_aug_desc {
 /* Weights of the shared per-point MLP in the reference's own state_dict layout
  * (ConvMLP built by PointNet.__init__, pointnet.py:106-109; mlp.py:43-56):
  *   conv0.weight [c1,C,1] conv0.bias [c1] ; conv1.weight [c2,c1,1] norm1.{weight,bias} [c2] ;
- *   conv2.weight [c3,c2,1] norm2.{weight,bias} [c3] ; LN eps (1e-6 in every shipped config). */
+ *   conv2.weight [c3,c2,1] norm2.{weight,bias} [c3] ; LN eps (1e-6 in every shipped config).
+ * Built (c1,c2,c3): (64,128,256), (128,128,256), (32,64,128) -- every shipped point-cloud SAC / DrQ config -- and the class
+ * default (64,128,1024) (pointnet.py:81): fp32 entry points only (pcrl_encoder_fwd_f32 / pcrl_encoder_bwd_f32, the latter
+ * needs `pooled`), no feature-head epilogue, not part of pcrl_update_step_*.  Anything else returns PCRL_E_ARG. */
 typedef struct pcrl_encoder_weights {
     int32_t c_in, c1, c2, c3;
     const float *w0, *b0, *w1, *g1, *be1, *w2, *g2, *be2;

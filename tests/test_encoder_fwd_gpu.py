@@ -152,7 +152,10 @@ def test_fwd_bad_arguments_raise(cuda):
     from pointcloud_rl_amd import hip
     from pointcloud_rl_amd._lib import PcrlError
     with pytest.raises(PcrlError):
-        hip.encoder_packed_bytes(6, 64, 128, 1024)      # c3 = 1024 not supported by the fused kernel
+        hip.encoder_packed_bytes(6, 64, 128, 512)       # not one of the built (c1, c2, c3) shapes
+    with pytest.raises(PcrlError):
+        hip.encoder_packed_bytes(6, 128, 128, 1024)     # the wide last layer is built for the class default only
+    assert hip.encoder_packed_bytes(6, 64, 128, 1024) > 0
 
 
 @pytest.mark.parametrize("name,B,N,extra,c1", [
