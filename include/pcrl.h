@@ -188,6 +188,21 @@ int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug
                          const int32_t* argmax, const float* grad_pooled, const float* pooled,
                          float* grads, int32_t* n_active,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward as two calls, so that the part that does not need d(loss)/d(pooled) can run early (on another stream, or as
+ * a forked branch of a captured graph) while the heads' backward is still producing it: `prepare` is the launch that turns the
+ * forward's argmax / pooled into the per-cloud lists of gradient-carrying points and builds M = W2^T W2; `prepared` is everything
+ * after it and must be ordered behind `prepare` on the same workspace, with the same clouds / aug / w / argmax / pooled and the
+ * weights unchanged in between.  Gram form only (PCRL_E_ARG where pcrl_encoder_bwd_f32 would run the round-2 kernels).
+ * prepare + prepared == pcrl_encoder_bwd_f32 bit for bit. */
+int pcrl_encoder_bwd_prepare_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                 const pcrl_encoder_weights* w, const void* packed,
+                                 const int32_t* argmax, const float* pooled,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                  const pcrl_encoder_weights* w, const void* packed,
+                                  const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                                  float* grads, int32_t* n_active,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of pcrl_encoder_fwd_bf16: the forward of the active points is recomputed with the same bf16 contractions (so
  * LayerNorm inputs, ReLU masks and argmax relations are the forward's) and the two data-gradient GEMMs contract bf16 too
  * (gradients rounded as they enter, fp32 accumulate); the weight-gradient GEMMs are fp32 on the unrounded operands and the

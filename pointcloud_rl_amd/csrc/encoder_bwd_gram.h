@@ -1026,15 +1026,18 @@ int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p
 template <int T0, int C1, int C2, int C3>
 static int launch_bwdg_wide(const BwdParams& p, hipStream_t stream) {
     const int nW = (p.cl.N + 31) / 32;
-    auto mt = encoder_bwdg_mtile_kernel<C2, C3>;
-    constexpr size_t mt_lds = 2 * 16 * (size_t)C3 * sizeof(float);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mt), mt_lds)) return rc;
-    hipLaunchKernelGGL(mt, dim3((C2 / 16) * (C2 / 16)), dim3(256), mt_lds, stream, p);
-    PCRL_BWDG_AFTER("encoder_bwdg_mtile_kernel");
-    auto prep = encoder_bwdg_prep_wide_kernel<C1, C2, C3>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
-    hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(1024), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
-    PCRL_BWDG_AFTER("encoder_bwdg_prep_wide_kernel");
+    if (p.phase != 2) {
+        auto mt = encoder_bwdg_mtile_kernel<C2, C3>;
+        constexpr size_t mt_lds = 2 * 16 * (size_t)C3 * sizeof(float);
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(mt), mt_lds)) return rc;
+        hipLaunchKernelGGL(mt, dim3((C2 / 16) * (C2 / 16)), dim3(256), mt_lds, stream, p);
+        PCRL_BWDG_AFTER("encoder_bwdg_mtile_kernel");
+        auto prep = encoder_bwdg_prep_wide_kernel<C1, C2, C3>;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
+        hipLaunchKernelGGL(prep, dim3(p.cl.B), dim3(1024), 2 * sizeof(unsigned) * (size_t)nW, stream, p);
+        PCRL_BWDG_AFTER("encoder_bwdg_prep_wide_kernel");
+    }
+    if (p.phase == 1) return PCRL_OK;
     const size_t lds = bwdg_lds_bytes_points(T0, C1, C2, C3);
     auto kern = encoder_bwdg_points_kernel<T0, C1, C2, C3, false>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds)) return rc;
@@ -1060,11 +1063,14 @@ template <int T0, int C1, int C2, int C3>
 static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     constexpr bool kSplit = PCRL_BWDG_ARITH == 2;
     const int nW = (p.cl.N + 31) / 32;
-    auto prep = encoder_bwdg_prep_kernel<C1, C2, C3>;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
-    const size_t prep_lds = std::max(2 * sizeof(unsigned) * (size_t)nW, (size_t)kGramTileLds);
-    hipLaunchKernelGGL(prep, dim3(p.cl.B + (C2 / 16) * (C2 / 16)), dim3(256), prep_lds, stream, p);   // behind the clouds: the Gram image's 16 x 16 tiles
-    PCRL_BWDG_AFTER("encoder_bwdg_prep_kernel");
+    if (p.phase != 2) {
+        auto prep = encoder_bwdg_prep_kernel<C1, C2, C3>;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
+        const size_t prep_lds = std::max(2 * sizeof(unsigned) * (size_t)nW, (size_t)kGramTileLds);
+        hipLaunchKernelGGL(prep, dim3(p.cl.B + (C2 / 16) * (C2 / 16)), dim3(256), prep_lds, stream, p);   // behind the clouds: the Gram image's 16 x 16 tiles
+        PCRL_BWDG_AFTER("encoder_bwdg_prep_kernel");
+    }
+    if (p.phase == 1) return PCRL_OK;
     const size_t lds = bwdg_lds_bytes_points(T0, C1, C2, C3);
     {   // (an eight-wave build -- two tiles in flight per SIMD, 256 registers each -- spilled ~150 registers and measured slower at
         // every batch size: B 256 175 vs 164 us, K3's 1024 clouds 864 vs 785 us, 512 x 8192 388 vs 339 us)

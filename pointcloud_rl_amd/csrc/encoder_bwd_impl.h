@@ -98,6 +98,7 @@ struct BwdParams {
     float* gvu;              // [C2*C2 + 2*C2] sums over the clouds of G, v, u
     float* mimg;             // [C2*C2 + C2] M = W2^T W2 in A-operand order, then s = W2^T 1 (built by the prep launch)
     int pw_stride;           // floats per cloud in pw (GradLayout.total() [+ C2*C2 + 2*C2 in the Gram form])
+    int phase;               // Gram form, host side: 0 whole backward, 1 the prep launch only, 2 everything after it (pcrl_encoder_bwd_prepare_f32)
 };
 
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
@@ -1262,8 +1263,8 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
                             const pcrl_encoder_weights* w, const void* packed,
                             const int32_t* argmax, const float* grad_pooled, const float* pooled,
                             float* grads, int32_t* n_active,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-    if (!clouds || !w || !packed || !argmax || !grad_pooled || !grads) return fail(PCRL_E_ARG, "NULL argument");
+                            void* workspace, size_t workspace_bytes, void* stream, int phase = 0) {
+    if (!clouds || !w || !packed || !argmax || (phase != 1 && (!grad_pooled || !grads))) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
     BwdParams p{};
@@ -1271,7 +1272,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     const GradLayout GL{w->c_in, w->c1, w->c2, w->c3};
     hipStream_t st = (hipStream_t)stream;
     if (p.cl.B == 0) {
-        PCRL_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * GL.total(), st));
+        if (phase != 1) PCRL_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * GL.total(), st));
         return PCRL_OK;
     }
     const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
@@ -1297,6 +1298,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             p.w2 = w->w2;
             p.pw_stride = GL.total() + GramExtra{w->c2}.total();
             p.tile_mode = 1;
+            p.phase = phase;
             p.parts = 1;
             while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;
             const int T0g = (p.cl.C + 1) / 2;
@@ -1304,9 +1306,12 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
                                       : encoder_bwdg_launch_f32(T0g, w->c1, w->c2, w->c3, p, st);
             if (rcg == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
             if (rcg) return rcg;
-            if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
+            if (n_active && phase != 1) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
             return PCRL_OK;
         }
+        if (phase != 0)
+            return fail(PCRL_E_ARG, "the two-call backward exists in Gram form only: fp32, the forward's pooled values given, at most %d clouds",
+                        kMaxTileModeClouds);
         if (w->c3 > 256)
             return fail(PCRL_E_ARG, "mlp_spec=[%d,%d,%d]: the wide last layer is built in Gram form only: fp32, the forward's pooled values "
                                     "given, at most %d clouds", w->c1, w->c2, w->c3, kMaxTileModeClouds);
@@ -1350,6 +1355,22 @@ extern "C" int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_au
                                     float* grads, int32_t* n_active,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     return encoder_bwd_impl(0, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pcrl_encoder_bwd_prepare_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                            const pcrl_encoder_weights* w, const void* packed,
+                                            const int32_t* argmax, const float* pooled,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pooled) return fail(PCRL_E_ARG, "pcrl_encoder_bwd_prepare_f32 needs the forward's pooled values");
+    return encoder_bwd_impl(0, clouds, aug, w, packed, argmax, nullptr, pooled, nullptr, nullptr, workspace, workspace_bytes, stream, 1);
+}
+
+extern "C" int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
+                                             const pcrl_encoder_weights* w, const void* packed,
+                                             const int32_t* argmax, const float* grad_pooled, const float* pooled,
+                                             float* grads, int32_t* n_active,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+    return encoder_bwd_impl(0, clouds, aug, w, packed, argmax, grad_pooled, pooled, grads, n_active, workspace, workspace_bytes, stream, 2);
 }
 
 extern "C" int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,

@@ -247,8 +247,19 @@ def encoder_grad_views(flat, ew):
     return out
 
 
+def encoder_bwd_prepare(desc, ew, packed, argmax, pooled, workspace, aug=None):
+    """First of the two calls of the fp32 backward (pcrl_encoder_bwd_prepare_f32): needs only the forward's outputs, so it may
+    run on a side stream while the heads' backward produces grad_pooled; finish with encoder_bwd(..., prepared=True) on the SAME
+    workspace, ordered behind this call."""
+    assert argmax.dtype == torch.int32 and argmax.is_contiguous() and pooled is not None
+    with _span("encoder_bwd_prepare"):
+        check(lib().pcrl_encoder_bwd_prepare_f32(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
+                                                 _ptr(packed), _ptr(argmax), _ptr(pooled), _ptr(workspace),
+                                                 ctypes.c_size_t(workspace.numel()), _stream()))
+
+
 def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None, want_n_active=False, out=None, bf16=False, pooled=None,
-                split=False):
+                split=False, prepared=False):
     """Flat encoder gradient [pcrl_encoder_num_grads] for d(loss)/d(pooled) = grad_pooled [B,c3]
     (written into `out` when given: a slice of an optimizer's flat gradient buffer)."""
     dev = packed.device
@@ -262,7 +273,9 @@ def encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=None, workspace=None,
         workspace = torch.empty(max(need.value, 1), dtype=torch.uint8, device=dev)
     n_active = torch.empty(desc.B, dtype=torch.int32, device=dev) if want_n_active else None
     with _span("encoder_bwd"):
-        fn = lib().pcrl_encoder_bwd_f32split if split else lib().pcrl_encoder_bwd_bf16 if bf16 else lib().pcrl_encoder_bwd_f32
+        assert not prepared or not (split or bf16)
+        fn = lib().pcrl_encoder_bwd_f32split if split else lib().pcrl_encoder_bwd_bf16 if bf16 else \
+            lib().pcrl_encoder_bwd_prepared_f32 if prepared else lib().pcrl_encoder_bwd_f32
         check(fn(ctypes.byref(desc), ctypes.byref(aug) if aug is not None else None, ctypes.byref(ew),
                                          _ptr(packed), _ptr(argmax), _ptr(grad_pooled), _ptr(pooled), _ptr(grads), _ptr(n_active),
                                          _ptr(workspace), ctypes.c_size_t(workspace.numel()), _stream()))

@@ -192,6 +192,13 @@ class FusedStep:
             return torch.full((self.A,), float(v), dtype=torch.float32, device=dev)
         self.head_scale, self.head_bias = _as_f32(head.scale), _as_f32(head.bias)
         assert self.head_scale.numel() == self.A and self.head_bias.numel() == self.A
+        # PCRL_BWD_FORK=1: the encoder backward's first launch (hip.encoder_bwd_prepare needs only the forward's outputs) runs on
+        # this stream, forked behind the forward and joined in front of the rest of the backward -- in a captured step a parallel
+        # branch of the graph under the head GEMMs.  Measured on MI355X (profiles/r03_graph_branch.md): the two cross-stream edges
+        # cost more than the 7.5 us launch they hide (K1 0.877 -> 0.902 ms per step, K3's 128-cloud share 0.701 -> 0.729), so the
+        # default keeps the step one chain.
+        self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
+        self._forked = False
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -260,6 +267,22 @@ class FusedStep:
                                          act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
         return feat, eps, saved, nlp, h1, h2
 
+    def _fork_prepare(self, enc, ctx, argmax):
+        if self._side is None:
+            return False
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._forked = enc.backward_prepare(ctx, argmax)
+        if not self._forked:
+            main.wait_stream(self._side)
+        return self._forked
+
+    def _join_prepare(self):
+        if self._forked:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._forked = False
+
     # -- the step -------------------------------------------------------------------------------------
     def run(self, *args, **kwargs):
         """Execute the step in one go; gradient exchanges (data-parallel) happen inline: `steps` yields ("start", pieces) where
@@ -314,6 +337,7 @@ class FusedStep:
             head_o, ((xhat, rstd),) = self._feature_jobs([job_o(0)])
             pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o, head=head_o)
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
+        prepared = self._fork_prepare(enc, ctx_o, argmax_o)
         _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
@@ -368,13 +392,15 @@ class FusedStep:
         # The Q heads' gradients (the tail of the critic's flat buffer: 2 x 1.1 M floats at K1 of 2.27 M) are final: their
         # all-reduce runs under the feature-head and encoder backward, only the small head of the buffer waits for those.
         if exchanging:
+            self._join_prepare()             # a segment of the step (one graph each) must not end with an open branch
             yield ("start", [fc.grad[self.q_base:]])
         c3 = self.c3
         dpooled = self._buf("dpooled", M, c3)
         hip.gemm_group([hip.gemm_desc(dy, pooled_o, fc.grad[off[pre + "0.weight"]:], F, c3 + 1, M, (1, F), (c3, 1), c3, ones_col=c3,
                                       c_ones=fc.grad[off[pre + "0.bias"]:]),
                         hip.gemm_desc(dy, fc.data[off[pre + "0.weight"]:], dpooled, M, c3, F, (F, 1), (c3, 1), c3)])
-        enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv])
+        self._join_prepare()
+        enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv], prepared=prepared)
         scale = (yield ("finish", [fc.grad[:self.q_base]])) if exchanging else 1.0
         pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
         stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image

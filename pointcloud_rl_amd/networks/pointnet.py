@@ -6,6 +6,8 @@ pyrl/networks/backbones/pointnet.py:76-157; parameter names follow its state_dic
 The per-point MLP, its LayerNorms, the max-pool and their backward run in libpcrl_hip.so; there
 is no eager or CPU path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -205,11 +207,20 @@ class PointNet(ExtendedModule):
         ew, packed = self._weights_desc()
         return desc, keep, aug, (hip.make_aug_desc(**aug) if aug else None), ew, packed, pooled
 
-    def backward_raw(self, ctx, argmax, grad_pooled, out):
+    def backward_prepare(self, ctx, argmax):
+        """The part of backward_raw that needs only the forward's outputs (hip.encoder_bwd_prepare); True when it was launched --
+        backward_raw must then be called with prepared=True, behind it.  Exact fp32 arithmetic, Gram form only."""
+        desc, keep, aug, aug_desc, ew, packed, pooled = ctx
+        if self.compute_dtype != "f32" or pooled is None or desc.B > 2048 or os.environ.get("PCRL_BWD_ALGO", "1") == "0":
+            return False
+        hip.encoder_bwd_prepare(desc, ew, packed, argmax, pooled, self._workspace("bwd", desc.B), aug=aug_desc)
+        return True
+
+    def backward_raw(self, ctx, argmax, grad_pooled, out, prepared=False):
         """Writes the flat gradient of the shared per-point MLP (reference parameter order) into `out`."""
         desc, keep, aug, aug_desc, ew, packed, pooled = ctx
         hip.encoder_bwd(desc, ew, packed, argmax, grad_pooled, aug=aug_desc, workspace=self._workspace("bwd", desc.B), out=out,
-                        bf16=self.compute_dtype == "bf16", pooled=pooled, split=self.compute_dtype == "f32split")
+                        bf16=self.compute_dtype == "bf16", pooled=pooled, split=self.compute_dtype == "f32split", prepared=prepared)
 
     def forward(self, inputs, object_feature=True, concat_state=None, **kwargs):
         feature, _ = self.pooled(inputs)

@@ -36,7 +36,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     lib = _lib.lib()
     n = ctypes.c_size_t()
     assert lib.pcrl_encoder_packed_bytes(6, 64, 128, 256, ctypes.byref(n)) == 0 and n.value > 4 * (64 * 6 + 128 * 64 + 256 * 128)
-    rc = lib.pcrl_encoder_packed_bytes(6, 64, 128, 1024, ctypes.byref(n))      # c3 = 1024: not supported by the fused kernel
+    rc = lib.pcrl_encoder_packed_bytes(6, 64, 128, 512, ctypes.byref(n))       # not one of the built (c1, c2, c3) shapes
     assert rc == -1 and b"unsupported encoder dims" in lib.pcrl_last_error()
     assert lib.pcrl_encoder_packed_bytes(17, 64, 128, 256, ctypes.byref(n)) == -1            # more than 16 channels
     assert lib.pcrl_encoder_fwd_f32(None, None, None, None, None, None, None, ctypes.c_size_t(0), None) == -1

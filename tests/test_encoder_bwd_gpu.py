@@ -128,6 +128,45 @@ def test_bwd_is_deterministic_and_linear(cuda):
     assert_grads_close(got, ref)
 
 
+@pytest.mark.parametrize("B,N,extra,c1,c3", [(5, 300, dict(), 64, 256), (130, 200, dict(seg=1), 128, 256), (3, 150, dict(), 64, 1024)])
+def test_bwd_in_two_calls_equals_one_call(cuda, B, N, extra, c1, c3):
+    """pcrl_encoder_bwd_prepare_f32 (on another stream, before grad_pooled exists) + pcrl_encoder_bwd_prepared_f32 ==
+    pcrl_encoder_bwd_f32, bit for bit; the prepare call refuses what the Gram form does not cover."""
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd._lib import PcrlError
+    obs_np = make_obs(B, N, seed=3 * B + N, **extra)
+    C = sum(v.shape[1] for v in obs_np.values())
+    w_np = make_encoder_weights(C, c1, 128, c3, seed=N)
+    wt = {k: torch.from_numpy(np.ascontiguousarray(v)).to(cuda) for k, v in w_np.items()}
+    ew, keep_w = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    desc, keep = hip.make_cloud_desc(obs)
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed)
+    gpool = torch.from_numpy(np.random.RandomState(N).randn(B, c3).astype(np.float32)).to(cuda)
+    one, n_one = hip.encoder_bwd(desc, ew, packed, argmax, gpool, want_n_active=True, pooled=pooled)
+    import ctypes
+    need = ctypes.c_size_t()
+    hip.check(hip.lib().pcrl_encoder_bwd_workspace_bytes(B, ew.c_in, ew.c1, ew.c2, ew.c3, ctypes.byref(need)))
+    ws = torch.zeros(need.value, dtype=torch.uint8, device=cuda)
+    side, main = torch.cuda.Stream(device=cuda), torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        hip.encoder_bwd_prepare(desc, ew, packed, argmax, pooled, ws)
+    main.wait_stream(side)
+    two, n_two = hip.encoder_bwd(desc, ew, packed, argmax, gpool, want_n_active=True, pooled=pooled, workspace=ws, prepared=True)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two) and torch.equal(n_one, n_two)
+    with pytest.raises(PcrlError):          # the round-2 kernels (no pooled values) have no two-call form
+        hip.check(hip.lib().pcrl_encoder_bwd_prepare_f32(ctypes.byref(desc), None, ctypes.byref(ew), hip._ptr(packed), hip._ptr(argmax), None,
+                                                         hip._ptr(ws), ctypes.c_size_t(ws.numel()), hip._stream()))
+    with pytest.raises(PcrlError):
+        hip.check(hip.lib().pcrl_encoder_bwd_prepared_f32(ctypes.byref(desc), None, ctypes.byref(ew), hip._ptr(packed), hip._ptr(argmax),
+                                                          hip._ptr(gpool), None, hip._ptr(two), None, hip._ptr(ws), ctypes.c_size_t(ws.numel()),
+                                                          hip._stream()))
+
+
 def _bf16_reference_grads(obs_np, w_np, gpool_np, eps=1e-6):
     """Autograd through the rounding emulation of the mixed-precision forward, roundings straight-through."""
     import torch.nn.functional as F

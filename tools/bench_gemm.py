@@ -26,6 +26,13 @@ def shapes():
     yield "dW1 x2", [dW]
     yield "dh1 x2", [dX]
     yield "dW1 | dh1 x2", [dW, dX]
+    yield "dh1 | dW1 x2 (long K first)", [dX, dW]
+    dW1 = hip.gemm_desc(h, h, t(1, H, H + 1), H, H + 1, M, (1, H), (H, 1), H + 1, ones_col=H)
+    dX1 = hip.gemm_desc(h, W1, t(1, M, H), M, H, H, (H, 1), (H, 1), H, mask=h, ld_mask=H)
+    yield "dW1 x1", [dW1]
+    yield "dh1 x1", [dX1]
+    yield "dW1 | dh1 x1", [dW1, dX1]
+    yield "dh1 | dW1 x1", [dX1, dW1]
     yield "dX0 1024->50 x2", [hip.gemm_desc(h, W0, t(2, M, 52), M, 50, H, (H, 1), (56, 1), 52, batch=2, batch_strides=(M * H, H * 56, M * 52, 0, 0))]
     yield "dW0 x2", [hip.gemm_desc(h, X56, t(2, H, 57), H, 57, M, (1, H), (56, 1), 57, ones_col=56, batch=2, batch_strides=(M * H, M * 56, H * 57, 0, 0))]
     yield "feat 256->50", [hip.gemm_desc(t(M, 256), t(50, 256), t(M, 50), M, 50, 256, (256, 1), (1, 256), 50)]

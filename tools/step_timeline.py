@@ -8,7 +8,7 @@ db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 rows = list(c.execute("select name,start,end from kernels order by start"))
 # steps are delimited by the critic Adam kernel following encoder_bwd_reduce; take the span between two packs far into the run
-idx = [i for i, r in enumerate(rows) if "encoder_bwd_reduce" in r[0]]
+idx = [i for i, r in enumerate(rows) if (sys.argv[2] if len(sys.argv) > 2 else "encoder_bwd_reduce") in r[0]]
 lo, hi = idx[len(idx) // 2], idx[len(idx) // 2 + 2]          # two consecutive steps (one with, one without the actor update)
 prev = rows[lo][2]
 tot = 0
