@@ -100,6 +100,13 @@ __device__ __forceinline__ void buf_store_f1(__amdgpu_buffer_rsrc_t r, unsigned 
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
 
+// NOTE: pass soff as the literal 0 when VALU code may follow closely (see store_block_pieces in encoder_bwd_gram.h: the store-data
+// hazard of stores wider than 64 bits is only guarded by the compiler for a non-register soffset).
+__device__ __forceinline__ void buf_store_f4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, f32x4 v) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 

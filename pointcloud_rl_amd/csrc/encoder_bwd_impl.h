@@ -295,6 +295,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
     float2* s_pt = reinterpret_cast<float2*>(s_xh + kC3);                         // [256] per active point: (sum dx, sum dx * xhat)
     int* s_first = reinterpret_cast<int*>(s_pt + kC3);                         // [256] sorted position where the point's run of keys starts
     float* s_w2 = reinterpret_cast<float*>(s_first + kC3);
+    // bf16 build: the conv2 image takes half of its room; the rest holds the waves' transposition scratch (store_block_pieces)
+    float* s_tr = s_w2 + kC3 * kC2 / 2 + (threadIdx.x >> 6) * kTrFloats;
+    constexpr bool WS = BF16 && 8 * kTrFloats <= kC3 * kC2 / 2;      // whole-piece stores: the scratch of 8 waves fits behind the bf16 image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             // lane-dependent byte offset of an operand element: octet q = s >> 3, k-lane (s >> 2) & 1, k-slot s & 3
             const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
             const unsigned xs_off = 4u * (unsigned)(wave * 64 * 64 + lane);
+            const unsigned tile_bytes = 4096u * (unsigned)wave;       // tile = wave; whole-piece stores of the bf16 build (store_block_pieces)
 
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pidx);
             if (half == 0) {   // B operand of the conv0 weight gradient: rows = input channels, row C = 1 (bias)
@@ -422,8 +426,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                 for (int r = 0; r < 16; ++r) {
                     a0[mb][r] = relu_nan(a0[mb][r]);
                     mask0[mb] |= (a0[mb][r] > 0.0f ? 1u : 0u) << r;
-                    buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.h0(), mb, 0), tile_bytes, a0[mb], l31, half, lane);
             }
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
             f32x16 a1[MB2];
@@ -449,8 +454,9 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                 for (int r = 0; r < 16; ++r) {
                     buf_store_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64), a1[mb][r]);
                     a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
-                    buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.h1(), mb, 0), tile_bytes, a1[mb], l31, half, lane);
             }
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
             f32x16 a2[MB3];
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             }
             const float cA = -(rstd2 * m2), cB = -(rstd2 * m1);     // dz = rstd*dx - rstd*m1 - xhat*rstd*m2
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb)
+            for (int mb = 0; mb < MB3; ++mb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch0 = acc_chan(mb * 16 + r, 0);
@@ -530,8 +536,10 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                         dz = __builtin_fmaf(rstd2, dx, dz);
                     }
                     a2[mb][r] = dz;
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz2(), mb, 0), tile_bytes, a2[mb], l31, half, lane);
+            }
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
             if (SPLIT)
@@ -583,12 +591,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
             both_halves(s2, lo, hi);
             const float n2 = (lo + hi) / (float)kC2;
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
+            for (int mb = 0; mb < MB2; ++mb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     d1[mb][r] = rstd1 * ((d1[mb][r] - n1) - xh1[mb][r] * n2);
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz1(), mb, 0), tile_bytes, d1[mb], l31, half, lane);
+            }
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
             if (SPLIT)
@@ -604,10 +614,14 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
                     d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
                     [&](int t) { return d1[t >> 4][t & 15]; });
 #pragma unroll
-            for (int mb = 0; mb < MB1; ++mb)
+            for (int mb = 0; mb < MB1; ++mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
+                for (int r = 0; r < 16; ++r) {
+                    d0[mb][r] = ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f;
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), d0[mb][r]);
+                }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz0(), mb, 0), tile_bytes, d0[mb], l31, half, lane);
+            }
         }
         __syncthreads();
         if (tid < 2 * kC2) {   // norm1 gradients: fixed-order sum over the waves of this cloud
@@ -657,6 +671,8 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
     float* s_b0 = s_ln2 + 2 * kC3;
     float* s_w0 = s_b0 + C1;
     float* s_w2 = s_w0 + MB1 * T0 * 64;
+    float* s_tr = s_w2 + kC3 * kC2 / 2 + (threadIdx.x >> 6) * kTrFloats;       // bf16 build only (see the cloud kernel)
+    constexpr bool WS = BF16 && 8 * kTrFloats <= kC3 * kC2 / 2;      // whole-piece stores: the scratch of 8 waves fits behind the bf16 image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -726,6 +742,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
             // lane-dependent byte offset of an operand element: octet q = s >> 3, k-lane (s >> 2) & 1, k-slot s & 3
             const unsigned lane_off = 4u * (unsigned)(((s >> 3) * 64 + ((s >> 2) & 1) * 32 + 4 * half) * 4 + (s & 3));
             const unsigned xs_off = 4u * (unsigned)(tile * 64 * 64 + lane);
+            const unsigned tile_bytes = 4096u * (unsigned)tile;       // whole-piece stores of the bf16 build (store_block_pieces)
 
             PCRL_STAMP(0);
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pidx);
@@ -753,8 +770,9 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
                 for (int r = 0; r < 16; ++r) {
                     a0[mb][r] = relu_nan(a0[mb][r]);
                     mask0[mb] |= (a0[mb][r] > 0.0f ? 1u : 0u) << r;
-                    buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.h0(), mb, r), a0[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.h0(), mb, 0), tile_bytes, a0[mb], l31, half, lane);
             }
             PCRL_STAMP(1);
             // ---- conv1 + LN: xhat1 is spilled to the workspace, h1 stays ---------------------------
@@ -781,8 +799,9 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
                 for (int r = 0; r < 16; ++r) {
                     buf_store_f1(r_xs, xs_off, 4u * (unsigned)((mb * 16 + r) * 64), a1[mb][r]);
                     a1[mb][r] = relu_nan(__builtin_fmaf(a1[mb][r], gbv[r].x, gbv[r].y));
-                    buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.h1(), mb, r), a1[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.h1(), mb, 0), tile_bytes, a1[mb], l31, half, lane);
             }
             PCRL_STAMP(2);
             // ---- conv2 + LN -> xhat2 -------------------------------------------------------------
@@ -845,7 +864,7 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
             }
             const float cA = -(rstd2 * m2), cB = -(rstd2 * m1);     // dz = rstd*dx - rstd*m1 - xhat*rstd*m2
 #pragma unroll
-            for (int mb = 0; mb < MB3; ++mb)
+            for (int mb = 0; mb < MB3; ++mb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch0 = acc_chan(mb * 16 + r, 0);
@@ -864,8 +883,10 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
                         dz = __builtin_fmaf(rstd2, dx, dz);
                     }
                     a2[mb][r] = dz;
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz2(), mb, r), dz);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz2(), mb, 0), tile_bytes, a2[mb], l31, half, lane);
+            }
             PCRL_STAMP(4);
             // ---- dH1 = W2^T dz2 ; ReLU + LN1 backward ----------------------------------------------
             f32x16 d1[MB2];
@@ -917,12 +938,14 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
             both_halves(s2, lo, hi);
             const float n2 = (lo + hi) / (float)kC2;
 #pragma unroll
-            for (int mb = 0; mb < MB2; ++mb)
+            for (int mb = 0; mb < MB2; ++mb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     d1[mb][r] = rstd1 * ((d1[mb][r] - n1) - xh1[mb][r] * n2);
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz1(), mb, r), d1[mb][r]);
                 }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz1(), mb, 0), tile_bytes, d1[mb], l31, half, lane);
+            }
             PCRL_STAMP(6);
             // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
             f32x16 d0[MB1];
@@ -939,10 +962,14 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
                     d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
                     [&](int t) { return d1[t >> 4][t & 15]; });
 #pragma unroll
-            for (int mb = 0; mb < MB1; ++mb)
+            for (int mb = 0; mb < MB1; ++mb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f);
+                for (int r = 0; r < 16; ++r) {
+                    d0[mb][r] = ((mask0[mb] >> r) & 1u) ? d0[mb][r] : 0.0f;
+                    if constexpr (!WS) buf_store_f1(r_ops, lane_off, op_off(OL.dz0(), mb, r), d0[mb][r]);
+                }
+                if constexpr (WS) store_block_pieces(r_ops, s_tr, op_off(OL.dz0(), mb, 0), tile_bytes, d0[mb], l31, half, lane);
+            }
             PCRL_STAMP(7);
         }
     }

@@ -284,6 +284,35 @@ __device__ __forceinline__ void stream_operands(LoadFn load, BodyFn body) {
 // (a dependent v_mfma_f32_32x32x2_f32 must otherwise issue in the exact cycle its predecessor retires;
 // any instruction slipped in between -- an operand load, a wait -- idles the matrix pipe), and the A
 // operands of pair-group g + DEPTH are in flight while group g computes.
+// Backward kernels: one 32-row block of an operand array (h0, h1, dz2, dz1, dz0) for one tile.  The lane that holds point p (l31, wave half h) owns rows
+// acc_chan(r, h), r = 0..15, of that point; the wgrad kernel reads pieces [octet p >> 3][k-lane (p >> 2) & 1][row][slot p & 3].
+// Stored straight from the registers that is sixteen 4-byte stores per block whose 64 lanes hit sixteen different 16-byte
+// pieces -- 199-263 such stores per tile, ~100 cycles of the vector-memory pipe each, and every later load of the wave queues behind
+// them (vmcnt is one in-order counter).  Instead the block is transposed through 4.1 KB of the wave's LDS (pitch 33 float4 per
+// (octet, k-lane) pair: both directions conflict-free) and leaves as four 1 KB stores, one octet each, 16 bytes per lane.
+constexpr int kTrFloats = 8 * 33 * 4;            // per wave
+__device__ __forceinline__ void store_block_pieces(const __amdgpu_buffer_rsrc_t& rs, float* s_tr, unsigned blk_bytes, unsigned tile_bytes,
+                                                   const f32x16& v, int l31, int half, int lane) {
+    float* w = s_tr + ((l31 >> 2) * 33 + 4 * half) * 4 + (l31 & 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 4] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const f32x4* rd = reinterpret_cast<const f32x4*>(s_tr) + (lane >> 5) * 33 + (lane & 31);
+    f32x4 t[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) t[n] = rd[2 * n * 33];
+    // soffset stays the literal 0 and the block / octet offsets travel in the vector offset and the instruction's immediate: with
+    // an SGPR soffset the compiler's hazard recogniser assumes a 128-bit buffer store has read its data registers when it issues
+    // and lets the next VALU instruction overwrite them -- on gfx950 it has not (measured: lanes 12-15 of every 16 of the second
+    // register arrived holding the following v_pk_add's result).  With a literal soffset the required wait states are inserted.
+    const unsigned voff = 16u * (unsigned)lane + tile_bytes + blk_bytes;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) buf_store_f4(rs, voff + 1024u * (unsigned)n, 0u, t[n]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 // load(mb, tq) -> the f32x4 holding A operands of k-steps 4tq..4tq+3 of row block mb;
 // act(t) -> the B operand (activation register) of k-step t.
 template <int MB, int TQ, int DEPTH, bool ZERO_START = true, class LoadFn, class ActFn>

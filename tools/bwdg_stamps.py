@@ -36,6 +36,8 @@ d = np.diff(st, axis=1)
 names = ["point load + conv0 (+ x, h0 stores)", "conv1 + LN1 (+ h1 stores)", "mu = s.h1", "loop over the owned channels", "q = M h1, rstd2",
          "dH1", "LN1 backward (+ dz1 stores)", "dH0 = W1^T dz1 (+ dz0 stores)"]
 tot = st[:, 8] - st[:, 0]
+st9 = np.frombuffer(tb, dtype=np.uint64).reshape(n_tiles, 12).astype(np.int64)[:, 9]
+print(f"  dH0: MFMA part (to the last MFMA's issue) median {np.median(st9 - st[:, 7]):.0f}, dz0 stores {np.median(st[:, 8] - st9):.0f}")
 print(f"B={a.B}: {n_tiles} tiles (mean active points {float(n_act.float().mean()):.0f}), chain median {np.median(tot):.0f} cycles (min {tot.min()}, max {tot.max()})")
 for i, n in enumerate(names):
     print(f"  {n:40s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles  {100 * np.median(d[:, i]) / np.median(tot):5.1f} %")
