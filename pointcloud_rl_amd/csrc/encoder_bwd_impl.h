@@ -295,9 +295,10 @@ __global__ __launch_bounds__(512, 2) void encoder_bwd_points_cloud_kernel(const 
     float2* s_pt = reinterpret_cast<float2*>(s_xh + kC3);                         // [256] per active point: (sum dx, sum dx * xhat)
     int* s_first = reinterpret_cast<int*>(s_pt + kC3);                         // [256] sorted position where the point's run of keys starts
     float* s_w2 = reinterpret_cast<float*>(s_first + kC3);
-    // bf16 build: the conv2 image takes half of its room; the rest holds the waves' transposition scratch (store_block_pieces)
-    float* s_tr = s_w2 + kC3 * kC2 / 2 + (threadIdx.x >> 6) * kTrFloats;
-    constexpr bool WS = BF16 && 8 * kTrFloats <= kC3 * kC2 / 2;      // whole-piece stores: the scratch of 8 waves fits behind the bf16 image
+    // whole-piece stores (store_block_pieces) stay off here: this 256-register build already spills and measured 386 -> 503 us with
+    // them at 512 x 1200 clouds (the tile-dealing kernel below gains: 162 -> 152 us at 256 x 1024)
+    float* s_tr = nullptr;
+    constexpr bool WS = false;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
@@ -671,7 +672,8 @@ __global__ __launch_bounds__(64 * NW, 1) void encoder_bwd_points_kernel(const Bw
     float* s_b0 = s_ln2 + 2 * kC3;
     float* s_w0 = s_b0 + C1;
     float* s_w2 = s_w0 + MB1 * T0 * 64;
-    float* s_tr = s_w2 + kC3 * kC2 / 2 + (threadIdx.x >> 6) * kTrFloats;       // bf16 build only (see the cloud kernel)
+    // bf16 build: the conv2 image takes half of its room; the rest holds the waves' transposition scratch (store_block_pieces)
+    float* s_tr = s_w2 + kC3 * kC2 / 2 + (threadIdx.x >> 6) * kTrFloats;
     constexpr bool WS = BF16 && 8 * kTrFloats <= kC3 * kC2 / 2;      // whole-piece stores: the scratch of 8 waves fits behind the bf16 image
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -1355,7 +1357,8 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         // measured (tools/bench_encoder.py, PCRL_BWD_TILE_MODE=0/1): dealing single tiles over all SIMDs also wins for large
         // batches of the c1 = 64 shapes (B 256: 212 -> 207 us, B 1024: 822 -> 739 us); with c1 = 128 the two schedules tie
         // (946 vs 960 us at B 1024, N 1200) and the one-workgroup-per-cloud kernel stays
-        const bool automatic = p.cl.B < num_cus() || w->c1 <= 64;
+        // (the bf16 build's tile kernel writes whole operand pieces: 512 x 1200 clouds with c1 = 128, 384 us by clouds, 366 us by tiles)
+        const bool automatic = p.cl.B < num_cus() || w->c1 <= 64 || mode == 1;
         p.tile_mode = (forced >= 0 ? forced != 0 : automatic) && p.cl.B <= kMaxTileModeClouds ? 1 : 0;
     }
     p.parts = 1;
