@@ -630,7 +630,10 @@ static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool
     // a row-contiguous operand read from LDS four bytes at a time (dX) -- are faster as 32x32 split-K tiles at four
     // workgroups per CU -- unless the caller forces the path (force_tile64: tests exercise every orientation).
     const bool big = d->M >= 48 && d->N >= 48 && d->K >= 64;
-    const bool pays = force_tile64 || (a_kc && b_kc && d->K >= 512);
+    // ... and the data gradient (dY k-contiguous, W row-contiguous) once the batch gives it several hundred tiles of its own
+    // (two heads of 1 024 rows: 43.6 us staged against 56.2 us; 512 rows tie; 256 rows lose 25.6 to 15.2)
+    const long long own_tiles64 = (long long)((d->M + 63) / 64) * ((d->N + 63) / 64) * d->batch;
+    const bool pays = force_tile64 || (a_kc && b_kc && d->K >= 512) || (a_kc && b_rc && d->K >= 512 && own_tiles64 >= 384);
     p.cfg = (want_tile64 && big && pays && (a_kc || a_rc) && (b_kc || b_rc)) ? 1 : 0;
     p.a_rc = !a_kc; p.b_rc = !b_kc;
     const int t = p.cfg ? 64 : 32;

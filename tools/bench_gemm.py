@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloud_rl_amd import hip
 
 dev = torch.device("cuda", 0)
-M, H = 256, 1024
+M, H = int(os.environ.get("GEMM_M", "256")), 1024
 
 
 def t(*shape):
