@@ -258,6 +258,9 @@ __device__ unsigned long long g_bwdg_wstamps[4096][8];
 // matrix cores they cost less than this form's fp32 M h1 -- measured 157 vs 163 us at B = 256.)
 // Four waves per workgroup = one per SIMD (512 registers each: nothing spills and xhat1 stays in registers).
 constexpr int kBwdgWaves = 4;
+#ifndef PCRL_BWDG_RING
+#define PCRL_BWDG_RING 6      // 16-byte operand loads in flight per row block of a pair, in groups of 8 MFMAs (dense_layer_mfma_stream)
+#endif
 #ifndef PCRL_BWDG_W1NB
 #define PCRL_BWDG_W1NB(MB1) ((MB1) >= 2 ? 2 : 1)
 #endif
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
                 a1, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1s(k) + (mb * (C1 / 16) + g) * 256)); },
                 [&](int t) { return a0[t >> 4][t & 15]; });
         else
-            dense_layer_mfma<MB2, C1 / 8, 6>(
+            dense_layer_mfma_stream<MB2, C1 / 8, PCRL_BWDG_RING>(
                 a1, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                 [&](int t) { return a0[t >> 4][t & 15]; });
         if (half == 0) {   // B operand of the conv0 weight gradient: rows = input channels, row C = 1 (bias)
@@ -527,9 +530,14 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
                 d0, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1ts(k) + (mb * (kC2 / 16) + g) * 256)); },
                 [&](int t) { return q[t >> 4][t & 15]; });
         else
-            dense_layer_mfma<MB1, kC2 / 8, 6>(
-                d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
-                [&](int t) { return q[t >> 4][t & 15]; });
+            if constexpr (MB1 % 2 == 0)
+                dense_layer_mfma_stream<MB1, kC2 / 8, PCRL_BWDG_RING>(
+                    d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
+                    [&](int t) { return q[t >> 4][t & 15]; });
+            else
+                dense_layer_mfma<MB1, kC2 / 8, 6>(
+                    d0, [&](int mb, int tq) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1t() + (mb * (kC2 / 8) + tq) * 256)); },
+                    [&](int t) { return q[t >> 4][t & 15]; });
         PCRL_GSTAMP(9);
 #pragma unroll
         for (int mb = 0; mb < MB2; ++mb) store_block_pieces(r_ops, s_tr, gop_off(OL.dz1(), mb, 0, OL.NP), tile_bytes, q[mb], l31, half, lane);

@@ -364,6 +364,39 @@ __device__ __forceinline__ void dense_layer_mfma(f32x16 (&acc)[MB], LoadFn load,
     }
 }
 
+// dense_layer_mfma for operands that stream from L2 (MB even): the same pair loop, with the scheduler forbidden to move anything across
+// the points where the ring is refilled.  Left free, the machine scheduler sinks every load to just in front of its first use (it
+// minimises live registers even where 512 are available): the ISA of the backward's conv1 showed `buffer_load x2; s_waitcnt vmcnt(1);
+// mfma; s_waitcnt vmcnt(0); mfma ...` -- a ring of depth one, an L2 round trip exposed per 8 MFMAs -- whatever DEPTH said.
+template <int MB, int TQ, int DEPTH, class LoadFn, class ActFn>
+__device__ __forceinline__ void dense_layer_mfma_stream(f32x16 (&acc)[MB], LoadFn load, ActFn act) {
+    static_assert(MB % 2 == 0, "row blocks are processed in pairs");
+    constexpr int NG = (MB / 2) * TQ;
+    f32x4 ra[DEPTH], rb[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < NG) { ra[d] = load(2 * (d / TQ), d % TQ); rb[d] = load(2 * (d / TQ) + 1, d % TQ); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const f32x4 wa = ra[g % DEPTH], wb = rb[g % DEPTH];
+        const int mb = 2 * (g / TQ), tq = g % TQ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float b = act(4 * tq + j);
+            const bool first = tq == 0 && j == 0;
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], b, first ? zero : acc[mb], 0, 0, 0);
+            acc[mb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[j], b, first ? zero : acc[mb + 1], 0, 0, 0);
+        }
+        if (g + DEPTH < NG) {       // refill the slot just consumed, DEPTH groups ahead of its use
+            ra[g % DEPTH] = load(2 * ((g + DEPTH) / TQ), (g + DEPTH) % TQ);
+            rb[g % DEPTH] = load(2 * ((g + DEPTH) / TQ) + 1, (g + DEPTH) % TQ);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Mixed-precision dense layer: acc[mb] (+)= W[32mb.., :] . act with bf16 operands on v_mfma_f32_32x32x16_bf16 and fp32
 // accumulation.  One MFMA contracts 16 input channels: the 8 accumulator registers 8g..8g+7 of BOTH wave halves, i.e.
 // channels acc_chan(8g + r, h) -- the weight image (PackedLayout::w1b/w2b) is packed in exactly that order, so the

@@ -41,6 +41,12 @@ print(f"  dH0: MFMA part (to the last MFMA's issue) median {np.median(st9 - st[:
 print(f"B={a.B}: {n_tiles} tiles (mean active points {float(n_act.float().mean()):.0f}), chain median {np.median(tot):.0f} cycles (min {tot.min()}, max {tot.max()})")
 for i, n in enumerate(names):
     print(f"  {n:40s} median {np.median(d[:, i]):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f} cycles  {100 * np.median(d[:, i]) / np.median(tot):5.1f} %")
+# between two tiles of one wave (item -> item + 4 * 256): the loop header (cloud search, n_act / act / own loads) and whatever the
+# last stores of the previous tile hold up
+stride = 4 * 256
+if n_tiles > stride:
+    gap = st[stride:n_tiles, 0] - st[:n_tiles - stride, 8]
+    print(f"  between a wave's consecutive tiles (end of chain -> first stamp of the next): median {np.median(gap):.0f}  p90 {np.percentile(gap, 90):.0f} cycles")
 ws = np.frombuffer(wb, dtype=np.uint64).reshape(n_waves, 8).astype(np.int64)[:, :7]
 dw = np.diff(ws, axis=1)
 wn = ["norm1 sums + staging (to the barrier)", "dW1 blocks", "G block pairs", "(v, u) / dW0 blocks", "wait at the barrier", "S rows"]
