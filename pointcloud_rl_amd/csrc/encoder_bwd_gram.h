@@ -261,6 +261,9 @@ constexpr int kBwdgWaves = 4;
 #ifndef PCRL_BWDG_RING
 #define PCRL_BWDG_RING 6      // 16-byte operand loads in flight per row block of a pair, in groups of 8 MFMAs (dense_layer_mfma_stream)
 #endif
+#ifndef PCRL_BWDG_WRING
+#define PCRL_BWDG_WRING 4     // octets of dW1 operands in flight per wave of the wgrad kernel (wgrad_blocks_stream)
+#endif
 #ifndef PCRL_BWDG_W1NB
 #define PCRL_BWDG_W1NB(MB1) ((MB1) >= 2 ? 2 : 1)
 #endif
@@ -551,6 +554,46 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
     }
 }
 
+// wgrad_blocks (encoder_bwd_impl.h) for two operands that stream from L2, through one buffer resource over the cloud's operand
+// region: out[32 x 32 block (mb, nb0 + n)] = sum over slots of A[32 mb + i][slot] * Bm[32 (nb0 + n) + j][slot].  D octets of operands
+// are in flight; the refills are UNCONDITIONAL (an octet past the end reads through an out-of-range offset: zeros, no memory request)
+// and pinned behind the MFMAs that freed their registers.  With conditional refills the compiler's wait bookkeeping assumed the
+// shortest queue and drained it after every octet (`7 mfma; vmcnt(1); 1 mfma; vmcnt(0)`): a ring of depth one whatever D said.
+template <int NB, int D>
+__device__ __forceinline__ void wgrad_blocks_stream(const __amdgpu_buffer_rsrc_t& rs, unsigned a_bytes, unsigned b_bytes, unsigned b_block_bytes,
+                                                    int n_oct, int lane, f32x16 (&acc)[NB]) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+    const unsigned lane16 = 16u * (unsigned)lane;
+    f32x4 ar[D], br[D][NB];
+    auto fetch = [&](int q, f32x4& a, f32x4 (&b)[NB]) {
+        const unsigned off = q < n_oct ? lane16 + 1024u * (unsigned)q : 0x80000000u;      // one octet = 64 lanes x 16 bytes
+        a = buf_load_f4(rs, off, a_bytes);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) b[n] = buf_load_f4(rs, off, b_bytes + (unsigned)n * b_block_bytes);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(d, ar[d], br[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int q0 = 0; q0 < n_oct; q0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const f32x4 a = ar[d];
+            f32x4 bv[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) bv[n] = br[d][n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[n][j], acc[n], 0, 0, 0);
+            fetch(q0 + d + D, ar[d], br[d]);       // past the end: zeros, which the MFMAs above add harmlessly
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // ---- wgrad: per cloud --------------------------------------------------------------------------------------------------
 // Two 32 x 32 blocks of G that share their A operand: sum over slots of (a_slot h1[32 mb + i][slot]) h1[32 nb + j][slot], both
 // operands from the LDS copy of the cloud's h1 pieces; the reads of the next octet are issued before this octet's MFMAs.
@@ -626,6 +669,7 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
     for (int item = blockIdx.x; item < p.cl.B * P; item += gridDim.x) {
         const int b = item / P, part = item - b * P;
         const float* ops = p.ops + (long long)b * OL.total();
+        const __amdgpu_buffer_rsrc_t r_ops = make_rsrc(ops, 4u * (unsigned)OL.total());
         float* pw = p.pw + (long long)b * p.pw_stride;
         float* px = pw + GL.total();
         const int n_tiles = (p.n_act[b] + 31) / 32, n_oct = n_tiles * 4;
@@ -704,8 +748,8 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
             f32x16 acc[W1NB];
             constexpr int per_row = MB1 / W1NB;
             // both operands stream from L2: six octets in flight (three left the matrix pipe waiting two thirds of the time)
-            wgrad_blocks<W1NB, const f32x4*, 6>(ops + OL.dz1(), reinterpret_cast<const f32x4*>(ops + OL.h0()), 32 * 64, u / per_row,
-                                                W1NB * (u % per_row), n_oct, lane, acc);
+            wgrad_blocks_stream<W1NB, PCRL_BWDG_WRING>(r_ops, 4u * (unsigned)(OL.dz1() + (u / per_row) * OL.blk()),
+                                                       4u * (unsigned)(OL.h0() + W1NB * (u % per_row) * OL.blk()), 4u * (unsigned)OL.blk(), n_oct, lane, acc);
 #pragma unroll
             for (int n = 0; n < W1NB; ++n) store_tile(pw + GL.w1(), C1, u / per_row, W1NB * (u % per_row) + n, C1, acc[n], lane);
         }
