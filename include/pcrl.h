@@ -182,7 +182,7 @@ int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t c1, int32_
  * the forward left at zero are dropped up front (n_active then counts the distinct argmax points of the remaining channels),
  * and the last layer's recompute and W2^T dz2 GEMM are replaced by one C2 -> C2 layer with M = W2^T W2 -- same gradients to
  * ~5e-7 of each tensor's largest entry, 25-35 % less time.  Without it the round-2 kernels run (n_active = all distinct argmax
- * points).  The f32split entry point takes the same path; the bf16 one always runs the round-2 kernels. */
+ * points).  The f32split and bf16 entry points take the same path (see pcrl_encoder_bwd_bf16). */
 int pcrl_encoder_bwd_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
                          const int32_t* argmax, const float* grad_pooled, const float* pooled,
@@ -203,11 +203,15 @@ int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_
                                   const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                   float* grads, int32_t* n_active,
                                   void* workspace, size_t workspace_bytes, void* stream);
-/* Backward of pcrl_encoder_fwd_bf16: the forward of the active points is recomputed with the same bf16 contractions (so
+/* Backward of pcrl_encoder_fwd_bf16.  With `pooled` (and up to 2 048 clouds; PCRL_BWD_BF16_GRAM, default 1): the fp32 Gram-form
+ * backward of pcrl_encoder_bwd_f32 at the bf16 forward's routing (its argmax, its pooled > 0 decisions) -- the exact fp32 gradient
+ * along that routing (tests: 2e-4 of each tensor's largest entry against fp32 autograd routed the same way; up to ~6e-2 from autograd
+ * through an emulation of the bf16 roundings, which is what bf16 operands change in the two lower layers).  Without `pooled`, or with
+ * PCRL_BWD_BF16_GRAM=0, the round-2 kernels: the forward of the active points is recomputed with the same bf16 contractions (so
  * LayerNorm inputs, ReLU masks and argmax relations are the forward's) and the two data-gradient GEMMs contract bf16 too
  * (gradients rounded as they enter, fp32 accumulate); the weight-gradient GEMMs are fp32 on the unrounded operands and the
- * result is the gradient w.r.t. the fp32 master weights (roundings straight-through).  `argmax` must come from the bf16
- * forward. */
+ * result is the gradient w.r.t. the fp32 master weights (roundings straight-through; within 3e-2 of the emulation's autograd).
+ * `argmax` must come from the bf16 forward. */
 int pcrl_encoder_bwd_bf16(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                          const pcrl_encoder_weights* w, const void* packed,
                          const int32_t* argmax, const float* grad_pooled, const float* pooled,

@@ -210,6 +210,17 @@ def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, 
         assert np.abs(g - r).max() / scale < 3e-2, f"{name}: {np.abs(g - r).max() / scale:.3e}"
     # bitwise reproducible
     assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True))
+    # With the forward's pooled values (what the agents pass) the bf16 mode runs the fp32 Gram-form backward at the bf16 forward's
+    # routing: the fp32 gradient along that argmax (PCRL_BWD_BF16_GRAM=0 keeps the kernels checked above)
+    import os
+    if os.environ.get("PCRL_BWD_BF16_GRAM", "1") != "0":
+        flat_g = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True, pooled=pooled)
+        got_g = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat_g, ew).items()}
+        ref32, _, _ = torch_reference_grads(obs, w, gpool, route=argmax.cpu().numpy())
+        for name in NAMES:
+            g, r = got_g[name].reshape(-1), ref32[name].reshape(-1)
+            scale = max(np.abs(r).max(), 1e-6)
+            assert np.abs(g - r).max() / scale < 2e-4, f"{name}: {np.abs(g - r).max() / scale:.3e} against fp32 autograd at the bf16 routing"
 
 
 def test_bwd_zero_gamma_falls_back_to_the_dense_path(cuda):

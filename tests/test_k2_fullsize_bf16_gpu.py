@@ -7,7 +7,8 @@ not fit a CPU test):
   * the virtual repeat (row_div) with per-row jitter equals the materialised repeat;
   * a slice of the launch equals the same clouds launched alone, and that slice is within the emulation's tolerance;
   * backward at the same geometry: bitwise reproducible, linear in the upstream gradient, equal on a slice to the slice's own
-    launch (per-cloud partial sums are independent) and within 3e-2 of autograd through the emulation there."""
+    launch (per-cloud partial sums are independent); there it is the fp32 gradient at the bf16 forward's routing (2e-4) and within
+    8e-2 of autograd through the emulation."""
 import numpy as np
 import pytest
 import torch
@@ -105,7 +106,26 @@ def test_k2_backward_full_size_properties(cuda):
     t, h2 = _bf16_reference_grads(obs_sl, w_np, None)
     picked = torch.gather(h2, 2, a_sl.cpu().long()[:, :, None])[:, :, 0]
     (picked * g1[sel].cpu()).sum().backward()
+    # The bf16 mode's backward is (default, PCRL_BWD_BF16_GRAM=1) the fp32 Gram-form kernel at the bf16 forward's routing (argmax,
+    # pooled > 0): the EXACT fp32 gradient at that routing (measured < 5e-5 of each tensor's largest entry), which differs from autograd
+    # through the rounding emulation by what bf16 operands change in the two recomputed layers (measured up to 5.8e-2, on norm1.bias /
+    # conv0.bias).  The round-2 bf16 kernels (PCRL_BWD_BF16_GRAM=0) are the mirror image: within 3e-3 of the emulation, up to 5.8e-2
+    # from the fp32 gradient.
+    import os
+    from test_encoder_bwd_gpu import torch_reference_grads
+    gram = os.environ.get("PCRL_BWD_BF16_GRAM", "1") != "0"
+    ref32, _, _ = torch_reference_grads(obs_sl, w_np, g1[sel].cpu().numpy(), route=a_sl.cpu().numpy())
+    worst = {}
     for name, k in NAMES.items():
         r = t[k].grad.numpy().reshape(-1)
         err = np.abs(got[name].reshape(-1) - r).max() / max(np.abs(r).max(), 1e-6)
-        assert err < 3e-2, f"{name}: {err:.3e}"
+        r32 = ref32[name].reshape(-1)
+        err32 = np.abs(got[name].reshape(-1) - r32).max() / max(np.abs(r32).max(), 1e-6)
+        worst[name] = (round(float(err), 5), round(float(err32), 5))
+    print("K2 slice, encoder gradient error (vs bf16 emulation, vs fp32 at the same routing):", worst)
+    for name, (err, err32) in worst.items():
+        if gram:
+            assert err32 < 2e-4, f"{name}: {err32:.3e} of the largest entry against fp32 autograd at the same routing"
+            assert err < 8e-2, f"{name}: {err:.3e} of the largest entry against autograd through the bf16 emulation"
+        else:
+            assert err < 3e-2, f"{name}: {err:.3e} of the largest entry against autograd through the bf16 emulation"
