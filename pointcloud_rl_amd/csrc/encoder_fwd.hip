@@ -132,6 +132,9 @@ struct FwdParams {
 // fed to the next layer) with fp32 accumulation; conv0, both LayerNorms and the max-pool are unchanged fp32 code.
 // SPLIT (experimental, never together with BF16): conv1 / conv2 in ~fp32 accuracy on the bf16 matrix cores, every operand split
 // into three bf16 terms (dense_layer_split); conv2's hi and mid weight images live in LDS, the lo image streams from L2.
+#ifndef PCRL_FWD_RING
+#define PCRL_FWD_RING 3
+#endif
 #ifndef PCRL_FWD_W1_LDS
 #define PCRL_FWD_W1_LDS 1
 #endif
@@ -250,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                     a1, [&](int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1b() + (mb * (C1 / 16) + g) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
             else
-                dense_layer_mfma<MB2, C1 / 8, 3>(
+                // (the L2-fed row blocks' operand ring is pinned: left to the scheduler every load sank to just in front of its wait)
+                dense_layer_mfma_stream<MB2, C1 / 8, PCRL_FWD_RING>(
                     a1, [&](int mb, int tq) {
                         return mb < W1L ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane]
                                         : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
