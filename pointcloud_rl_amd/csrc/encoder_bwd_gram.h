@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
 // shortest queue and drained it after every octet (`7 mfma; vmcnt(1); 1 mfma; vmcnt(0)`): a ring of depth one whatever D said.
 template <int NB, int D>
 __device__ __forceinline__ void wgrad_blocks_stream(const __amdgpu_buffer_rsrc_t& rs, unsigned a_bytes, unsigned b_bytes, unsigned b_block_bytes,
-                                                    int n_oct, int lane, f32x16 (&acc)[NB]) {
+                                                    int n_oct, int lane, f32x16 (&acc)[NB], unsigned b_dead = 0u) {
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -572,7 +572,7 @@ __device__ __forceinline__ void wgrad_blocks_stream(const __amdgpu_buffer_rsrc_t
         const unsigned off = q < n_oct ? lane16 + 1024u * (unsigned)q : 0x80000000u;      // one octet = 64 lanes x 16 bytes
         a = buf_load_f4(rs, off, a_bytes);
 #pragma unroll
-        for (int n = 0; n < NB; ++n) b[n] = buf_load_f4(rs, off, b_bytes + (unsigned)n * b_block_bytes);
+        for (int n = 0; n < NB; ++n) b[n] = buf_load_f4(rs, off | b_dead, b_bytes + (unsigned)n * b_block_bytes);   // b_dead: lanes whose B rows read as zero
     };
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch(d, ar[d], br[d]);
@@ -621,32 +621,13 @@ __device__ __forceinline__ void gram_pair(const f32x4* s_h1, const f32x4* s_a4, 
 
 // conv0.weight [C1][C] and conv0.bias (column C of the x|1 operand), row block mb: wgrad_conv0 of encoder_bwd_impl.h with the
 // operands of the next three octets in flight (its load -> wait -> 4 MFMAs loop paid an L2 round trip per octet).
-__device__ __forceinline__ void wgrad_conv0_pipelined(const BwdParams& p, const float* ops, float* pw, const GradLayout& GL, int dz0_off,
-                                                      int xb_off, int mb, int n_oct, int lane) {
-    f32x16 acc;
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(ops + dz0_off) + (long long)mb * 32 * 64 + lane;
-    const f32x4* b4 = reinterpret_cast<const f32x4*>(ops + xb_off) + lane;
-    const bool live = (lane & 31) <= p.cl.C;      // rows of the x|1 block beyond C are never written: masked out of the B operand
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    constexpr int D = 6;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 ar[D], br[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < n_oct) { ar[d] = a4[d * 64]; br[d] = live ? b4[d * 64] : zero4; }
-    for (int q0 = 0; q0 < n_oct; q0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int q = q0 + d;
-            if (q < n_oct) {
-                const f32x4 a = ar[d], bv = br[d];
-                if (q + D < n_oct) { ar[d] = a4[(q + D) * 64]; br[d] = live ? b4[(q + D) * 64] : zero4; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv[j], acc, 0, 0, 0);
-            }
-        }
-    }
+__device__ __forceinline__ void wgrad_conv0_pipelined(const BwdParams& p, const __amdgpu_buffer_rsrc_t& rs, int blk_floats, float* pw, const GradLayout& GL,
+                                                      int dz0_off, int xb_off, int mb, int n_oct, int lane) {
+    // rows of the x|1 block beyond C are never written: those lanes read their B operand through an out-of-range offset (zeros)
+    const bool live = (lane & 31) <= p.cl.C;
+    f32x16 accs[1];
+    wgrad_blocks_stream<1, PCRL_BWDG_WRING>(rs, 4u * (unsigned)(dz0_off + mb * blk_floats), 4u * (unsigned)xb_off, 0u, n_oct, lane, accs, live ? 0u : 0x80000000u);
+    const f32x16 acc = accs[0];
     const int col = lane & 31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -762,7 +743,7 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
             store_tile(px + GX.G(), kC2, mb, nb0 + 1, kC2, acc[1], lane);
         }
         PCRL_WSTAMP(3);
-        for (int t = g0; t < nW0; t += G8) wgrad_conv0_pipelined(p, ops, pw, GL, OL.dz0(), OL.xb(), t, n_oct, lane);
+        for (int t = g0; t < nW0; t += G8) wgrad_conv0_pipelined(p, r_ops, OL.blk(), pw, GL, OL.dz0(), OL.xb(), t, n_oct, lane);
         PCRL_WSTAMP(4);
         // What needs only the LDS copy -- v, u (2 C2 dot products over the active slots; as MFMA blocks they cost C2 / 32 blocks for two
         // useful rows) and the sparse rows of dW2, S[c][j] = (rstd2 dx)_c h1[slot(c)][j] -- is cut into 1 024-element chunks that the
