@@ -199,6 +199,7 @@ class FusedStep:
         # default keeps the step one chain.
         self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
         self._forked = False
+        self.policy_tail_max = int(__import__("os").environ.get("PCRL_POLICY_TAIL_MAX", "4096"))
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -249,7 +250,10 @@ class FusedStep:
         act = self._buf(f"pi_act_{tag}", M, A)
         nlp = self._buf(f"pi_nlp_{tag}", M)
         saved = self._buf(f"pi_saved_{tag}", M, 2 * A) if save else None
-        if self.tails:                   # two layers as GEMMs, the last one inside the head kernel
+        # the head kernel is one wave per row (or four) streaming all 2 A rows of the last layer from L2: a latency chain that
+        # beats GEMM + a separate head launch only while rows x outputs is small (K1: 256 x 12 -> 8.6 us; K3: 1 024 x 44 -> 34.5 us
+        # against ~13 us for the two launches)
+        if self.tails and M * 2 * A <= self.policy_tail_max:   # two layers as GEMMs, the last one inside the head kernel
             launch_layers(mlp_forward_descs(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)[:2])
             eps_in = head._standard_normal(eps) if head.noise_override else None
             hip.policy_tail_fwd(h2, M, H, self.pi.W(2), self.pi.Bv(2), A, eps_in, self.seed, a.critic_optim.step_counter,
