@@ -91,6 +91,10 @@ class RandomJitterPoints(_PointAug):
         self.calls = 0
         self._counter = None           # device int64 call counter: a hipGraph replay must draw fresh noise
         self.noise_override = []       # parity tests queue explicit noise tensors here (consumed in call order)
+        # Inside an update step whose replay sampling is a device launch the step's own draw counter (DeviceReplay.state[0], advanced
+        # by that launch) is the Philox offset and the calls of the step differ by their seed: no per-call `counter += 1` / `clone()`
+        # (two 4-5 us ATen launches each; K2 has two calls per step).  Set / cleared by the agent around the step (`begin_step`).
+        self._shared, self._slot = None, 0
 
     def __call__(self, data):
         self._check(data)
@@ -99,6 +103,10 @@ class RandomJitterPoints(_PointAug):
             noise = self.noise_override.pop(0)
             assert tuple(noise.shape) == _batch_shape(data), f"{tuple(noise.shape)} vs {_batch_shape(data)}"
             out.aug["jitter_noise"] = noise.to(device=data["xyz"].device, dtype=torch.float32).contiguous()
+        elif self._shared is not None and self._shared.device == data["xyz"].device:
+            self._slot += 1
+            out.aug.update(jitter_range=self.jitter_range, seed=(self.seed + 0x9E3779B97F4A7C15 * self._slot) & 0x7FFFFFFFFFFFFFFF,
+                           offset=self.calls, offset_tensor=self._shared)
         else:
             dev = data["xyz"].device
             if self._counter is None or self._counter.device != dev:
@@ -108,6 +116,12 @@ class RandomJitterPoints(_PointAug):
                            offset_tensor=self._counter.clone())   # this call's own slot, filled on the device
         self.calls += 1
         return out
+
+    def begin_step(self, shared_counter):
+        """shared_counter: device int64 [1] tensor that changes exactly once per update step before the step's encoder launches
+        (None: every call advances its own counter, as outside update steps)."""
+        assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1 and shared_counter.is_cuda)
+        self._shared, self._slot = shared_counter, 0
 
     def __repr__(self):
         return f"{type(self).__name__}(jitter_range={self.jitter_range},"

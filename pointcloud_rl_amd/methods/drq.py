@@ -9,6 +9,8 @@ trains on [augmented s_b, plain s_b] pairs against ONE target per sample compute
 plain observations -- no shipped config turns it on, so it runs on the HIP encoder + autograd-heads path, not on the
 fused launch sequence.
 """
+import os
+
 import torch
 
 from ..augmentations import build_data_augmentations
@@ -124,5 +126,20 @@ class DrQ(SAC):
             next_obs = self._augment(batch["next_obs"], virtual=True)
         return (obs, next_obs, batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), dict(
             group=self.num_aug, repeat=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
+
+    def update_parameters(self, memory, updates):
+        """SAC's, with the jitter augmentations told where the step's device draw counter lives: a replay whose sampling is one
+        device launch (`DeviceReplay.graph_sampling`) advances `state[0]` once per sample -- the Philox offset of every jitter
+        call of this step (calls differ by seed), instead of a counter increment + clone per call."""
+        jitters = [t for t in (self.obs_aug.transforms if self.obs_aug is not None else []) if hasattr(t, "begin_step")]
+        shared = memory.state[:1] if (jitters and getattr(memory, "graph_sampling", False) and torch.is_tensor(getattr(memory, "state", None))
+                                      and os.environ.get("PCRL_JITTER_SHARED_COUNTER", "1") == "1") else None
+        for t in jitters:
+            t.begin_step(shared)
+        try:
+            return super().update_parameters(memory, updates)
+        finally:
+            for t in jitters:
+                t.begin_step(None)
 
     _process_sampled_obs = False        # drq.py:46-49 samples without process_obs; update_parameters itself is SAC's

@@ -672,3 +672,28 @@ def test_graph_replayed_acting_equals_the_eager_launches_and_follows_the_paramet
     samples = [agent(obs, mode="explore") for _ in range(6)]
     assert len(fa.graphs) == 3 and all(not torch.equal(samples[i], samples[i + 1]) for i in range(3, 5))
     assert all(bool(torch.isfinite(s_).all()) and float(s_.abs().max()) <= 1.0 + 1e-6 for s_ in samples)
+
+
+def test_jitter_shares_the_steps_device_counter(cuda):
+    """Inside an update step fed by a device-sampling replay the jitter calls take the replay's draw counter as their Philox offset
+    (no per-call counter launch) and differ by seed; outside a step every call advances its own counter as before."""
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.augmentations import RandomJitterPoints
+    aug = RandomJitterPoints(main_key="xyz", req_keys=["xyz"], jitter_range=[-0.01, 0.01], seed=5)
+    obs = {"xyz": torch.randn(4, 3, 64, device=cuda)}
+    shared = torch.full((3,), 7, dtype=torch.int64, device=cuda)[:1]
+    aug.begin_step(shared)
+    a, b = aug(obs), aug(obs)
+    assert a.aug["offset_tensor"].data_ptr() == shared.data_ptr() == b.aug["offset_tensor"].data_ptr()
+    assert a.aug["seed"] != b.aug["seed"] and a.aug["seed"] != aug.seed
+    xa = hip.augment_xyz(obs["xyz"], jitter_range=aug.jitter_range, seed=a.aug["seed"], offset=0, offset_tensor=shared)
+    xb = hip.augment_xyz(obs["xyz"], jitter_range=aug.jitter_range, seed=b.aug["seed"], offset=0, offset_tensor=shared)
+    assert not torch.equal(xa, xb)                                   # two calls of one step: independent noise
+    shared += 1                                                      # the next step's sampling launch
+    xa2 = hip.augment_xyz(obs["xyz"], jitter_range=aug.jitter_range, seed=a.aug["seed"], offset=0, offset_tensor=shared)
+    assert not torch.equal(xa, xa2)                                  # the same (captured) call, next step: fresh noise
+    aug.begin_step(None)
+    c, d = aug(obs), aug(obs)
+    assert c.aug["seed"] == aug.seed == d.aug["seed"]
+    assert int(d.aug["offset_tensor"]) == int(c.aug["offset_tensor"]) + 1
+
