@@ -120,7 +120,7 @@ class RandomJitterPoints(_PointAug):
     def begin_step(self, shared_counter):
         """shared_counter: device int64 [1] tensor that changes exactly once per update step before the step's encoder launches
         (None: every call advances its own counter, as outside update steps)."""
-        assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1 and shared_counter.is_cuda)
+        assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1)
         self._shared, self._slot = shared_counter, 0
 
     def __repr__(self):

@@ -170,6 +170,18 @@ def test_jitter_augmentation_spec_and_override():
     assert torch.equal(aug(obs).aug["jitter_noise"], noise)
     with pytest.raises(NotImplementedError):
         RandomJitterPoints(main_key="obs/pointcloud/xyz", req_keys=["obs/pointcloud/xyz"])
+    # inside an update step: the step's shared draw counter is the offset of every call, the calls differ by seed, no counter of
+    # their own is advanced; outside again: one counter step per call
+    before = int(aug(obs).aug["offset_tensor"])
+    shared = torch.tensor([41], dtype=torch.int64)
+    aug[0].begin_step(shared)
+    a, b = aug(obs), aug(obs)
+    assert a.aug["offset_tensor"] is shared and b.aug["offset_tensor"] is shared
+    assert len({a.aug["seed"], b.aug["seed"], 7}) == 3
+    aug[0].begin_step(shared)
+    assert aug(obs).aug["seed"] == a.aug["seed"]                                 # slots restart with every step (captured descs stay valid)
+    aug[0].begin_step(None)
+    assert int(aug(obs).aug["offset_tensor"]) == before + 1
 
 
 def test_global_rot_scale_trans_matrix_semantics():
