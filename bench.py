@@ -442,7 +442,7 @@ def main():
         elapsed, nocomm_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
-        spans = timer.summary()
+        spans, span_detail = timer.summary(), timer.detail()
         n_fwd, ms_fwd = spans.get("encoder_fwd", (0, float("nan")))
         f_pt = 2.0 * (C * agent.encoder.mlp_spec[0] + agent.encoder.mlp_spec[0] * agent.encoder.mlp_spec[1] +
                       agent.encoder.mlp_spec[1] * agent.encoder.mlp_spec[2])
@@ -483,7 +483,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * agent.encoder.mlp_spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
                          "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
                          "algorithmic_flops_per_launch": flops_per_launch},
-            "kernels_ms": {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()},
+            "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
         }
         if nocomm_ms is not None:
             out["ms_per_step_nocomm"] = nocomm_ms

@@ -28,6 +28,16 @@ class KernelTimer:
         """name -> (launches, mean ms); call after torch.cuda.synchronize()."""
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.spans.items() if v}
 
+    def detail(self):
+        """name -> dict(min_ms, median_ms, max_ms): a mean far from the median marks spans that held more than
+        their kernel (an eager pass the host cannot keep ahead of, a launch queued behind another stream's work)."""
+        out = {}
+        for k, v in self.spans.items():
+            if v:
+                ms = sorted(a.elapsed_time(b) for a, b in v)
+                out[k] = dict(min_ms=ms[0], median_ms=ms[len(ms) // 2], max_ms=ms[-1])
+        return out
+
 
 class _Span:
     def __init__(self, timer, name):
