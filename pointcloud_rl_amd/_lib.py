@@ -95,6 +95,10 @@ def lib():
             raise PcrlError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C pointcloud_rl_amd/csrc)")
+        # torch first: its wheel carries its own libamdhip64, and the process must end up with ONE HIP runtime.  With this
+        # library (linked against /opt/rocm's) loaded before torch, kernels launched here fail with "no ROCm-capable device
+        # is detected" while torch's own work runs (seen with build() followed by smoke() in one process on the GPU box).
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.pcrl_last_error.restype = ctypes.c_char_p
     return _lib

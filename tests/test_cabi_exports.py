@@ -66,3 +66,16 @@ def test_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+
+
+def test_binding_loads_torch_before_the_library():
+    """One HIP runtime per process: the binding imports torch (whose wheel carries its own libamdhip64) before it maps
+    libpcrl_hip.so, whatever the caller imported first -- build() followed by smoke() in one process failed on the GPU box
+    ("no ROCm-capable device is detected" from the library's launches) when the library came first."""
+    import subprocess
+    import sys
+    code = ("import sys; from pointcloud_rl_amd import _lib; assert 'torch' not in sys.modules; "
+            "_lib.lib(); assert 'torch' in sys.modules; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
