@@ -83,18 +83,21 @@ class FlatBuffer:
         return (self.grad * self.grad).sum()
 
 
-class HipAdam:
-    """torch.optim.Adam-compatible facade over the fused flat-buffer kernel (pcrl_adam_step_f32).
+class HipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam-compatible optimizer over the fused flat-buffer kernel (pcrl_adam_step_f32).
 
-    Keeps what the reference's drivers touch: `param_groups` (one group per tensor, as
-    build_optimizer makes them), `state_dict()/load_state_dict()` in torch's format (checkpoints store
-    the optimizers under their attribute names, checkpoint_utils.py:215-237), `zero_grad()`, `step()`.
+    A real `torch.optim.Optimizer`: the reference's checkpoint code only saves / restores attributes that pass
+    `isinstance(child, Optimizer)` (checkpoint_utils.py:59-71, 226-229), and train_rl.py:392-405 calls it on the agent after
+    the first update.  Keeps what the reference's drivers touch: `param_groups` (one group per tensor, as
+    build_optimizer makes them, optimizer_utils.py:43-57), `state_dict()/load_state_dict()` in torch.optim.Adam's format,
+    `zero_grad()`, `step()`.  The moments live in two flat buffers next to the flat parameter buffer; `self.state`
+    (torch's per-parameter dict) stays empty -- `state_dict()` builds the per-parameter views on demand.
     """
 
     def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, **unused):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False)
+        super().__init__([dict(params=[p]) for p in flat.params], defaults)
         self.flat = flat
-        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False)
-        self.param_groups = [dict(self.defaults, params=[p]) for p in flat.params]
         dev = flat.data.device
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
@@ -103,6 +106,7 @@ class HipAdam:
         self.workspace = torch.empty(hip.adam_workspace_bytes(flat.data.numel()), dtype=torch.uint8, device=dev)
 
     def zero_grad(self, set_to_none=False):
+        """Gradients are views of the flat gradient buffer the kernels write: zeroed in place, never set to None."""
         self.flat.zero_grad()
 
     def hyper(self):
@@ -120,6 +124,8 @@ class HipAdam:
         """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...).
         lr / betas / eps are kernel arguments: a launch captured in a hipGraph keeps the values it was captured with, which
         is why SAC._run_step drops its graphs when an optimizer's hyper() changes (scheduler, load_state_dict)."""
+        if callable(grad_scale):       # torch's `optimizer.step(closure)` form
+            raise NotImplementedError("HipAdam.step takes no closure")
         g = self.param_groups[0]
         self.hyper()
         return hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
@@ -130,6 +136,7 @@ class HipAdam:
         return self.flat.views(flat_tensor)
 
     def state_dict(self):
+        """torch.optim.Adam's layout: {"state": {i: {step, exp_avg, exp_avg_sq}}, "param_groups": [{..., "params": [i]}]}."""
         step = self.step_counter.to(torch.float32).reshape(())
         state = {i: dict(step=step.clone(), exp_avg=m, exp_avg_sq=v)
                  for i, (m, v) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq)))} if int(self.step_counter.item()) > 0 else {}
@@ -137,12 +144,15 @@ class HipAdam:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
+        saved = sd.get("param_groups", [])
+        if saved and len(saved) != len(self.param_groups):
+            raise ValueError(f"loaded state dict has {len(saved)} parameter groups, the optimizer has {len(self.param_groups)}")
         for i, st in sd.get("state", {}).items():
             i = int(i)
             self._views(self.exp_avg)[i].copy_(st["exp_avg"])
             self._views(self.exp_avg_sq)[i].copy_(st["exp_avg_sq"])
             self.step_counter.fill_(int(st["step"]))
-        for g, src in zip(self.param_groups, sd.get("param_groups", [])):
+        for g, src in zip(self.param_groups, saved):
             g.update({k: v for k, v in src.items() if k != "params"})
 
 
@@ -236,9 +246,16 @@ class SAC(BaseAgent):
 
     def _prepare(self):
         """Lazily (after .to(device)) move every optimizer's parameters into flat buffers."""
-        dev = self.device
-        if dev.type != "cuda":
+        if self.device.type != "cuda":
             raise RuntimeError("pointcloud_rl_amd agents update on MI355X only (agent.to('cuda') first); there is no CPU path")
+        self._prepare_buffers()
+        self._prepare_schedule()
+
+    def _prepare_buffers(self):
+        """Flat parameter / gradient buffers and the fused optimizers that replace torch.optim.Adam (plain tensor bookkeeping:
+        runs on any device, which is how the container-side integration probe checks the reference's checkpoint functions
+        against the post-update optimizers without a GPU)."""
+        dev = self.device
         self._flat = {
             "critic": FlatBuffer(select_optimizer_params(self.critic, self._critic_optim_cfg.get("param_cfg"))),
             "actor": FlatBuffer(select_optimizer_params(self.actor, self._actor_optim_cfg.get("param_cfg"))),
@@ -257,6 +274,8 @@ class SAC(BaseAgent):
                 if old.state:                          # a checkpoint was loaded before the first update: keep moments and step
                     fused.load_state_dict(old.state_dict())
                 setattr(self, f"{name}_optim", fused)
+
+    def _prepare_schedule(self):
         # Polyak: the target's own (non-shared) parameters mirror a tail range of the critic buffer
         online = {id(p) for p in self.critic.parameters()}
         tgt = [(n, p) for n, p in self.target_critic.named_parameters() if id(p) not in online]

@@ -19,8 +19,8 @@ import torch
 
 
 def _is_optimizer(obj):
-    return isinstance(obj, torch.optim.Optimizer) or (hasattr(obj, "param_groups") and hasattr(obj, "state_dict")
-                                                      and hasattr(obj, "load_state_dict") and not isinstance(obj, torch.nn.Module))
+    """The reference's filter (checkpoint_utils.py:59, 227): torch optimizers only.  The fused HipAdam is one."""
+    return isinstance(obj, torch.optim.Optimizer)
 
 
 def get_state_dict(module, destination=None, prefix="", keep_vars=False):

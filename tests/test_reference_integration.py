@@ -30,7 +30,7 @@ def probe():
 
 def test_the_override_block_is_the_one_in_integration_md(probe):
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    assert probe["override"] in text and "register_module(name=name, force=True, module=cls)" in probe["override"]
+    assert probe["override"] in text and "pointcloud_rl_amd.bind_reference()" in probe["override"]
 
 
 def test_reference_configs_build_reference_classes_before_the_override(probe):
@@ -41,7 +41,8 @@ def test_reference_configs_build_reference_classes_before_the_override(probe):
 
 def test_reference_configs_build_through_the_overridden_registries(probe):
     """Class identity: every registry lookup the shipped pn_* configs make now lands on this package's classes."""
-    want_agent = {"sac": "pointcloud_rl_amd.methods.sac.SAC", "drq": "pointcloud_rl_amd.methods.drq.DrQ"}
+    # the registered agents are bind.py's classes: this package's agent re-based onto the reference's BaseAgent too
+    want_agent = {"sac": "pointcloud_rl_amd.bind.SAC", "drq": "pointcloud_rl_amd.bind.DrQ"}
     assert probe["extra"]["mfrl_sac_is_ours"] == "pointcloud_rl_amd.methods.sac"
     assert set(probe["after"]) >= {"sac_dmc_pn", "sac_maniskill_pn", "drq_dmc_pn_jitter", "drq_maniskill_pn_jitter"}
     for name, d in probe["after"].items():
@@ -62,3 +63,35 @@ def test_parameter_names_shapes_sharing_and_optimizer_groups_are_the_reference_s
         assert a["params"] == b["params"], name
         assert a["encoder_shared"] is True and b["encoder_shared"] is True, name
         assert a["optim_groups"] == b["optim_groups"], name
+
+
+def test_main_rl_sequence_on_the_overridden_registries(probe):
+    """run_rl.py:298-313 replayed with the reference's own objects: build_agent, the parameter counts it logs, `.to()`, the
+    `isinstance(agent, BaseAgent)` assert against the REFERENCE's base class; every driver-facing method still resolves to this
+    package's (its classes come first in the MRO)."""
+    for name, d in probe["extra"]["main_rl"].items():
+        assert d["is_base_agent"] is True, (name, d["mro"])
+        assert d["mro"][1].startswith("pointcloud_rl_amd.methods."), d["mro"]
+        assert "pyrl.utils.torch.module_utils.BaseAgent" in d["mro"], d["mro"]
+        assert d["mro"].index("pointcloud_rl_amd.utils.torch_utils.BaseAgent") < d["mro"].index("pyrl.utils.torch.module_utils.BaseAgent")
+        assert d["to_ddp_is_ours"] == "pointcloud_rl_amd.utils.torch_utils", name
+        assert d["num_trainable_parameters"] > 0 and d["size_trainable_parameters"] > 0
+
+
+def test_the_reference_s_checkpoint_functions_keep_the_optimizers_after_the_first_update(probe):
+    """checkpoint_utils.py:59-71, 226-229 only see `isinstance(child, Optimizer)`: the fused optimizers that replace
+    torch.optim.Adam at the first update are torch Optimizers, so train_rl.py:392-405's mid-training checkpoint holds all three
+    with their moments, and the reference's load_checkpoint restores them into a fresh agent (before or after ITS first update)."""
+    keys = ["actor_optim", "critic_optim", "alpha_optim"]
+    for name, d in probe["extra"]["main_rl"].items():
+        assert d["optimizers_before_update"] == dict.fromkeys(keys, "Adam"), name
+        assert d["optimizers_after_update"] == dict.fromkeys(keys, "HipAdam"), name
+        assert d["optimizers_are_torch_optimizers"] is True
+        assert sorted(d["state_dict_optim_keys_before_update"]) == sorted(keys)
+        assert sorted(d["state_dict_optim_keys_after_update"]) == sorted(keys), name
+        for k in keys:
+            n_state, n_groups, step = d["moments_in_state_dict"][k]
+            assert n_state == n_groups > 0 and step == 3.0, (name, k)
+        for stage in ("fresh", "after_update"):
+            assert d[f"reference_checkpoint_round_trip_{stage}"] is True, (name, stage, d[f"load_messages_{stage}"])
+            assert d[f"load_messages_{stage}"] == [], (name, stage)

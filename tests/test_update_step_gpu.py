@@ -255,6 +255,56 @@ def test_checkpoint_resume_continues_bit_for_bit(cuda, tmp_path):
         assert torch.equal(p, q), n
 
 
+def test_reference_style_state_dict_keeps_the_fused_optimizers(cuda):
+    """The reference's get_state_dict / load_state_dict walk `module.__dict__` and keep what passes
+    `isinstance(child, torch.optim.Optimizer)` (checkpoint_utils.py:59-71, 226-229); train_rl.py:392-405 calls them on the agent
+    AFTER updates, when the three torch.optim.Adam objects have been replaced by the fused optimizer.  The same walk, written out
+    here (the reference tree does not travel to the GPU box), must find all three with their moments, in torch.optim.Adam's
+    state_dict layout, and a genuine torch.optim.Adam must accept what they wrote."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A = 8, 96, 4
+    cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    names = ("actor_optim", "critic_optim", "alpha_optim")
+    assert all(type(getattr(agent, n)) is torch.optim.Adam for n in names)
+    mem = SyntheticReplay(B, N, A, seed=6, device=cuda)
+    for u in (1, 2, 3, 4):
+        agent.update_parameters(mem, u)
+
+    def reference_walk(module):      # checkpoint_utils.py:226-229
+        found, seen = {}, []
+        for name, child in module.__dict__.items():
+            if child is not None and isinstance(child, torch.optim.Optimizer) and id(child) not in seen:
+                seen.append(id(child))
+                found[name] = child.state_dict()
+        return found
+
+    found = reference_walk(agent)
+    assert sorted(found) == sorted(names), sorted(found)
+    for n in names:
+        opt, sd = getattr(agent, n), found[n]
+        assert type(opt).__name__ == "HipAdam"
+        assert len(sd["param_groups"]) == len(sd["state"]) == len(opt.param_groups) > 0
+        steps = {float(st["step"]) for st in sd["state"].values()}
+        assert steps == {4.0 if n == "critic_optim" else 2.0}, (n, steps)
+        assert any(float(st["exp_avg"].abs().max()) > 0 for st in sd["state"].values()), n
+        # a genuine torch.optim.Adam over the same parameters takes the dict, and hands the same moments back
+        twin = torch.optim.Adam([dict(params=g["params"]) for g in opt.param_groups], lr=opt.param_groups[0]["lr"])
+        twin.load_state_dict(sd)
+        back = twin.state_dict()
+        for i, st in sd["state"].items():
+            assert torch.equal(back["state"][i]["exp_avg"], st["exp_avg"]) and torch.equal(back["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
+        # and the fused optimizer takes a torch.optim.Adam's dict back (checkpoint_utils.py:62: child.load_state_dict(...))
+        before = (opt.exp_avg.clone(), opt.exp_avg_sq.clone())
+        opt.exp_avg.zero_(), opt.exp_avg_sq.zero_()
+        opt.load_state_dict(back)
+        assert torch.equal(opt.exp_avg, before[0]) and torch.equal(opt.exp_avg_sq, before[1]), n
+
+
 @pytest.mark.parametrize("device_replay", [False, True], ids=["fixed-batch", "device-replay"])
 def test_graph_replay_honours_a_changed_learning_rate(cuda, device_replay):
     """lr / betas / eps are kernel arguments of the fused Adam launch; graphs captured with the old values must be
