@@ -231,6 +231,23 @@ def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0, warmup_batch=0):
                       f"(box grants {usable_cpus()} of {os.cpu_count()} logical CPUs)"}
 
 
+RC_EXCHANGE_IN_GRAPH = 75      # exit code of a rank whose step failed with the all-reduces captured in its hipGraph (launcher: retry segmented)
+
+
+def exchange_in_graph_failure(err):
+    """Is `err` the failure the launcher's one retry exists for?  A data-parallel run over RCCL whose exchanging step was
+    captured whole (PCRL_CAPTURE_EXCHANGE != 0) and then either published no metrics (a collective inside the replayed graph
+    hangs) or raised from the graph launch / RCCL.  Anything else -- out of memory, assertions, argument errors -- is not."""
+    if os.environ.get("PCRL_CAPTURE_EXCHANGE", "1") == "0" or int(os.environ.get("WORLD_SIZE", "1")) < 2:
+        return False
+    if not isinstance(err, RuntimeError) or isinstance(err, (AssertionError, NotImplementedError)):
+        return False
+    text = str(err).lower()
+    if "out of memory" in text:
+        return False
+    return any(k in text for k in ("did not publish its metrics", "without publishing its metrics", "nccl", "rccl", "hipgraph", "graph", "captur"))
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of THIS process -- one per GPU, each
     with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in its environment, exactly what torch.distributed.run
@@ -281,8 +298,11 @@ def launch_ranks(args):
 
     failed, chatter, line = attempt({})
     note = None
-    if failed and args.backend == "nccl" and os.environ.get("PCRL_CAPTURE_EXCHANGE", "1") != "0":
-        print(f"bench.py launcher: {n} ranks failed with captured all-reduces ({failed}); once more with PCRL_CAPTURE_EXCHANGE=0", file=sys.stderr)
+    # Repeated ONLY on the dedicated signal: a rank left with RC_EXCHANGE_IN_GRAPH, which `__main__` uses when a step whose
+    # all-reduces are nodes of its hipGraph failed while replaying or published nothing (the one thing a one-GPU box cannot
+    # show).  Out of memory, an assertion, a missing result line or the deadline fail the run with the ranks' stderr above.
+    if any(f.endswith(f"rc {RC_EXCHANGE_IN_GRAPH}") for f in failed) and args.backend == "nccl" and os.environ.get("PCRL_CAPTURE_EXCHANGE", "1") != "0":
+        print(f"bench.py launcher: a rank reported a failure of the captured all-reduces ({failed}); once more with PCRL_CAPTURE_EXCHANGE=0", file=sys.stderr)
         note = f"first attempt (all-reduces captured in the step's hipGraph) failed: {failed}; this line is the PCRL_CAPTURE_EXCHANGE=0 run"
         failed, chatter, line = attempt({"PCRL_CAPTURE_EXCHANGE": "0"})
     for l in chatter:
@@ -518,25 +538,28 @@ def main():
             ctypes.CDLL(None).fflush(None)
             print(json.dumps(d), flush=True)
         os._exit(0)
+    if dist_on:
+        torch.distributed.barrier()        # every rank starts its watchdog at the same point
     timer_x = threading.Timer(args.extra_timeout, give_up)
     timer_x.daemon = True
     timer_x.start()
-    if plain_k1 and not dist_on and not args.no_experimental:
-        # the same step with the EXPERIMENTAL split-precision encoder forward (three-term bf16 split of the fp32 contractions,
-        # within ~3e-6 of the exact kernel, argmax exact on the reference fixtures)
-        del agent
-        torch.cuda.empty_cache()
-        extras["experimental_f32split"] = dict(
-            side_rate("k1", rank, world, device, dist_on, max(args.steps // 2, 10), max(args.warmup // 2, 30), "f32split", memory=memory, graphs=not args.no_graphs),
-            note="encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); opt-in, not the reported value")
-        agent = None
-    if plain_k1 and not args.no_extra_workloads and WORKLOADS["k3"]["B"] % world == 0:
-        # BASELINE config 4 on the same ranks: the shape the >= 6x strong-scaling target of north_star is stated for.  Each
-        # `--gpus N` line carries it, so the scaling of K3 can be read off the driver's own N = 1, 2, 4, 8 runs.
+    try:
+        held = {"agent": agent, "memory": memory}      # handed over: the extras free the headline's agent / ring before building theirs
         agent = memory = None
-        torch.cuda.empty_cache()
-        extras["config4_k3"] = dict(side_rate("k3", rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs),
-                                    workload=WORKLOADS["k3"]["desc"])
+        run_extras(args, extras, plain_k1, rank, world, device, dist_on, held)
+    except BaseException as err:           # an extra must never cost the headline: report it and print the line already built
+        import traceback
+        traceback.print_exc()
+        timer_x.cancel()
+        if rank == 0:
+            import ctypes
+            d = json.loads(line)
+            d.update(extras)
+            d["extras_error"] = f"{type(err).__name__}: {str(err).splitlines()[0] if str(err) else ''}"[:300]
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+            print(json.dumps(d), flush=True)
+        os._exit(0)                        # peers still inside a collective leave on their own watchdog
     timer_x.cancel()
     if rank == 0:
         if extras:
@@ -554,15 +577,36 @@ def main():
         print(line, flush=True)
 
 
+def run_extras(args, extras, plain_k1, rank, world, device, dist_on, held):
+    """The extra objects of a default K1 line (never the reported value); fills `extras` as it goes."""
+    memory = held.get("memory")
+    held.pop("agent", None)
+    if plain_k1 and not dist_on and not args.no_experimental:
+        # the same step with the EXPERIMENTAL split-precision encoder forward (three-term bf16 split of the fp32 contractions,
+        # within ~3e-6 of the exact kernel, argmax exact on the reference fixtures; DESIGN.md section 4.8)
+        torch.cuda.empty_cache()
+        extras["experimental_f32split"] = dict(
+            side_rate("k1", rank, world, device, dist_on, max(args.steps // 2, 10), max(args.warmup // 2, 30), "f32split", memory=memory, graphs=not args.no_graphs),
+            note="encoder conv1/conv2 and the backward data-gradient GEMMs as three-term bf16 splits (pcrl_encoder_{fwd,bwd}_f32split); opt-in, not the reported value")
+    if plain_k1 and not args.no_extra_workloads and WORKLOADS["k3"]["B"] % world == 0:
+        # BASELINE config 4 on the same ranks: the shape the >= 6x strong-scaling target of north_star is stated for.  Each
+        # `--gpus N` line carries it, so the scaling of K3 can be read off the driver's own N = 1, 2, 4, 8 runs.
+        memory = None
+        held.clear()
+        torch.cuda.empty_cache()
+        extras["config4_k3"] = dict(side_rate("k3", rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs),
+                                    workload=WORKLOADS["k3"]["desc"])
+
+
 if __name__ == "__main__":
     try:
         main()
     except SystemExit:
         raise
-    except BaseException:
+    except BaseException as err:
         # a rank that failed must END (its peers wait for it in a collective, the launcher watches exit codes): no interpreter /
         # process-group teardown that could itself wait for a wedged stream
         import traceback
         traceback.print_exc()
         sys.stderr.flush()
-        os._exit(1)
+        os._exit(RC_EXCHANGE_IN_GRAPH if exchange_in_graph_failure(err) else 1)

@@ -134,6 +134,18 @@ class DrQ(SAC):
         jitters = [t for t in (self.obs_aug.transforms if self.obs_aug is not None else []) if hasattr(t, "begin_step")]
         shared = memory.state[:1] if (jitters and getattr(memory, "graph_sampling", False) and torch.is_tensor(getattr(memory, "state", None))
                                       and os.environ.get("PCRL_JITTER_SHARED_COUNTER", "1") == "1") else None
+        # A captured encoder launch holds the counter's ADDRESS.  The shared counter is used only where a captured step would also
+        # hold the replay's sampling launch (no obs_processor, PCRL_GRAPH_SAMPLING on: SAC._run_step's rule; the same rule eagerly,
+        # so that an eager and a graph-replayed run draw the same noise), and a graph captured with one replay's counter must not
+        # be replayed against another replay (or none): a changed address drops the captured graphs.
+        if not (os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1" and self.obs_processor is None):
+            shared = None
+        if getattr(self, "_use_graphs", False):
+            ptr = None if shared is None else shared.data_ptr()
+            if self.__dict__.get("_graphs") and self.__dict__.get("_jitter_counter_ptr", ptr) != ptr:
+                self._graphs, self._graph_seen, self._fast = {}, {k: self._graph_warmup for k in self._graph_seen}, None
+                self._graph_sampler, self._graph_flag = {}, {}
+            self._jitter_counter_ptr = ptr
         for t in jitters:
             t.begin_step(shared)
         try:

@@ -156,6 +156,13 @@ class HipAdam(torch.optim.Optimizer):
             g.update({k: v for k, v in src.items() if k != "params"})
 
 
+def _is_capture_error(err):
+    """True for the errors HIP / RCCL / torch raise when an operation is not allowed while a stream is being captured
+    (hipErrorStreamCaptureUnsupported / Invalidated / ..., "operation not permitted when stream is capturing")."""
+    text = str(err).lower()
+    return "captur" in text and "out of memory" not in text
+
+
 def _plain_adam(optim):
     if type(optim) is not torch.optim.Adam:
         return None
@@ -587,13 +594,19 @@ class SAC(BaseAgent):
             elif capture_exchange():
                 # data-parallel, RCCL: the all-reduces are nodes of the step's graph (forked onto RCCL's stream by the process
                 # group, joined before each optimizer pass) -- one graph launch per step, no host work between the segments
+                host_state = self._host_step_state()
                 try:
                     captured = self._capture_whole(batch, do_actor, polyak, pre, exchanging=True)
-                except RuntimeError as err:          # a stack that refuses collectives under capture: every rank fails alike
+                except RuntimeError as err:
+                    # ONLY a stack that refuses collectives under stream capture (every rank fails alike) falls back to segments;
+                    # any other error of the step body (a kernel argument check, out of memory, an assertion) is a bug and is raised
+                    if not _is_capture_error(err):
+                        raise
                     import warnings
                     warnings.warn(f"capturing the gradient exchange failed ({str(err).splitlines()[0]}); cutting the step into segments instead")
                     os.environ["PCRL_CAPTURE_EXCHANGE"] = "0"
                     torch.cuda.synchronize()
+                    self._host_step_state(restore=host_state)    # the aborted capture ran the step body's host side once
             if captured is None:
                 captured = self._capture_segments(batch, do_actor, polyak, pre)
                 self._graphs[key] = captured
@@ -627,6 +640,17 @@ class SAC(BaseAgent):
             stream.synchronize()
             return self._finish(dict.fromkeys(names), updates, host_values=out.tolist())
         return self._finish(dict(zip(names, out.unbind(0))), updates)
+
+    def _host_step_state(self, restore=None):
+        """Host-side state one pass through the step body advances (the jitter augmentations' call counts, the fused step's
+        open-branch flag): snapshot, or put a snapshot back after a capture that was aborted half-way."""
+        jitters = [t for t in (getattr(getattr(self, "obs_aug", None), "transforms", None) or []) if hasattr(t, "calls")]
+        if restore is None:
+            return dict(calls=[t.calls for t in jitters], slots=[getattr(t, "_slot", 0) for t in jitters])
+        for t, c, sl in zip(jitters, restore["calls"], restore["slots"]):
+            t.calls, t._slot = c, sl
+        if self._fused is not None:
+            self._fused._forked = False
 
     def _invalidate_packed_after_replay(self):
         """A replayed step updated the encoder weights through raw pointers (no autograd version bump) and re-packs only

@@ -610,6 +610,50 @@ def test_synthetic_then_device_replay_does_not_freeze_the_batch(cuda):
     assert len(set(seen)) == len(seen)
 
 
+def test_drq_jitter_counter_follows_the_replay_that_feeds_the_step(cuda, monkeypatch):
+    """DrQ's fused jitter reads its Philox offset from the replay's device draw counter (`DeviceReplay.state[0]`), an ADDRESS
+    baked into the captured encoder launches.  Swapping the replay must drop the graphs captured with the old address (else the
+    noise would repeat on every step: the old replay's counter no longer advances); without the sampling launch in the graph
+    (PCRL_GRAPH_SAMPLING=0) the shared counter is not used at all.  Both ways the graph-replayed run equals the eager run fed
+    the same sequence bit for bit."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 8, 64, 4
+    schedule = [0] * 6 + [1] * 6 + [0] * 4
+
+    def run(graphs):
+        cfg = configs.drq_dmc(6, A, B, head_hidden=64, obs_aug=dict(configs.JITTER, seed=5))
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        rings = []
+        for seed in (3, 4):
+            mem = DeviceReplay(64, device=cuda, seed=seed)
+            mem.push_batch(make_batch_np(64, N, A, seed=10 + seed))
+            rings.append(mem)
+        if graphs:
+            agent.enable_graphs(warmup=1)
+        rets, ptrs = [], []
+        for u, which in enumerate(schedule, 1):
+            rets.append(agent.update_parameters(rings[which], u))
+            ptrs.append(agent.__dict__.get("_jitter_counter_ptr"))
+        return agent, rings, rets, ptrs
+
+    for sampling in ("1", "0"):
+        monkeypatch.setenv("PCRL_GRAPH_SAMPLING", sampling)
+        eager, _, rets_e, _ = run(False)
+        graph, rings, rets_g, ptrs = run(True)
+        if sampling == "1":
+            assert ptrs[5] == rings[0].state.data_ptr() and ptrs[11] == rings[1].state.data_ptr() and ptrs[-1] == rings[0].state.data_ptr()
+        else:
+            assert set(ptrs) == {None}
+        assert [r_["drq/critic_loss"] for r_ in rets_e] == [r_["drq/critic_loss"] for r_ in rets_g], sampling
+        for (n, p), (_, q) in zip(eager.named_parameters(), graph.named_parameters()):
+            assert torch.equal(p, q), (sampling, n)
+
+
 def test_sampling_state_shorter_than_the_batch_is_refused(cuda):
     """pcrl_replay_sample_gather_state is told how many words `state` holds and returns PCRL_E_ARG below 3 + B."""
     import ctypes

@@ -41,3 +41,51 @@ def test_a_rank_sees_the_launchers_rendezvous_variables(tmp_path):
     seen = sorted((tmp_path / f"rank{r}").read_text().split() for r in range(2))
     assert [s[:4] for s in seen] == [["0", "0", "2", "127.0.0.1"], ["1", "1", "2", "127.0.0.1"]]
     assert seen[0][4] == seen[1][4] and int(seen[0][4]) > 1024
+
+
+def test_the_launcher_retries_only_on_the_dedicated_signal(tmp_path):
+    """A failed first attempt is repeated with PCRL_CAPTURE_EXCHANGE=0 ONLY when a rank left with RC_EXCHANGE_IN_GRAPH (the step's
+    captured all-reduces failed while replaying); an ordinary failure (here: no GPU -> SystemExit, rc 1) is reported once, with no
+    second attempt and no note blaming the captured exchange."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by the two-rank run")
+    hook = tmp_path / "sitecustomize.py"
+    hook.write_text(
+        "import os, sys\n"
+        "if os.environ.get('WORLD_SIZE') and sys.argv and sys.argv[0].endswith('bench.py'):\n"
+        "    d = os.environ['PCRL_TEST_DIR']\n"
+        "    open(os.path.join(d, 'attempt_%s_cap%s_rank%s' % (len(os.listdir(d)), os.environ.get('PCRL_CAPTURE_EXCHANGE', '1'), os.environ['RANK'])), 'w').close()\n"
+        "    if os.environ.get('PCRL_TEST_RC') and os.environ.get('PCRL_CAPTURE_EXCHANGE', '1') != '0':\n"
+        "        os._exit(int(os.environ['PCRL_TEST_RC']))\n")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PCRL_CAPTURE_EXCHANGE")}
+    for rc, attempts in ((None, 1), ("75", 2), ("1", 1)):
+        d = tmp_path / f"run_{rc}"
+        d.mkdir()
+        env = dict(base, PYTHONPATH=str(tmp_path) + os.pathsep + base.get("PYTHONPATH", ""), PCRL_TEST_DIR=str(d))
+        if rc:
+            env["PCRL_TEST_RC"] = rc
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                             capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert out.returncode == 1                                   # no GPU here: every attempt ends in a failure
+        caps = sorted({f.split("_")[2] for f in os.listdir(d)})
+        assert caps == (["cap0", "cap1"] if attempts == 2 else ["cap1"]), (rc, sorted(os.listdir(d)))
+        assert ("once more with PCRL_CAPTURE_EXCHANGE=0" in out.stderr) == (attempts == 2), out.stderr[-800:]
+
+
+def test_which_errors_count_as_a_failure_of_the_captured_exchange(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("PCRL_CAPTURE_EXCHANGE", raising=False)
+    yes = [RuntimeError("update step did not publish its metrics within PCRL_STEP_TIMEOUT_S (90 s): a kernel hangs or a peer of a collective is gone"),
+           RuntimeError("NCCL error in: ProcessGroupNCCL.cpp, unhandled cuda error"), RuntimeError("HIP error: operation not permitted when stream is capturing")]
+    no = [RuntimeError("HIP out of memory. Tried to allocate 2.00 GiB (captured graph pool)"), AssertionError("batch must divide over the ranks"),
+          ValueError("graph"), RuntimeError("pcrl error -2: bad argument")]
+    assert all(bench.exchange_in_graph_failure(e) for e in yes)
+    assert not any(bench.exchange_in_graph_failure(e) for e in no)
+    monkeypatch.setenv("PCRL_CAPTURE_EXCHANGE", "0")
+    assert not any(bench.exchange_in_graph_failure(e) for e in yes)      # the segmented schedule has nothing left to fall back to
+    monkeypatch.delenv("PCRL_CAPTURE_EXCHANGE")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert not any(bench.exchange_in_graph_failure(e) for e in yes)
