@@ -252,6 +252,15 @@ int pcrl_segmax_bwd_f32(const float* grad_out, const int32_t* idx, int64_t rows,
 /* RandomJitterPoints / GlobalRotScaleTrans applied to a [B,3,N] f32 tensor (in place when xyz_out ==
  * xyz_in): pcd_aug.py:306-327, 84-123.  Same pcrl_aug_desc semantics as the fused encoder load. */
 int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t B, int32_t N, const pcrl_aug_desc* aug, void* stream);
+/* GlobalRotScaleTrans.process_single's matrix draw (pcd_aug.py:178-196; batch_rot_with_axis, pyrl/utils/torch/ops.py:171-183) as
+ * one launch: mat [B][3][4] row-major = [diag(s) R(angle) | t] with angle ~ U(rot_range), s_i ~ U(scale_range), t_i = (U(0,1) - 0.5)
+ * * 2 * translation_range[i] (zero for the LAST cloud unless shift_height) -- each range pointer (host, 2 / 2 / 3 floats) may be
+ * NULL: no rotation -> identity block (the scale then has nothing to act on, as in the reference), no translation -> zero.
+ * Philox4x32-10 keyed by (seed, offset, cloud); offset_ptr (device, may be NULL) overrides offset at run time, so a launch
+ * replayed from a hipGraph draws fresh matrices.  Feeds pcrl_aug_desc.affine. */
+int pcrl_affine_sample_f32(float* mat, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                           const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset,
+                           const uint64_t* offset_ptr, void* stream);
 /* ColorJitterPoints on a [B,3,N] uint8 tensor (strides in elements).  pcrl_color_contrast_mean_u8 applies the steps that
  * precede the contrast step and returns each cloud's mean grayscale value at that point (mean_out [B] f32; the
  * reduction over the N points of a cloud is the one thing the fused encoder load cannot do on the fly);

@@ -66,6 +66,22 @@ def encoder_fwd(feat, w, eps=1e-6, want_prepool=False):
     return (pooled, argmax, prepool) if want_prepool else (pooled, argmax)
 
 
+def point_preacts(x, w, eps=1e-6):
+    """x [n, C] f32 points (preprocessed features); returns the values the three per-point ReLUs decide on, in the HIP
+    kernels' summation order: (pre0 [n, c1], pre1 [n, c2], pre2 [n, c3])."""
+    x = _f32(x)
+    n, C = x.shape
+    w0, b0, w1, g1, be1, w2, g2, be2 = [_f32(np.asarray(w[k]).reshape(np.asarray(w[k]).shape[0], -1) if np.asarray(w[k]).ndim > 1 else w[k])
+                                        for k in ("w0", "b0", "w1", "g1", "be1", "w2", "g2", "be2")]
+    c1, c2, c3 = w0.shape[0], w1.shape[0], w2.shape[0]
+    assert w0.shape[1] == C
+    pre = [np.empty((n, c), np.float32) for c in (c1, c2, c3)]
+    rc = lib().pcrl_oracle_point_preacts_f32(_p(x), n, C, c1, c2, c3, _p(w0), _p(b0), _p(w1), _p(g1), _p(be1), _p(w2), _p(g2), _p(be2),
+                                             ctypes.c_float(eps), _p(pre[0]), _p(pre[1]), _p(pre[2]))
+    assert rc == 0, rc
+    return tuple(pre)
+
+
 def segmax(x):
     x = _f32(x)
     B, c, N = x.shape

@@ -72,13 +72,15 @@ static float half_sumsq_centered(const float* x, float mean, int C, int h) {
  * (then every output of the point is NaN, as in torch).
  */
 static int ln_relu_point(float* x, int C, const float* gamma, const float* beta, float eps,
-                         float* mean_out, float* rstd_out) {
+                         float* mean_out, float* rstd_out, float* pre /* optional [C]: the value ReLU decides on */) {
     float mean = (half_sum(x, C, 0) + half_sum(x, C, 1)) / (float)C;
     float var = (half_sumsq_centered(x, mean, C, 0) + half_sumsq_centered(x, mean, C, 1)) / (float)C;
     float rstd = 1.0f / sqrtf(var + eps);
     for (int c = 0; c < C; ++c) {
         float d = x[c] - mean;
-        x[c] = relu_f(fmaf(d * rstd, gamma[c], beta[c]));
+        float y = fmaf(d * rstd, gamma[c], beta[c]);
+        if (pre) pre[c] = y;
+        x[c] = relu_f(y);
     }
     if (mean_out) *mean_out = mean;
     if (rstd_out) *rstd_out = rstd;
@@ -98,7 +100,8 @@ static int mlp_point(const float* x, int C, int c1, int c2, int c3,
                      const float* w1, const float* g1, const float* be1,
                      const float* w2, const float* g2, const float* be2, float eps,
                      float* h0, float* h1, float* h2,
-                     float* z1, float* z2, float* stats /* mean1,rstd1,mean2,rstd2 or NULL */) {
+                     float* z1, float* z2, float* stats /* mean1,rstd1,mean2,rstd2 or NULL */,
+                     float* pre0, float* pre1, float* pre2 /* optional: what each layer's ReLU decides on */) {
     int Cp = (C + 1) & ~1;
     for (int o = 0; o < c1; ++o) {
         float a = b0[o];
@@ -106,6 +109,7 @@ static int mlp_point(const float* x, int C, int c1, int c2, int c3,
             float w = k < C ? w0[o * C + k] : 0.0f, xv = k < C ? x[k] : 0.0f;
             a = fmaf(w, xv, a);
         }
+        if (pre0) pre0[o] = a;
         h0[o] = relu_f(a);
     }
     for (int o = 0; o < c2; ++o) {
@@ -114,14 +118,14 @@ static int mlp_point(const float* x, int C, int c1, int c2, int c3,
         h1[o] = a;
     }
     if (z1) memcpy(z1, h1, sizeof(float) * c2);
-    ln_relu_point(h1, c2, g1, be1, eps, stats ? stats + 0 : NULL, stats ? stats + 1 : NULL);
+    ln_relu_point(h1, c2, g1, be1, eps, stats ? stats + 0 : NULL, stats ? stats + 1 : NULL, pre1);
     for (int o = 0; o < c3; ++o) {
         float a = 0.0f;
         for (int k = 0; k < c2; ++k) { int c = pi_chan(k); a = fmaf(w2[o * c2 + c], h1[c], a); }
         h2[o] = a;
     }
     if (z2) memcpy(z2, h2, sizeof(float) * c3);
-    int nan_pt = ln_relu_point(h2, c3, g2, be2, eps, stats ? stats + 2 : NULL, stats ? stats + 3 : NULL);
+    int nan_pt = ln_relu_point(h2, c3, g2, be2, eps, stats ? stats + 2 : NULL, stats ? stats + 3 : NULL, pre2);
     if (nan_pt) for (int o = 0; o < c3; ++o) h2[o] = NAN;
     return nan_pt;
 }
@@ -150,7 +154,7 @@ PCRL_ORACLE_API int pcrl_oracle_encoder_fwd_f32(
         int32_t* bi = argmax + (size_t)b * c3;
         for (int n = 0; n < N; ++n) {
             for (int c = 0; c < C; ++c) x[c] = feat[((size_t)b * C + c) * N + n];
-            mlp_point(x, C, c1, c2, c3, w0, b0, w1, g1, be1, w2, g2, be2, eps, h0, h1, h2, NULL, NULL, NULL);
+            mlp_point(x, C, c1, c2, c3, w0, b0, w1, g1, be1, w2, g2, be2, eps, h0, h1, h2, NULL, NULL, NULL, NULL, NULL, NULL);
             for (int o = 0; o < c3; ++o) {
                 float v = h2[o];
                 if (prepool) prepool[((size_t)b * c3 + o) * N + n] = v;
@@ -160,6 +164,28 @@ PCRL_ORACLE_API int pcrl_oracle_encoder_fwd_f32(
         }
     }
     free(x);
+    return 0;
+}
+
+/*
+ * The values the three ReLUs of the per-point MLP decide on (conv0 + bias; LayerNorm-1 and LayerNorm-2 outputs), for
+ * n_pts given points x [n_pts][C], in the canonical order above -- i.e. the branch decisions the HIP forward kernel takes
+ * (it is bit-identical to this file).  tests/test_fullsize_parity_gpu.py confirms every located "encoder event" with it:
+ * a ReLU decision of the ATen restatement counts as flipped by the summation order only if THIS order decides otherwise.
+ * Restates the same lines as mlp_point (mlp.py:43-56; nn_layer.py:207-219; block_utils.py:92-96).
+ */
+PCRL_ORACLE_API int pcrl_oracle_point_preacts_f32(
+    const float* x, int n_pts, int C, int c1, int c2, int c3,
+    const float* w0, const float* b0, const float* w1, const float* g1, const float* be1,
+    const float* w2, const float* g2, const float* be2, float eps,
+    float* pre0 /* [n_pts][c1] */, float* pre1 /* [n_pts][c2] */, float* pre2 /* [n_pts][c3] */) {
+    if (c1 % 32 || c2 % 32 || c3 % 32 || C < 1 || n_pts < 0) return -1;
+    float* h0 = (float*)malloc(sizeof(float) * (c1 + c2 + c3));
+    float *h1 = h0 + c1, *h2 = h1 + c2;
+    for (int i = 0; i < n_pts; ++i)
+        mlp_point(x + (size_t)i * C, C, c1, c2, c3, w0, b0, w1, g1, be1, w2, g2, be2, eps, h0, h1, h2, NULL, NULL, NULL,
+                  pre0 + (size_t)i * c1, pre1 + (size_t)i * c2, pre2 + (size_t)i * c3);
+    free(h0);
     return 0;
 }
 

@@ -69,6 +69,7 @@ def pointnet_forward(P, obs, prefix=ENC, ln_eps=1e-6, route=None, keep=None):
         keep["pooled"], keep["obs"] = feat, obs
         with torch.no_grad():       # how far the routing is from torch's own: entries that differ, and the value gap there
             top, own = pre.max(-1)
+            keep["argmax"] = own
             keep["route_differs"] = int((own != route).sum()) if route is not None else 0
             keep["route_gap"] = float((top - feat).abs().max())
     f = prefix + "final_mlp."

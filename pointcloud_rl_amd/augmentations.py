@@ -252,7 +252,7 @@ class GlobalRotScaleTrans(_PointAug):
     translation when shift_height is False); the encoder kernel applies it as R x + t."""
 
     def __init__(self, main_key=["obs/pointcloud/xyz"], req_keys=None, rot_range=[-0.78539816, 0.78539816], rot_axis="z",
-                 scale_ratio_range=[0.95, 1.05], translation_range=[0, 0, 0], shift_height=False):
+                 scale_ratio_range=[0.95, 1.05], translation_range=[0, 0, 0], shift_height=False, seed=None):
         super().__init__(main_key, req_keys)
         if rot_range is not None and not isinstance(rot_range, (list, tuple, np.ndarray)):
             rot_range = [-rot_range, rot_range]
@@ -266,6 +266,11 @@ class GlobalRotScaleTrans(_PointAug):
         self.translation_range = translation_range
         self.shift_height = shift_height
         self.matrix_override = []
+        # Inside an update step fed by a device-sampling replay (`begin_step`, as RandomJitterPoints) the matrices are drawn by ONE
+        # launch keyed by the step's device draw counter instead of ~15 ATen launches per call from torch's generator.
+        self.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
+        self.calls = 0
+        self._shared, self._slot, self._mats = None, 0, {}
 
     def sample_matrix(self, batch_size, device):
         mat = torch.zeros([batch_size, 3, 4], device=device)
@@ -287,8 +292,27 @@ class GlobalRotScaleTrans(_PointAug):
     def __call__(self, data):
         self._check(data)
         out = _as_augmented(data)
+        if any(k.startswith("jitter") for k in out.aug):
+            # the fused point load applies the matrix first and the jitter second (include/pcrl.h, pcrl_aug_desc); a list that
+            # jitters first would need M (x + n) -- refuse instead of silently computing M x + n
+            raise NotImplementedError("list GlobalRotScaleTrans BEFORE RandomJitterPoints: the fused encoder load applies the affine map "
+                                      "first, then the jitter")
         if self.matrix_override:
             mat = self.matrix_override.pop(0)
+        elif self._shared is not None and self._shared.device == data["xyz"].device:
+            # one launch; its matrices already carry a zero translation when there is no range (pcrl_affine_sample_f32)
+            from . import hip
+            self._slot += 1
+            rows = batch_rows(data)
+            key = (rows, self._slot)
+            if key not in self._mats:          # persistent output buffers: a captured launch keeps writing the same memory
+                self._mats[key] = torch.empty(rows, 3, 4, dtype=torch.float32, device=data["xyz"].device)
+            mat = hip.affine_sample(self._mats[key], self.rot_axis, self.rot_range, self.scale_ratio_range,
+                                    None if self.translation_range is None else self.translation_range.tolist(), self.shift_height,
+                                    (self.seed + 0x9E3779B97F4A7C15 * self._slot) & 0x7FFFFFFFFFFFFFFF, offset=self.calls, offset_tensor=self._shared)
+            self.calls += 1
+            out.aug["affine"] = mat
+            return out
         else:
             mat = self.sample_matrix(batch_rows(data), data["xyz"].device)
         if self.translation_range is None:
@@ -296,6 +320,12 @@ class GlobalRotScaleTrans(_PointAug):
             mat[..., :3, 3] = 0
         out.aug["affine"] = mat.to(torch.float32).contiguous()
         return out
+
+    def begin_step(self, shared_counter):
+        """shared_counter: device int64 [1] tensor the step advances once before its encoder launches (DeviceReplay.state[:1]);
+        None: every call draws with torch's generator, as the reference does."""
+        assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1)
+        self._shared, self._slot = shared_counter, 0
 
     def __repr__(self):
         return (f"{type(self).__name__}(rot_range={self.rot_range}, scale_ratio_range={self.scale_ratio_range}, "

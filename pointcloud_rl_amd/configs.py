@@ -62,7 +62,18 @@ MANISKILL_NETS = ([128, 128, 256], 128)    # configs/mfrl/drq/maniskill/base/pn_
 JITTER = dict(type="RandomJitterPoints", main_key="xyz", req_keys=["xyz"], jitter_range=[-0.01, 0.01])
 
 
+# "jitter+scale" (BASELINE.json config 3): the reference's scale is a factor on the ROWS of the rotation block (pcd_aug.py:187-189), so
+# a scale augmentation is a GlobalRotScaleTrans with a rotation range; values of configs/mfrl/drq/*/pn_rot.py + the class default scale
+ROT_SCALE = dict(type="GlobalRotScaleTrans", main_key="xyz", req_keys=["xyz"], rot_range=[-0.15, 0.15], rot_axis="z",
+                 scale_ratio_range=[0.95, 1.05], translation_range=None)
 MOTIVATING_NETS = ([32, 64, 128], 50)      # configs/mfrl/sac/dm_control/pn_motivating.py:25-31, drq/dm_control/pn_shift_motivating.py
+
+
+def _aug_cfg(obs_aug):
+    """One augmentation dict or a list of them (build_data_augmentations takes either, builder.py:97-104)."""
+    if not obs_aug:
+        return None
+    return [dict(a) for a in obs_aug] if isinstance(obs_aug, (list, tuple)) else dict(obs_aug)
 
 
 def sac_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, nets=DMC_NETS, **extra):
@@ -82,7 +93,7 @@ def sac_maniskill(pcd_channels=7, action_dim=22, agent_dim=68, batch_size=256, h
 def drq_dmc(pcd_channels=6, action_dim=6, batch_size=256, head_hidden=1024, obs_aug=JITTER, num_aug=2, svea=False):
     """configs/mfrl/drq/dm_control/{base/pn_base.py, pn_jitter.py}"""
     cfg = _agent_cfg("DrQ", DMC_NETS, pcd_channels, action_dim, 0, batch_size, 0.95, head_hidden,
-                     dict(num_aug=num_aug, svea=svea, obs_aug=dict(obs_aug) if obs_aug else None))
+                     dict(num_aug=num_aug, svea=svea, obs_aug=_aug_cfg(obs_aug)))
     cfg["critic_cfg"]["nn_cfg"]["mlp_cfg"]["bias"] = True
     return cfg
 
@@ -91,7 +102,7 @@ def drq_maniskill(pcd_channels=7, action_dim=22, agent_dim=68, batch_size=256, h
                   encoder_dtype="f32"):
     """configs/mfrl/drq/maniskill/{base/pn_base.py, pn_jitter.py}; encoder_dtype="bf16" = BASELINE.json config 3."""
     cfg = _agent_cfg("DrQ", MANISKILL_NETS, pcd_channels, action_dim, agent_dim, batch_size, 0.95, head_hidden,
-                     dict(num_aug=num_aug, svea=False, obs_aug=dict(obs_aug) if obs_aug else None))
+                     dict(num_aug=num_aug, svea=False, obs_aug=_aug_cfg(obs_aug)))
     cfg["actor_cfg"]["nn_cfg"]["mlp_cfg"]["zero_out_indices"] = slice(action_dim, None, None)
     cfg["actor_cfg"]["nn_cfg"]["visual_nn_cfg"]["compute_dtype"] = encoder_dtype
     return cfg

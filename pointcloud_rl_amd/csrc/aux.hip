@@ -142,6 +142,64 @@ __global__ __launch_bounds__(256) void color_jitter_kernel(const ColorParams p) 
     p.out[off] = (unsigned char)r; p.out[off + p.sc] = (unsigned char)g; p.out[off + 2 * p.sc] = (unsigned char)bl;
 }
 
+// ---- GlobalRotScaleTrans: the per-cloud [3 x 4] matrix drawn on the device -------------------------------------------------
+// pcd_aug.py:178-196: mat = 0; R(angle ~ U(rot_range)) about rot_axis into [:3,:3]; rows of [:3,:] scaled by s_i ~ U(scale range)
+// (so the scale acts only through a rotation block, and before the translation is written); translation (U(0,1) - 0.5) * 2 * range,
+// zero for the LAST cloud unless shift_height; apply_rot_trans skips the product when there is no rotation (identity here) and the
+// shift when there is no translation range (zero here).  The reference draws with ~15 ATen launches per call from torch's
+// generator; this is one launch, Philox4x32-10 keyed by (seed, offset | *offset_ptr, cloud) -- a launch replayed from a hipGraph
+// draws fresh matrices when offset_ptr names a counter the step advances.
+struct AffineSampleParams {
+    float* mat; int B, rot_axis, has_rot, has_scale, has_trans, shift_height;
+    float rot_lo, rot_hi, scale_lo, scale_hi, trans[3];
+    unsigned long long seed, offset; const unsigned long long* offset_ptr;
+};
+__global__ __launch_bounds__(256) void affine_sample_kernel(const AffineSampleParams p) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.B) return;
+    const unsigned long long off = p.offset_ptr ? *p.offset_ptr : p.offset;
+    uint32_t w0[4], w1[4];
+    philox4x32_10((uint32_t)b, 0u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32) ^ 0xA0F1E2D3u, w0);
+    philox4x32_10((uint32_t)b, 1u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32) ^ 0xA0F1E2D3u, w1);
+    float m[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[i][j] = 0.0f;
+    if (p.has_rot) {
+        const float ang = u01_to_range(w0[0], p.rot_lo, p.rot_hi);
+        const float c = cosf(ang), s = sinf(ang);
+        const int a = p.rot_axis, j = (a + 1) % 3, k = (a + 2) % 3;          // batch_rot_with_axis, ops.py:171-183
+        m[a][a] = 1.0f; m[j][j] = c; m[k][k] = c; m[j][k] = -s; m[k][j] = s;
+    }
+    if (p.has_scale) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float sc = u01_to_range(w0[1 + i], p.scale_lo, p.scale_hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] *= sc;
+        }
+    }
+    if (p.has_trans) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float u = (float)(w1[i] >> 8) * (1.0f / 16777216.0f);
+            m[i][3] = (!p.shift_height && b == p.B - 1) ? 0.0f : (u - 0.5f) * 2.0f * p.trans[i];
+        }
+    }
+    if (!p.has_rot) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) m[i][j] = i == j ? 1.0f : 0.0f;
+    }
+    float* dst = p.mat + (long long)b * 12;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[4 * i + j] = m[i][j];
+}
+
 }  // namespace pcrl
 
 using namespace pcrl;
@@ -188,6 +246,22 @@ extern "C" int pcrl_color_jitter_u8(const uint8_t* rgb_in, uint8_t* rgb_out, int
     const long long n = (long long)B * N;
     hipLaunchKernelGGL(color_jitter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("color_jitter_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_affine_sample_f32(float* mat, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                                      const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset,
+                                      const uint64_t* offset_ptr, void* stream) {
+    if (!mat || B < 1 || rot_axis < 0 || rot_axis > 2) return fail(PCRL_E_ARG, "affine sample: bad arguments");
+    AffineSampleParams p{};
+    p.mat = mat; p.B = B; p.rot_axis = rot_axis; p.shift_height = shift_height;
+    p.has_rot = rot_range != nullptr; p.has_scale = scale_range != nullptr; p.has_trans = translation_range != nullptr;
+    if (rot_range) { p.rot_lo = rot_range[0]; p.rot_hi = rot_range[1]; }
+    if (scale_range) { p.scale_lo = scale_range[0]; p.scale_hi = scale_range[1]; }
+    if (translation_range) for (int i = 0; i < 3; ++i) p.trans[i] = translation_range[i];
+    p.seed = seed; p.offset = offset; p.offset_ptr = reinterpret_cast<const unsigned long long*>(offset_ptr);
+    hipLaunchKernelGGL(affine_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    PCRL_CHECK_LAUNCH("affine_sample_kernel");
     return PCRL_OK;
 }
 

@@ -582,6 +582,20 @@ def segmax_bwd(grad_out, idx, N):
     return dx
 
 
+def affine_sample(out, rot_axis, rot_range, scale_range, translation_range, shift_height, seed, offset=0, offset_tensor=None):
+    """GlobalRotScaleTrans's [B,3,4] matrices drawn by one launch (pcrl_affine_sample_f32) into `out` (float32, contiguous, cuda).
+    Ranges are None or sequences of 2 / 2 / 3 floats; offset_tensor: device int64 [1] read at run time (hipGraph replays)."""
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[1:]) == (3, 4)
+    arr = lambda v, n: None if v is None else (ctypes.c_float * n)(*[float(x) for x in v])
+    if offset_tensor is not None:
+        assert offset_tensor.dtype == torch.int64 and offset_tensor.is_cuda
+    with _span("affine_sample"):
+        check(lib().pcrl_affine_sample_f32(_ptr(out), out.shape[0], int(rot_axis), arr(rot_range, 2), arr(scale_range, 2), arr(translation_range, 3),
+                                           int(bool(shift_height)), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_uint64(int(offset)),
+                                           _ptr(offset_tensor) if offset_tensor is not None else None, _stream()))
+    return out
+
+
 def augment_xyz(xyz, out=None, **aug):
     """Materialised RandomJitterPoints / GlobalRotScaleTrans on xyz [B,3,N] (same keywords as make_aug_desc)."""
     assert xyz.is_cuda and xyz.dtype == torch.float32 and xyz.is_contiguous() and xyz.shape[1] == 3

@@ -227,3 +227,113 @@ def test_bench_single_rank_exchange_over_rccl(cuda):
     assert d["n_gpus"] == 1 and "debug" in d and d["value"] > 0
     assert "ms_per_step_nocomm" in d and "comm_ms_per_step" in d
     assert d["config"]["graph_variants"] >= 2 if "graph_variants" in d["config"] else True
+
+
+# ---- two real RCCL ranks: run wherever two GPUs are visible (collected and skipped on the one-GPU pool) ------------------------
+def _two_gpus():
+    return torch.cuda.device_count() >= 2        # counting devices does not initialise the GPU
+
+
+def _nccl_worker(rank, world, port, graphs, out):
+    """One rank per GPU over RCCL (backend "nccl"), as the reference's driver sets it up (run_rl.py:315-329)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    torch.cuda.set_device(rank)
+    dev = f"cuda:{rank}"
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    from pointcloud_rl_amd.utils.dist import shard_slice
+    from pointcloud_rl_amd.utils.torch_utils import to_torch
+    cfg = configs.sac_dmc(6, A, B // world, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(100 + rank)                  # the reference seeds each rank differently (run_rl.py:263): to_ddp must broadcast
+    agent = build_agent(cfg).to(dev)
+    agent.to_ddp(device_ids=["cuda"])
+    if graphs:
+        agent.enable_graphs(warmup=1)
+    sl = shard_slice(B, rank, world)
+    full = SyntheticReplay(B, N, A, seed=9)
+    shard = {k: ({kk: vv[sl] for kk, vv in v.items()} if isinstance(v, dict) else v[sl]) for k, v in full.batch_np.items()}
+    mem = SyntheticReplay.__new__(SyntheticReplay)
+    mem.batch_np, mem.batch = shard, to_torch(shard, device=dev)
+    init = {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}
+    for u in range(1, STEPS + 1 + (4 if graphs else 0)):
+        if not graphs:
+            agent.actor.head.noise_override = [e[sl].to(dev) for e in _eps(u)][:2 if u % 2 == 0 else 1]
+        ret = agent.update_parameters(mem, u)
+        assert np.isfinite(list(ret.values())).all()
+    modes = None
+    if graphs:
+        modes = sorted({len(segs) for segs, _, _ in agent._graphs.values()})
+    torch.cuda.synchronize()
+    torch.save({"params": {n: p.detach().cpu() for n, p in agent.named_parameters()}, "init": init, "segments": modes,
+                "capture": os.environ.get("PCRL_CAPTURE_EXCHANGE", "1")}, os.path.join(out, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_nccl(graphs):
+    import tempfile
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_nccl_worker, args=(2, _free_port(), graphs, out), nprocs=2, join=True)
+        return tuple(torch.load(os.path.join(out, f"rank{r}.pt")) for r in range(2))
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_sharded_update_equals_whole_batch_update():
+    """The sharded == whole-batch check of this file over REAL RCCL: two ranks on two GPUs, each owning half of the batch, flat
+    gradient buffers all-reduced over xGMI.  Rank 1 starts from other weights (the driver seeds seed + rank): to_ddp's broadcast
+    must make them rank 0's."""
+    r0, r1 = _run_nccl(graphs=False)
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(100)
+    agent = build_agent(cfg).to("cuda:0")
+    for n, p in agent.named_parameters():
+        assert torch.equal(p.detach().cpu(), r0["init"][n]), n          # same initial weights as rank 0 of the sharded run
+    mem = _memory(slice(0, B))
+    for u in range(1, STEPS + 1):
+        agent.actor.head.noise_override = [e.to("cuda:0") for e in _eps(u)][:2 if u % 2 == 0 else 1]
+        agent.update_parameters(mem, u)
+    for n, p in agent.named_parameters():
+        err = (p.detach().cpu() - r0["params"][n]).abs()
+        assert (err <= 1e-5).float().mean() >= 0.999 and err.max() <= 2e-4, (n, float(err.max()))
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_rccl_ranks_replay_the_exchange_from_the_step_s_hipgraph():
+    """RCCL kernels INSIDE a replayed hipGraph -- what a one-rank group cannot show (its all-reduce launches no kernel): the
+    exchanging step is captured whole (one graph per variant), replicas stay bit-identical over the replays."""
+    r0, r1 = _run_nccl(graphs=True)
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+        assert torch.isfinite(r0["params"][n]).all()
+    assert r0["segments"] == r1["segments"]
+    if r0["capture"] != "0":
+        assert r0["segments"] == [1], r0["segments"]        # the all-reduces are nodes of the step's one graph
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_bench_two_rccl_ranks_print_the_contract_line():
+    """`python bench.py --gpus 2 --backend nccl`: the driver's own multi-GPU invocation, two RCCL ranks, collectives captured in the
+    step's hipGraph (or the launcher's note saying that the captured exchange failed and the segmented schedule ran)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "10", "--backend", "nccl",
+                          "--no-cpu-baseline", "--replay-capacity", "512", "--no-extra-workloads"],
+                         cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{"), lines[-3:]
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["backend"].startswith("nccl")
+    assert d["config"]["exchange"] == "captured in the step's hipGraph" or "launcher_note" in d, d["config"]["exchange"]
+    assert d["value"] > 0 and d["config"]["batch_per_gpu"] == 128 and "comm_ms_per_step" in d

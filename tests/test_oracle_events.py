@@ -72,14 +72,63 @@ def test_one_flipped_decision_is_located_and_removed():
     shift = max(float((flipped[n] - base[n]).abs().max()) / float(P[pre + n].grad.abs().max()) for n in NAMES)
     assert shift > 1e-4                                                   # the event is far above the tolerance it would break
     ref = types.SimpleNamespace(P=P, keep=keep, route=route)
-    report = dict(argmax_differs=0, argmax_gap=0.0, encoder_events=0, encoder_candidates=0, event_max_preact=0.0, events=[])
-    _locate_encoder_events(ref, other, report)
-    assert report["encoder_events"] == 1 and report["argmax_differs"] == 0
+    report = dict(argmax_differs=0, argmax_gap=0.0, encoder_events=0, encoder_candidates=0, event_max_preact=0.0, events=[],
+                  candidates_not_confirmed=0, unconfirmed_events=0)
+    # (confirm=False: the flip is synthetic -- the HIP summation order does not really decide this unit the other way)
+    _locate_encoder_events(ref, other, report, confirm=False)
+    assert report["encoder_events"] == 1 and report["argmax_differs"] == 0 and report["unconfirmed_events"] == 1
     ev = report["events"][0]
     assert (ev["cloud"], ev["layer"], ev["channel"]) == (b_ev, 0, ch_ev) and ev["preact"] <= EVENT_TAU
     for n in NAMES:
         gr = P[pre + n].grad
         assert float((other[n] - gr).abs().max()) <= 2e-6 * float(gr.abs().max()), n
+
+
+def test_an_event_the_hip_summation_order_does_not_confirm_is_not_accepted():
+    """Round 4: the projection coefficient alone accepts nothing.  The same synthetic one-flip difference as above, but with the
+    confirmation on: oracle/pcrl_oracle.c evaluates the point in the HIP kernels' order, finds the pre-activation (~ +3e-6, far
+    above the ~1e-7 the two orders differ by) on the SAME side of zero as ATen -- so a kernel error that merely looks like that
+    flip stays in the residual instead of being moved into the restatement."""
+    T, P, obs, g = _setup()
+    route = T.pointnet_prepool(P, obs).argmax(-1)
+    b_ev, ch_ev = 2, 11
+    pts = torch.unique(route[b_ev])
+    with torch.no_grad():
+        x = T.preprocess({k: v[b_ev:b_ev + 1, :, pts] for k, v in obs.items()})
+        z0 = torch.nn.functional.conv1d(x, P[T.ENC + "conv.mlp.conv0.weight"], P[T.ENC + "conv.mlp.conv0.bias"])[0, ch_ev]
+        P[T.ENC + "conv.mlp.conv0.bias"][ch_ev] -= z0[int(z0.abs().argmin())] - 3e-6
+    route = T.pointnet_prepool(P, obs).argmax(-1)
+    keep = {}
+    feat = T.pointnet_forward(P, obs, route=route, keep=keep)
+    (feat * torch.randn(feat.shape, generator=g)).sum().backward()
+    cloud = T.CloudEncoder(P, {k: v[b_ev] for k, v in obs.items()}, route[b_ev], keep["pooled"].grad[b_ev])
+    cand = [c for c in cloud.candidates(EVENT_TAU) if c[0] == 0 and c[1] == ch_ev][0]
+    base, flipped = cloud.grads(), cloud.grads(flip=cand[:3])
+    pre = T.ENC + "conv.mlp."
+    before = {n: P[pre + n].grad.clone() for n in NAMES}
+    other = {n: P[pre + n].grad + (flipped[n] - base[n]) for n in NAMES}
+    report = dict(argmax_differs=0, argmax_gap=0.0, encoder_events=0, encoder_candidates=0, event_max_preact=0.0, events=[],
+                  candidates_not_confirmed=0, unconfirmed_events=0)
+    _locate_encoder_events(types.SimpleNamespace(P=P, keep=keep, route=route), other, report)
+    assert report["encoder_events"] == 0 and report["candidates_not_confirmed"] >= 1
+    for n in NAMES:
+        assert torch.equal(P[pre + n].grad, before[n]), n          # nothing was patched
+
+
+def test_the_c_oracle_s_relu_inputs_are_the_forward_s():
+    """oracle/pcrl_oracle.c::pcrl_oracle_point_preacts_f32 (what confirms an event) against the same file's encoder forward:
+    max(pre2, 0) is the pre-pool feature bit for bit, and the three layers agree with ATen to rounding."""
+    from oracle import c_oracle
+    w = make_encoder_weights(6, 64, 128, 256, seed=9)
+    obs = make_obs(3, 50, seed=10)
+    feat = c_oracle.preprocess(obs)
+    _, _, prepool = c_oracle.encoder_fwd(feat, w, want_prepool=True)
+    for b in range(3):
+        p0, p1, p2 = c_oracle.point_preacts(np.ascontiguousarray(feat[b].T), w)
+        assert np.array_equal(np.maximum(p2, 0).T, prepool[b])
+        x = torch.from_numpy(feat[b:b + 1])
+        z0 = torch.nn.functional.conv1d(x, torch.from_numpy(w["w0"])[..., None], torch.from_numpy(w["b0"]))[0]
+        assert np.abs(z0.numpy().T - p0).max() <= 1e-5
 
 
 def test_no_event_is_invented_when_the_gradients_agree():
@@ -90,6 +139,7 @@ def test_no_event_is_invented_when_the_gradients_agree():
     (feat * torch.randn(feat.shape, generator=g)).sum().backward()
     pre = T.ENC + "conv.mlp."
     other = {n: P[pre + n].grad + 5e-7 * float(P[pre + n].grad.abs().max()) * torch.randn(P[pre + n].grad.shape, generator=g) for n in NAMES}
-    report = dict(argmax_differs=0, argmax_gap=0.0, encoder_events=0, encoder_candidates=0, event_max_preact=0.0, events=[])
+    report = dict(argmax_differs=0, argmax_gap=0.0, encoder_events=0, encoder_candidates=0, event_max_preact=0.0, events=[],
+                  candidates_not_confirmed=0, unconfirmed_events=0)
     _locate_encoder_events(types.SimpleNamespace(P=P, keep=keep, route=route), other, report)
     assert report["encoder_events"] == 0

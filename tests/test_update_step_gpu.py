@@ -296,6 +296,8 @@ def test_reference_style_state_dict_keeps_the_fused_optimizers(cuda):
         twin = torch.optim.Adam([dict(params=g["params"]) for g in opt.param_groups], lr=opt.param_groups[0]["lr"])
         twin.load_state_dict(sd)
         back = twin.state_dict()
+        # (torch keeps the tensors it is handed when dtype and device already match: clone before zeroing the originals)
+        back = dict(back, state={i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in back["state"].items()})
         for i, st in sd["state"].items():
             assert torch.equal(back["state"][i]["exp_avg"], st["exp_avg"]) and torch.equal(back["state"][i]["exp_avg_sq"], st["exp_avg_sq"])
         # and the fused optimizer takes a torch.optim.Adam's dict back (checkpoint_utils.py:62: child.load_state_dict(...))
