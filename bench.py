@@ -13,7 +13,9 @@ scaling, value = global gradient steps per second.
 
 Defaults: 500 warm-up + 2000 timed steps (about 2.5 s on one GPU); a training run is 10^5-10^6 updates.  Every default K1 line also
 carries, as extra top-level objects that are never the reported value, `config4_k3` (the same ranks on BASELINE config 4: B 1024,
-N 1200, C 7 -- the shape north_star's strong-scaling target is stated for) and, at N = 1, `experimental_f32split`.
+N 1200, C 7 -- the shape north_star's strong-scaling target is stated for), `config3_k2` (config 3: DrQ, jitter + scale fused into the
+bf16 encoder load; with its own cpu_baseline at N = 1) and `config5_k4` (config 5: B 512, N 8192), each with its own `roofline`
+object, and, at N = 1, `experimental_f32split`.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (the fused encoder forward),
 timed with HIP events inside the timed region; `cpu_baseline` is the op-for-op PyTorch-CPU
@@ -35,9 +37,12 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (B, N, pcd channels extras, action_dim, agent_dim, config builder)
     "k1": dict(B=256, N=1024, A=6, S=0, obs_kw={}, cfg="sac_dmc", desc="SAC PointNet, synthetic replay B=256 N=1024 C=6 (BASELINE config 2)"),
-    "k2": dict(B=256, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="drq_maniskill_bf16",
-               desc="DrQ pn_jitter, PointNet [128,128,256], B=256 x 2 augmentations, N=1200 C=7, jitter fused into the encoder load, "
-                    "bf16 conv1/conv2 with fp32 accumulate (BASELINE config 3)"),
+    "k2": dict(B=256, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="drq_maniskill_bf16", aug="rot_scale+jitter",
+               desc="DrQ, PointNet [128,128,256], B=256 x 2 augmentations, N=1200 C=7, GlobalRotScaleTrans (rotation + per-axis scale) and "
+                    "RandomJitterPoints fused into the encoder load, bf16 conv1/conv2 with fp32 accumulate (BASELINE config 3: jitter+scale)"),
+    "k2j": dict(B=256, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="drq_maniskill_bf16", aug="jitter",
+                desc="DrQ pn_jitter (the reference's configs/mfrl/drq/maniskill/pn_jitter.py as shipped: jitter only), B=256 x 2 augmentations, "
+                     "N=1200 C=7, bf16 conv1/conv2 with fp32 accumulate"),
     "k3": dict(B=1024, N=1200, A=22, S=68, obs_kw=dict(seg=1), cfg="sac_maniskill",
                desc="SAC PointNet, ManiSkill shape B=1024 N=1200 C=7 (BASELINE config 4)"),
     "k4": dict(B=512, N=8192, A=6, S=0, obs_kw={}, cfg="sac_dmc", capacity=1024,
@@ -82,8 +87,9 @@ def parse():
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16", "f32split"], help="override the workload's encoder arithmetic; "
                     "f32split = the EXPERIMENTAL three-term bf16 split of the fp32 contractions (~1e-6 of fp32, not bit-comparable): the JSON "
                     "line then says dtype f32split and is not the headline configuration")
-    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the short extra run of BASELINE config 4 (K3: B=1024, N=1200, C=7, the "
-                    "shape north_star's strong-scaling target is stated for) that every default k1 line carries as `config4_k3`")
+    ap.add_argument("--no-extra-workloads", action="store_true", help="skip the short extra runs of BASELINE configs 4, 3 and 5 (K3: B=1024, N=1200, C=7, "
+                    "the shape north_star's strong-scaling target is stated for; K2: DrQ bf16 jitter+scale; K4: B=512, N=8192) that every default "
+                    "k1 line carries as `config4_k3`, `config3_k2`, `config5_k4`")
     ap.add_argument("--extra-steps", type=int, default=100)
     ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
@@ -97,7 +103,9 @@ def build_agent(wl, batch_per_rank, device, encoder_dtype=None):
     if wl["cfg"] == "sac_dmc":
         cfg = configs.sac_dmc(C, wl["A"], batch_per_rank)
     elif wl["cfg"] == "drq_maniskill_bf16":
-        cfg = configs.drq_maniskill(C, wl["A"], wl["S"], batch_per_rank, encoder_dtype="bf16")
+        # the fused load applies the matrix first, then the jitter: the list is in that order (augmentations.py)
+        aug = [configs.ROT_SCALE, configs.JITTER] if wl.get("aug") == "rot_scale+jitter" else configs.JITTER
+        cfg = configs.drq_maniskill(C, wl["A"], wl["S"], batch_per_rank, obs_aug=aug, encoder_dtype="bf16")
     else:
         cfg = configs.sac_maniskill(C, wl["A"], wl["S"], batch_per_rank)
     obs_shape = {"xyz": [3, wl["N"]], "rgb": [3, wl["N"]]}
@@ -120,14 +128,48 @@ def device_ring(wl, capacity, rank, device):
     return memory
 
 
-def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True):
+def encoder_roofline(agent, wl, C, b_rank, n_fwd, ms_fwd, steps_timed, workload, graphed, use_traffic):
+    """`roofline` object of the dominant kernel (the fused encoder forward) from its HIP-event spans: algorithmic FLOPs per average
+    launch (F_pt = 2 (C c1 + c1 c2 + c2 c3) per point) / average launch duration, against the dense MFMA
+    peak of the arithmetic it contracts in (MI355X_MICROARCH.md: fp32 157.3, bf16 2 500 TFLOP/s)."""
+    spec = agent.encoder.mlp_spec
+    f_pt = 2.0 * (C * spec[0] + spec[0] * spec[1] + spec[1] * spec[2])
+    is_bf16 = getattr(agent.encoder, "compute_dtype", "f32") == "bf16"
+    num_aug = getattr(agent, "num_aug", 1)
+    # clouds per encoder launch: a step encodes s' and s (b * num_aug clouds each; ONE launch when the replay stages them back
+    # to back) and, every second step, s again for the actor (b clouds) -- divided by the launches the timer counted
+    clouds_per_launch = b_rank * (2 * num_aug + 0.5) * steps_timed / max(n_fwd, 1)
+    flops_per_launch = f_pt * clouds_per_launch * wl["N"]
+    achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
+    peak = 2500.0 if is_bf16 else 157.3
+    traffic, traffic_src = None, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}.json")))
+    if cands and use_traffic:
+        # HBM bytes per encoder_fwd launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process.
+        # The file names the hash of the kernel's sources it was measured on: a figure from another kernel is not reported.
+        tj = json.load(open(cands[-1]))
+        if tj.get("kernel_source_sha") == kernel_source_sha():
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], ROOT)
+        else:
+            traffic_src = f"{os.path.relpath(cands[-1], ROOT)} is stale (measured on kernel sources {tj.get('kernel_source_sha')}, " \
+                          f"now {kernel_source_sha()}): not reported"
+    return {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
+            "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
+            "algorithmic_flops_per_launch": flops_per_launch}
+
+
+def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True, roofline=False,
+              cpu_steps=0, cpu_threads=0):
     """A short, separately reported run of another workload (or of another encoder arithmetic) with the same protocol as the
     headline -- device ring, hipGraph replay, barrier + synchronize on both sides, MAX over ranks -- for the extra objects of the
     JSON line.  Never the reported `value`."""
     wl = WORKLOADS[name]
     assert wl["B"] % world == 0
     b_rank = wl["B"] // world
-    agent, _ = build_agent(wl, b_rank, device, encoder_dtype)
+    agent, C = build_agent(wl, b_rank, device, encoder_dtype)
     if dist_on:
         agent.to_ddp(device_ids=["cuda"])
     if memory is None:
@@ -162,7 +204,32 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
         dt = float(t.item())
     out = {"value": steps / dt, "unit": "gradient steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "global_batch": wl["B"], "batch_per_gpu": b_rank, "points": wl["N"], "n_gpus": world, "scaling": "strong",
-           "exchange": exchange_mode(agent, dist_on)}
+           "exchange": exchange_mode(agent, dist_on), "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32")}
+    if roofline:
+        # per-kernel spans from an eager pass over the same ring and weights (a replayed graph's launches cannot be bracketed by
+        # host-recorded events); every rank runs it (the step's collectives are inside), rank 0's spans are reported
+        from pointcloud_rl_amd import hip
+        if graphs:
+            agent.enable_graphs(False)
+        for _ in range(2):
+            u += 1
+            agent.update_parameters(memory, u)
+        sync()
+        hip.TIMER = hip.KernelTimer()
+        eager_steps = 6
+        for _ in range(eager_steps):
+            u += 1
+            agent.update_parameters(memory, u)
+        sync()
+        timer, hip.TIMER = hip.TIMER, None
+        spans = timer.summary()
+        n_fwd, ms_fwd = spans.get("encoder_fwd", (0, float("nan")))
+        out["roofline"] = encoder_roofline(agent, wl, C, b_rank, n_fwd, ms_fwd, eager_steps, name, graphs, use_traffic=not dist_on)
+        out["kernels_ms"] = {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()}
+    if cpu_steps and rank == 0:
+        points = wl["B"] * wl["N"] * getattr(agent, "num_aug", 1)
+        out["cpu_baseline"] = cpu_baseline(agent, wl, cpu_steps, cpu_threads, sample_batch=wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points)),
+                                           warmup_batch=4)
     del agent, memory
     torch.cuda.empty_cache()
     return out
@@ -201,9 +268,11 @@ def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0, warmup_batch=0):
     from oracle import torch_ref
     from pointcloud_rl_amd.synthetic import make_batch_np
     params = {n: p.detach().cpu().clone() for n, p in agent.named_parameters()}
-    ref = torch_ref.RefAgent(params, kind="sac", gamma=agent.gamma, reward_scale=agent.reward_scale, alpha=0.1,
+    kind = "drq" if wl["cfg"].startswith("drq") else "sac"
+    num_aug = getattr(agent, "num_aug", 1) if kind == "drq" else 1
+    ref = torch_ref.RefAgent(params, kind=kind, gamma=agent.gamma, reward_scale=agent.reward_scale, alpha=0.1,
                              target_entropy=agent.target_entropy, actor_update_interval=agent.actor_update_interval,
-                             target_update_interval=agent.target_update_interval,
+                             target_update_interval=agent.target_update_interval, num_aug=max(num_aug, 1),
                              update_coeff=agent.update_coeff["default"], mirror_redundancy=True)
     Bs = min(sample_batch, wl["B"]) if sample_batch else wl["B"]
     batch = make_batch_np(Bs, wl["N"], wl["A"], seed=1, agent=wl["S"], **wl["obs_kw"])
@@ -212,18 +281,32 @@ def cpu_baseline(agent, wl, steps, threads=0, sample_batch=0, warmup_batch=0):
     torch.set_num_threads(threads if threads else usable_cpus())
     cores = torch.get_num_threads()
     g = torch.Generator().manual_seed(0)
-    eps = lambda n: [torch.randn(n, wl["A"], generator=g), torch.randn(n, wl["A"], generator=g)]
+    eps = lambda n: [torch.randn(n * num_aug, wl["A"], generator=g), torch.randn(n, wl["A"], generator=g)]
+    # DrQ: the augmentation draws are part of the reference's step (CPU generators, drq.py:52-60; pcd_aug.py:178-196, 316-322), so they
+    # are made inside the timed loop: jitter noise for obs and next_obs, and the rotation / scale matrices when the workload has them
+    aug = None
+    if kind == "drq":
+        from pointcloud_rl_amd.augmentations import GlobalRotScaleTrans
+        from pointcloud_rl_amd import configs
+        rst = GlobalRotScaleTrans(**{k: v for k, v in configs.ROT_SCALE.items() if k != "type"}) if wl.get("aug") == "rot_scale+jitter" else None
+
+        def aug(n):
+            rows = n * num_aug
+            jit = [torch.empty(rows, 3, wl["N"]).uniform_(-0.01, 0.01, generator=g) for _ in range(2)]
+            aff = [rst.sample_matrix(rows, "cpu") for _ in range(2)] if rst is not None else None
+            return dict(jitter_list=jit, affine_list=aff)
+    draws = (lambda n: aug(n)) if aug is not None else (lambda n: {})
     if warmup_batch and warmup_batch < Bs:
         cut = lambda v: v[:warmup_batch]
         wb = {k: ({kk: cut(vv) for kk, vv in v.items()} if isinstance(v, dict) else cut(v)) for k, v in tb.items()}
-        ref.update_parameters(wb, 2, eps(warmup_batch))           # an even count: the actor / target branch is warmed up too
+        ref.update_parameters(wb, 2, eps(warmup_batch), **draws(warmup_batch))           # an even count: the actor / target branch is warmed up too
     else:
-        ref.update_parameters(tb, 1, eps(Bs))
+        ref.update_parameters(tb, 1, eps(Bs), **draws(Bs))
     t0 = time.perf_counter()
     for u in range(2, 2 + steps):
-        ref.update_parameters(tb, u, eps(Bs))
+        ref.update_parameters(tb, u, eps(Bs), **draws(Bs))
     dt = (time.perf_counter() - t0) / steps * (wl["B"] / Bs)
-    what = f"{steps} full update step(s) (B={wl['B']}, N={wl['N']})" if Bs == wl["B"] else \
+    what = f"{steps} full {kind.upper() if kind == 'sac' else 'DrQ'} update step(s) (B={wl['B']}" + (f" x {num_aug} augmentations" if num_aug > 1 else "") + f", N={wl['N']})" if Bs == wl["B"] else \
         f"{steps} update steps on a {Bs}-transition slice of the B={wl['B']}, N={wl['N']} batch, time scaled by {wl['B']}/{Bs}"
     warm = f"1 warm-up step on {warmup_batch} transitions" if (warmup_batch and warmup_batch < Bs) else "1 warm-up"
     return {"value": 1.0 / dt, "unit": "gradient steps/s", "cores": cores, "kind": "port", "extrapolated": Bs != wl["B"],
@@ -464,30 +547,8 @@ def main():
     if rank == 0:
         spans, span_detail = timer.summary(), timer.detail()
         n_fwd, ms_fwd = spans.get("encoder_fwd", (0, float("nan")))
-        f_pt = 2.0 * (C * agent.encoder.mlp_spec[0] + agent.encoder.mlp_spec[0] * agent.encoder.mlp_spec[1] +
-                      agent.encoder.mlp_spec[1] * agent.encoder.mlp_spec[2])
-        # the launches of one step have different cloud counts only for DrQ; for SAC every launch encodes b_rank clouds
-        is_bf16 = getattr(agent.encoder, "compute_dtype", "f32") == "bf16"
-        num_aug = getattr(agent, "num_aug", 1)
-        # clouds per encoder launch: a step encodes s' and s (b * num_aug clouds each; ONE launch when the replay stages them back
-        # to back) and, every second step, s again for the actor (b clouds) -- divided by the launches the timer counted
         steps_timed = timed_eager_steps if graphed else args.steps
-        clouds_per_launch = b_rank * (2 * num_aug + 0.5) * steps_timed / max(n_fwd, 1)
-        flops_per_launch = f_pt * clouds_per_launch * wl["N"]
-        achieved = flops_per_launch / (ms_fwd * 1e-3) / 1e12
-        peak = 2500.0 if is_bf16 else 157.3        # dense MFMA peaks of MI355X_MICROARCH.md (bf16 / fp32)
-        traffic, traffic_src = None, None
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{args.workload}.json")))
-        if cands and not args.batch and not dist_on:
-            # HBM bytes per encoder_fwd launch from the committed rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_traffic.py) -- counters cannot be read in-process.
-            # The file names the hash of the kernel's sources it was measured on: a figure from another kernel is not reported.
-            tj = json.load(open(cands[-1]))
-            if tj.get("kernel_source_sha") == kernel_source_sha():
-                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(cands[-1], ROOT)
-            else:
-                traffic_src = f"{os.path.relpath(cands[-1], ROOT)} is stale (measured on kernel sources {tj.get('kernel_source_sha')}, " \
-                              f"now {kernel_source_sha()}): not reported"
+        roof = encoder_roofline(agent, wl, C, b_rank, n_fwd, ms_fwd, steps_timed, args.workload, graphed, use_traffic=not args.batch and not dist_on)
         out = {
             "metric": "SAC gradient steps/sec (encoder+update) on B=256, N=1024 pts" if args.workload == "k1" else f"SAC gradient steps/sec ({args.workload})",
             "value": args.steps / elapsed, "unit": "gradient steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -498,11 +559,7 @@ def main():
                        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist_on else None,
                        "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1, "exchange": exch_mode,
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
-            "roofline": {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * agent.encoder.mlp_spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
-                         "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
-                         "algorithmic_flops_per_launch": flops_per_launch},
+            "roofline": roof,
             "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
         }
         if nocomm_ms is not None:
@@ -510,11 +567,11 @@ def main():
             out["comm_ms_per_step"] = elapsed / args.steps * 1e3 - nocomm_ms
         if dist_on and world == 1:
             out["debug"] = f"single-rank exchange over backend {args.backend}: data-parallel schedule with a one-rank process group"
-        if not dist_on and not args.no_cpu_baseline and wl["cfg"].startswith("sac"):
+        if not dist_on and not args.no_cpu_baseline:
             # bounded samples (about 10-30 s of CPU work each): every granted core on a slice of the batch that takes a few
             # seconds per step, and the reference's shipped single-thread setting (pyrl/utils/meta/__init__.py:38-49) on a
             # smaller slice
-            points = wl["B"] * wl["N"]
+            points = wl["B"] * wl["N"] * getattr(agent, "num_aug", 1)
             all_cores_b = wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points))
             out["cpu_baseline"] = cpu_baseline(agent, wl, args.cpu_steps, args.cpu_threads, sample_batch=all_cores_b)
             if not args.cpu_threads:
@@ -594,8 +651,17 @@ def run_extras(args, extras, plain_k1, rank, world, device, dist_on, held):
         memory = None
         held.clear()
         torch.cuda.empty_cache()
-        extras["config4_k3"] = dict(side_rate("k3", rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs),
+        extras["config4_k3"] = dict(side_rate("k3", rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs, roofline=True),
                                     workload=WORKLOADS["k3"]["desc"])
+        # BASELINE configs 3 and 5 as worded, same protocol, each with its own roofline object (and, at N = 1, config 3's CPU
+        # baseline: the DrQ restatement on a bounded slice) -- every BASELINE config is in the driver's line
+        for key, name in (("config3_k2", "k2"), ("config5_k4", "k4")):
+            if WORKLOADS[name]["B"] % world:
+                continue
+            torch.cuda.empty_cache()
+            extras[key] = dict(side_rate(name, rank, world, device, dist_on, args.extra_steps, 30, graphs=not args.no_graphs, roofline=True,
+                                         cpu_steps=(2 if (name == "k2" and not dist_on and not args.no_cpu_baseline) else 0), cpu_threads=args.cpu_threads),
+                               workload=WORKLOADS[name]["desc"])
 
 
 if __name__ == "__main__":

@@ -290,16 +290,20 @@ class RefAgent:
                     t.copy_(t * (1.0 - tau) + self.P[k] * tau)
 
     # -- augmentation ----------------------------------------------------------------------
-    def _aug(self, obs, noise):
-        """GDict.repeat(num_aug, 0) = repeat_interleave of every leaf (array_ops.py:106-121), then
-        RandomJitterPoints on xyz (pcd_aug.py:316-322) with the injected noise."""
+    def _aug(self, obs, noise, affine=None):
+        """GDict.repeat(num_aug, 0) = repeat_interleave of every leaf (array_ops.py:106-121), then -- in the order of the
+        obs_aug list [GlobalRotScaleTrans, RandomJitterPoints] -- apply_rot_trans on xyz with the injected [rows, 3, 4] matrices
+        (pcd_aug.py:84-123: einsum("bin,bji->bjn", x, rot) + xyz[..., None]) and RandomJitterPoints (pcd_aug.py:316-322) with the
+        injected noise."""
         rep = {k: torch.repeat_interleave(v, self.num_aug, dim=0) for k, v in obs.items()}
+        if affine is not None:
+            rep["xyz"] = torch.einsum("bin,bji->bjn", rep["xyz"], affine[:, :, :3]) + affine[:, :, 3:]
         if noise is not None:
             rep["xyz"] = rep["xyz"] + noise
         return rep
 
     # -- the update step ---------------------------------------------------------------------
-    def update_parameters(self, batch, updates, eps_list, jitter_list=None, relu_masks=None):
+    def update_parameters(self, batch, updates, eps_list, jitter_list=None, relu_masks=None, affine_list=None):
         """relu_masks (tests only): {"q": [head][layer], "pi": [layer], "q_pi": [head][layer]} ReLU decisions of the
         gradient-carrying head passes taken from the implementation under test (see linear_mlp)."""
         P = self.P
@@ -318,8 +322,8 @@ class RefAgent:
             actions = torch.repeat_interleave(actions, 2, dim=0)
         elif self.kind == "drq":
             # drq.py:52-63
-            obs = self._aug(obs, jitter_list[0] if jitter_list else None)
-            next_obs = self._aug(next_obs, jitter_list[1] if jitter_list else None)
+            obs = self._aug(obs, jitter_list[0] if jitter_list else None, affine_list[0] if affine_list else None)
+            next_obs = self._aug(next_obs, jitter_list[1] if jitter_list else None, affine_list[1] if affine_list else None)
             actions = torch.repeat_interleave(actions, self.num_aug, dim=0)
             rewards = torch.repeat_interleave(rewards, self.num_aug, dim=0)
             dones = torch.repeat_interleave(dones, self.num_aug, dim=0)

@@ -741,3 +741,103 @@ def test_jitter_shares_the_steps_device_counter(cuda):
     assert c.aug["seed"] == aug.seed == d.aug["seed"]
     assert int(d.aug["offset_tensor"]) == int(c.aug["offset_tensor"]) + 1
 
+
+
+def test_affine_sample_kernel_draws_the_reference_s_matrix_family(cuda):
+    """pcrl_affine_sample_f32 (GlobalRotScaleTrans's draw as one launch): every matrix has the structure the reference builds
+    (pcd_aug.py:178-196) -- diag(s) R_axis(angle) with angle / s_i inside their ranges, translation (u - 0.5) * 2 * range, zero for
+    the LAST cloud unless shift_height, identity block without a rotation range -- the draws have the uniform law's first two
+    moments, are reproducible for a fixed (seed, offset), change with either, and follow a device-side offset slot."""
+    from pointcloud_rl_amd import hip
+    B = 4096
+    rot, sc, tr = [-0.15, 0.15], [0.95, 1.05], [0.1, 0.2, 0.3]
+    draw = lambda **kw: hip.affine_sample(torch.empty(B, 3, 4, device=cuda), **dict(dict(rot_axis=2, rot_range=rot, scale_range=sc, translation_range=tr,
+                                                                                        shift_height=False, seed=9, offset=0), **kw))
+    m = draw()
+    assert torch.equal(m, draw()) and not torch.equal(m, draw(offset=1)) and not torch.equal(m, draw(seed=10))
+    off = torch.tensor([1], dtype=torch.int64, device=cuda)
+    assert torch.equal(draw(offset_tensor=off), draw(offset=1))
+    v = m.double().cpu().numpy()
+    s = np.linalg.norm(v[:, :, :3], axis=2)                                   # row norms of diag(s) R = s_i
+    assert s.min() >= 0.95 - 1e-6 and s.max() <= 1.05 + 1e-6
+    R = v[:, :, :3] / s[:, :, None]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-5
+    assert np.abs(R[:, 2, 2] - 1).max() < 1e-6 and np.abs(R[:, 2, :2]).max() < 1e-6 and np.abs(R[:, :2, 2]).max() < 1e-6      # about z
+    ang = np.arctan2(R[:, 1, 0], R[:, 0, 0])
+    assert ang.min() >= -0.15 - 1e-6 and ang.max() <= 0.15 + 1e-6
+    for x, lo, hi in [(ang, *rot)] + [(s[:, i], *sc) for i in range(3)] + [(v[:-1, i, 3], -tr[i], tr[i]) for i in range(3)]:
+        w = hi - lo
+        assert abs(x.mean() - (lo + hi) / 2) < 5 * (w / np.sqrt(12)) / np.sqrt(len(x))
+        assert abs(x.var() - w * w / 12) < 0.08 * w * w / 12
+    assert np.abs(np.corrcoef(np.stack([ang, s[:, 0], s[:, 1], s[:, 2], v[:, 0, 3]]))[np.triu_indices(5, 1)]).max() < 0.06
+    assert np.all(v[-1, :, 3] == 0) and np.any(draw(shift_height=True)[-1, :, 3].cpu().numpy() != 0)       # delta_xyz[-1] = 0
+    ident = draw(rot_range=None, translation_range=None)                      # the scale has nothing to act on, as in the reference
+    assert torch.equal(ident[:, :, :3], torch.eye(3, device=cuda).expand(B, 3, 3)) and torch.all(ident[:, :, 3] == 0)
+
+
+def test_drq_jitter_plus_scale_step_matches_the_restatement_and_draws_fresh_matrices(cuda):
+    """BASELINE config 3 as worded ("jitter+scale aug fused into encoder kernel"): DrQ with obs_aug = [GlobalRotScaleTrans(rotation +
+    per-axis scale), RandomJitterPoints].  (a) With the matrices and the noise injected on both sides the fused HIP step equals the
+    CPU restatement of the reference's step (apply_rot_trans, then the jitter).  (b) Fed by a device replay and replayed from a
+    hipGraph, the matrices come from ONE launch per call keyed by the step's device counter: fresh every step, no ATen launches."""
+    from oracle import torch_ref
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.augmentations import GlobalRotScaleTrans, RandomJitterPoints
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    B, N, A = 8, 96, 4
+    cfg = configs.drq_dmc(6, A, B, head_hidden=64, obs_aug=[configs.ROT_SCALE, configs.JITTER])
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg)
+    assert [type(t) for t in agent.obs_aug.transforms] == [GlobalRotScaleTrans, RandomJitterPoints]
+    params = {n: p.detach().clone() for n, p in agent.named_parameters()}
+    ref = torch_ref.RefAgent(params, kind="drq", gamma=agent.gamma, alpha=0.1, target_entropy=agent.target_entropy,
+                             update_coeff=agent.update_coeff["default"], num_aug=2, mirror_redundancy=False)
+    agent = agent.to(cuda)
+    g = torch.Generator().manual_seed(4)
+    rst = agent.obs_aug[0]
+
+    class Mem:
+        def __init__(self, b):
+            self.b = b
+
+        def sample(self, n):
+            return self
+
+        def to_torch(self, device=None, non_blocking=False):
+            from pointcloud_rl_amd.utils.torch_utils import to_torch
+            return to_torch(self.b, device=device)
+    for u in (1, 2):
+        batch_np = make_batch_np(B, N, A, seed=30 + u)
+        cpu_batch = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch_np.items()}
+        eps = [torch.randn(2 * B, A, generator=g)] + ([torch.randn(B, A, generator=g)] if u % 2 == 0 else [])
+        jit = [torch.empty(2 * B, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)]
+        aff = [rst.sample_matrix(2 * B, "cpu") for _ in range(2)]
+        assert all(float(m[:, :, 3].abs().max()) == 0 for m in aff)                      # translation_range=None
+        agent.actor.head.noise_override = [e.to(cuda) for e in eps]
+        agent.obs_aug[0].matrix_override = [m.to(cuda) for m in aff]
+        agent.obs_aug[1].noise_override = [j.to(cuda) for j in jit]
+        got = agent.update_parameters(Mem(batch_np), u)
+        assert agent._fused is not None
+        want = ref.update_parameters(cpu_batch, u, eps, jit, affine_list=aff)
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 5e-5 * max(1.0, abs(v)), (u, k, got[k], v)
+    for n, p in agent.named_parameters():
+        err = (p.detach().cpu() - ref.P[n].detach()).abs()
+        assert (err <= 1e-5).float().mean() >= 0.999 and err.max() <= 2e-4, (n, float(err.max()))
+    # (b) device replay + hipGraph: one affine_sample launch per augmentation call, fresh matrices on every replay
+    mem = DeviceReplay(64, device=cuda, seed=3)
+    mem.push_batch(make_batch_np(64, N, A, seed=40))
+    agent.enable_graphs(warmup=1)
+    seen, losses = [], []
+    for u in range(3, 13):
+        losses.append(agent.update_parameters(mem, u)["drq/critic_loss"])
+        torch.cuda.synchronize()
+        seen.append(torch.stack([m.clone() for m in rst._mats.values()]))
+    assert len(rst._mats) == 2 and agent._graphs                                        # obs and next_obs: two persistent buffers
+    for a, b in zip(seen[3:-1], seen[4:]):
+        assert not torch.equal(a, b)                                                     # replayed launches drew again
+    assert not torch.equal(seen[-1][0], seen[-1][1])                                     # the two calls of a step differ
+    assert np.isfinite(losses).all() and len(set(np.round(losses, 7))) == len(losses)
