@@ -239,6 +239,20 @@ int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* e
                        int32_t* step_counter, float* grad_norm_out,
                        float* target, size_t target_begin, size_t target_end, float tau,
                        void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream);
+/* The same pass with a second, small optimizer riding on the launch in one extra workgroup: SAC's temperature next to the actor
+ * (sac.py:184-195 steps actor_optim and alpha_optim back to back; log_alpha is one float with its own betas, moments and step
+ * count).  rider->partial: one float of scratch; rider_defer as defer_finalize (NULL: finished right away by a second launch). */
+typedef struct pcrl_adam_rider {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; size_t n;      /* 1 <= n <= 4096 */
+    float lr, beta1, beta2, eps, grad_scale; int32_t _pad;
+    int32_t* step_counter; float* grad_norm_out; float* partial;
+} pcrl_adam_rider;
+int pcrl_adam_step_rider_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                             float lr, float beta1, float beta2, float eps, float grad_scale,
+                             int32_t* step_counter, float* grad_norm_out,
+                             float* target, size_t target_begin, size_t target_end, float tau,
+                             void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
+                             const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream);
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 
@@ -384,6 +398,23 @@ int pcrl_q_tail_actor_f32(const float* h2, int64_t h2_head_stride, const float* 
                           const float* neg_logp, const float* log_alpha, int32_t M, int32_t H, float* q, int64_t ld_q,
                           float* dq, int64_t ld_dq, float* dh2, int64_t dh2_head_stride, float* d_neglogp, float* stat_part,
                           void* stream);
+/* pcrl_q_tail_actor_f32 whose launch also writes, from extra workgroups, columns [col0, col0 + ncols) of the two heads' FIRST
+ * layer weight w0 [2][H][ld_w0] as the compact image cols_out [2][ncols][H] -- the action columns pcrl_policy_tail_bwd_f32 reads. */
+int pcrl_q_tail_actor_cols_f32(const float* h2, int64_t h2_head_stride, const float* w2, const float* b2, int64_t w_head_stride,
+                               const float* neg_logp, const float* log_alpha, int32_t M, int32_t H, float* q, int64_t ld_q,
+                               float* dq, int64_t ld_dq, float* dh2, int64_t dh2_head_stride, float* d_neglogp, float* stat_part,
+                               const float* w0, int64_t w0_head_stride, int32_t ld_w0, int32_t col0, int32_t ncols, float* cols_out,
+                               void* stream);
+/* The actor phase's backward between the Q heads' dh1 and the policy's dh2 in ONE launch (autograd of sac.py:177-189 through
+ * visuomotor.py:130-144, gaussian.py:83-87, mlp.py:97-100): d_action = sum_h dh1_h W0_h[:, action columns] (w0_action_cols [2][A][H]
+ * from pcrl_q_tail_actor_cols_f32), pcrl_tanh_gaussian_bwd_f32's arithmetic -> d_feat [M][2A], and the policy's last layer's data
+ * gradient dh2 = (d_feat w2) (.) [h2 > 0] (w2 [2A][H]).  With stat_part != NULL one more workgroup does pcrl_actor_finalize_f32. */
+int pcrl_policy_tail_bwd_f32(const float* dh1, int64_t dh1_head_stride, const float* w0_action_cols, int64_t w0a_head_stride,
+                             int32_t M, int32_t H, int32_t A, const float* feat, int64_t ld_feat, const float* eps, const float* saved,
+                             const float* scale, float log_std_min, float log_std_max, float epsilon, const float* d_neglogp,
+                             float* d_feat, int64_t ld_d_feat, const float* h2, const float* w2, float* dh2,
+                             const float* stat_part, const float* log_alpha, float target_entropy, float* alpha_grad, float* stats,
+                             void* stream);
 int pcrl_actor_finalize_f32(const float* stat_part, int32_t M, const float* log_alpha, float target_entropy, float* alpha_grad,
                             float* stats, void* stream);
 int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,

@@ -47,6 +47,13 @@ class AdamPending(ctypes.Structure):
                 ("grad_norm_out", ctypes.c_void_p), ("step_counter", ctypes.c_void_p)]
 
 
+class AdamRider(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p), ("exp_avg_sq", ctypes.c_void_p),
+                ("n", ctypes.c_size_t), ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("grad_scale", ctypes.c_float), ("_pad", ctypes.c_int32), ("step_counter", ctypes.c_void_p), ("grad_norm_out", ctypes.c_void_p),
+                ("partial", ctypes.c_void_p)]
+
+
 class LnJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
                 ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),

@@ -63,6 +63,10 @@ struct QTailParams {
     float* part; int part_ld;                      // critic: [n_wg][2][part_ld]: dW2 partial (cols < H), db2 partial (col H)
     float* stat_part;                              // [n_wg][4]: critic {sum d^2, max |d|, sum min_h q, sum y}; actor {sum min_h q, sum nlp, -, -}
     float* d_neglogp;                              // actor: device scalar = -alpha / M
+    // extra workgroups behind the row blocks (actor mode, optional): columns [cg_col0, cg_col0 + cg_ncols) of the two heads'
+    // FIRST layer weight w0 [2][H][cg_ld] written as a compact image cg_dst [2][cg_ncols][H] -- the action columns, which
+    // policy_tail_bwd_kernel contracts with dh1 (coalesced 16-byte rows instead of 4-byte loads cg_ld floats apart)
+    const float* cg_w0; long long cg_hs; int cg_ld, cg_col0, cg_ncols; float* cg_dst;
 };
 
 template <int NC>
@@ -72,6 +76,16 @@ __global__ __launch_bounds__(256) void q_tail_kernel(const QTailParams p) {
     __shared__ float s_db[4][2];
     extern __shared__ __attribute__((aligned(16))) float s_dw[];          // critic: [4 waves][2][H]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_row_blocks = (p.M + 3) >> 2;
+    if ((int)blockIdx.x >= n_row_blocks) {         // column-gather workgroups: one element per thread, coalesced stores
+        const int per_head = p.cg_ncols * p.H;
+        const int i = ((int)blockIdx.x - n_row_blocks) * 256 + (int)threadIdx.x;
+        if (i < 2 * per_head) {
+            const int h = i / per_head, r = i - h * per_head, j = r / p.H, col = r - j * p.H;
+            p.cg_dst[i] = p.cg_w0[h * p.cg_hs + (long long)col * p.cg_ld + p.cg_col0 + j];
+        }
+        return;
+    }
     const int m = blockIdx.x * 4 + wave;
     const bool live = m < p.M;
     const int mr = live ? m : p.M - 1;
@@ -185,12 +199,12 @@ struct ActorFinalizeParams {
     const float* log_alpha; float target_entropy;
     float* alpha_grad; float* stats;               // stats [3]: actor_loss, entropy, alpha_loss
 };
-__global__ __launch_bounds__(64) void actor_finalize_kernel(const ActorFinalizeParams p) {
+__device__ __forceinline__ void actor_finalize_wave(const ActorFinalizeParams& p, int lane) {
     // one wave; lane l sums workgroups l, l + 64, ... in order, then a fixed butterfly
     float sq = 0.0f, se = 0.0f;
-    for (int i = threadIdx.x; i < p.n_wg; i += 64) { sq += p.stat_part[(long long)i * 4]; se += p.stat_part[(long long)i * 4 + 1]; }
+    for (int i = lane; i < p.n_wg; i += 64) { sq += p.stat_part[(long long)i * 4]; se += p.stat_part[(long long)i * 4 + 1]; }
     sq = wave_sum(sq); se = wave_sum(se);
-    if (threadIdx.x == 0) {
+    if (lane == 0) {
         const float alpha = expf(p.log_alpha[0]);
         const float entropy = se / (float)p.M;
         p.stats[0] = -(sq / (float)p.M + alpha * entropy);
@@ -198,6 +212,116 @@ __global__ __launch_bounds__(64) void actor_finalize_kernel(const ActorFinalizeP
         const float al = alpha * (entropy - p.target_entropy);
         p.stats[2] = al;
         p.alpha_grad[0] = al;                      // d/d(log_alpha) of exp(log_alpha) * c = exp(log_alpha) * c
+    }
+}
+__global__ __launch_bounds__(64) void actor_finalize_kernel(const ActorFinalizeParams p) { actor_finalize_wave(p, threadIdx.x); }
+
+// ---- policy tail, backward -------------------------------------------------------------------------------------------------
+// Three launches of the actor phase in one (sac.py:177-189 backward): the Q heads' first-layer data gradient restricted to the
+// action columns, d_act = sum_h dh1_h W0_h[:, action columns] (a GEMM with n = A outputs), TanhGaussianHead's backward
+// (tanh_gaussian_bwd_kernel: d(mean | log_std) from d_act and d(-log pi)), and the policy's last layer's data gradient
+// dh2 = (dfeat W2) (.) [h2 > 0] (a GEMM with k = 2A).  A wave owns a row.  One more workgroup runs actor_finalize.
+struct PolicyTailBwdParams {
+    const float* dh1; long long dh1_hs;            // Q(s, pi) heads' dh1 [2][M][H], ReLU mask applied
+    const float* w0a; long long w0a_hs;            // [2][A][H]: the action columns of the heads' first layer (q_tail's column gather)
+    int M, H, A;
+    const float* feat; long long ld_feat; const float* eps; const float* saved; const float* scale;
+    float ls_min, ls_max, epsilon; const float* d_neglogp;
+    float* dfeat; long long ld_dfeat;              // [M][2A]
+    const float* h2; const float* w2; float* dh2;  // policy: h2 [M][H], w2 [2A][H], dh2 [M][H]
+    int fin_on; ActorFinalizeParams fin;
+};
+
+template <int NC>
+__global__ __launch_bounds__(256) void policy_tail_bwd_kernel(const PolicyTailBwdParams p) {
+    __shared__ float s_v[4][64];                   // [wave]: d_act [A], then dfeat [2A]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_row_blocks = (p.M + 3) >> 2;
+    if ((int)blockIdx.x >= n_row_blocks) {
+        if (wave == 0 && p.fin_on) actor_finalize_wave(p.fin, lane);
+        return;
+    }
+    const int m = blockIdx.x * 4 + wave;
+    const bool live = m < p.M;
+    const int mr = live ? m : p.M - 1;
+    {
+        f32x4 dv[2][NC];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) tail_load_row<NC>(p.dh1 + h * p.dh1_hs + (long long)mr * p.H, lane, dv[h]);
+        for (int j0 = 0; j0 < p.A; j0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float s = 0.0f;
+                if (j0 + k < p.A) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 wv[NC];
+                        tail_load_row<NC>(p.w0a + h * p.w0a_hs + (long long)(j0 + k) * p.H, lane, wv);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(dv[h][c][e], wv[c][e], s);
+                    }
+                }
+                v[k] = s;
+            }
+            allreduce_add32_x16(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float lo, hi;
+                both_halves(v[k], lo, hi);
+                if (lane == 0 && j0 + k < p.A) s_v[wave][j0 + k] = lo + hi;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // TanhGaussianHead backward, lane = action dimension (the arithmetic of tanh_gaussian_bwd_kernel)
+    float g_u = 0.0f, g_ls = 0.0f;
+    if (lane < p.A) {
+        const int j = lane;
+        const float ga = s_v[wave][j];
+        const float t = p.saved[(long long)mr * 2 * p.A + j], std = p.saved[(long long)mr * 2 * p.A + p.A + j];
+        const float e = p.eps[(long long)mr * p.A + j], sc = p.scale[j];
+        const float ls = p.feat[(long long)mr * p.ld_feat + p.A + j];
+        const float g_lp = -p.d_neglogp[0];
+        const float omt2 = 1.0f - t * t;
+        const float sq = 2.0f * sc * t * omt2 / (sc * omt2 + p.epsilon);
+        g_u = ga * sc * omt2 + g_lp * sq;
+        const float g_std = g_u * e + g_lp * (-1.0f / std);
+        g_ls = (ls >= p.ls_min && ls <= p.ls_max) ? g_std * std : 0.0f;
+        if (live) { p.dfeat[(long long)m * p.ld_dfeat + j] = g_u; p.dfeat[(long long)m * p.ld_dfeat + p.A + j] = g_ls; }
+    }
+    __builtin_amdgcn_wave_barrier();               // every lane has read its d_act before the slots are re-used
+    if (lane < p.A) { s_v[wave][lane] = g_u; s_v[wave][p.A + lane] = g_ls; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // dh2[m][:] = sum_n dfeat[m][n] W2[n][:], masked by the ReLU that produced h2
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = 0; n < 2 * p.A; ++n) {
+        const float g = s_v[wave][n];
+        f32x4 wv[NC];
+        tail_load_row<NC>(p.w2 + (long long)n * p.H, lane, wv);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] = __builtin_fmaf(g, wv[c][e], acc[c][e]);
+    }
+    if (live) {
+        f32x4 hv[NC];
+        tail_load_row<NC>(p.h2 + (long long)m * p.H, lane, hv);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = hv[c][e] > 0.0f ? acc[c][e] : 0.0f;
+            *reinterpret_cast<f32x4*>(p.dh2 + (long long)m * p.H + 256 * c + 4 * lane) = o;
+        }
     }
 }
 
@@ -334,7 +458,7 @@ extern "C" int pcrl_q_tail_workspace_floats(int32_t M, int32_t H, size_t* part_f
 
 static int q_tail_launch(const QTailParams& p, hipStream_t st) {
     if (p.H % 256 || p.H < 256 || p.H > 256 * kTailMaxChunks) return fail(PCRL_E_ARG, "head tail: H must be a multiple of 256, <= %d (got %d)", 256 * kTailMaxChunks, p.H);
-    const int grid = (p.M + 3) / 4;
+    const int grid = (p.M + 3) / 4 + (p.cg_dst ? (2 * p.cg_ncols * p.H + 255) / 256 : 0);
     const size_t lds = p.mode == 0 ? sizeof(float) * 8 * (size_t)p.H : 0;
     switch (p.H / 256) {
 #define PCRL_QT_CASE(NC_) case NC_: \
@@ -378,6 +502,50 @@ extern "C" int pcrl_q_tail_actor_f32(const float* h2, int64_t h2_head_stride, co
     p.group = 1; p.rd_div = 1; p.M = M; p.H = H; p.q = q; p.ld_q = ld_q; p.dq = dq; p.ld_dq = ld_dq; p.dh2 = dh2; p.dh2_hs = dh2_head_stride;
     p.d_neglogp = d_neglogp; p.stat_part = stat_part;
     return q_tail_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int pcrl_q_tail_actor_cols_f32(const float* h2, int64_t h2_head_stride, const float* w2, const float* b2, int64_t w_head_stride,
+                                          const float* neg_logp, const float* log_alpha, int32_t M, int32_t H, float* q, int64_t ld_q,
+                                          float* dq, int64_t ld_dq, float* dh2, int64_t dh2_head_stride, float* d_neglogp, float* stat_part,
+                                          const float* w0, int64_t w0_head_stride, int32_t ld_w0, int32_t col0, int32_t ncols, float* cols_out,
+                                          void* stream) {
+    if (!h2 || !w2 || !b2 || !neg_logp || !log_alpha || !q || !dq || !dh2 || !d_neglogp || !stat_part) return fail(PCRL_E_ARG, "NULL argument");
+    if (M < 1) return fail(PCRL_E_ARG, "bad shape");
+    if (!w0 || !cols_out || ncols < 1 || col0 < 0 || col0 + ncols > ld_w0) return fail(PCRL_E_ARG, "q tail: bad column gather (col0=%d ncols=%d ld=%d)", col0, ncols, ld_w0);
+    QTailParams p{};
+    p.mode = 1; p.h2 = h2; p.h2_hs = h2_head_stride; p.w2 = w2; p.b2 = b2; p.w_hs = w_head_stride; p.nlp = neg_logp; p.log_alpha = log_alpha;
+    p.group = 1; p.rd_div = 1; p.M = M; p.H = H; p.q = q; p.ld_q = ld_q; p.dq = dq; p.ld_dq = ld_dq; p.dh2 = dh2; p.dh2_hs = dh2_head_stride;
+    p.d_neglogp = d_neglogp; p.stat_part = stat_part;
+    p.cg_w0 = w0; p.cg_hs = w0_head_stride; p.cg_ld = ld_w0; p.cg_col0 = col0; p.cg_ncols = ncols; p.cg_dst = cols_out;
+    return q_tail_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int pcrl_policy_tail_bwd_f32(const float* dh1, int64_t dh1_head_stride, const float* w0_action_cols, int64_t w0a_head_stride,
+                                        int32_t M, int32_t H, int32_t A, const float* feat, int64_t ld_feat, const float* eps, const float* saved,
+                                        const float* scale, float log_std_min, float log_std_max, float epsilon, const float* d_neglogp,
+                                        float* d_feat, int64_t ld_d_feat, const float* h2, const float* w2, float* dh2,
+                                        const float* stat_part, const float* log_alpha, float target_entropy, float* alpha_grad, float* stats,
+                                        void* stream) {
+    if (!dh1 || !w0_action_cols || !feat || !eps || !saved || !scale || !d_neglogp || !d_feat || !h2 || !w2 || !dh2) return fail(PCRL_E_ARG, "NULL argument");
+    if (M < 1 || A < 1 || 2 * A > 64) return fail(PCRL_E_ARG, "policy tail: 1 <= A <= 32 (got %d)", A);
+    if (H % 256 || H < 256 || H > 1024) return fail(PCRL_E_ARG, "policy tail: H must be 256, 512, 768 or 1024 (got %d)", H);
+    if (stat_part && (!log_alpha || !alpha_grad || !stats)) return fail(PCRL_E_ARG, "policy tail: the finalize part needs log_alpha, alpha_grad and stats");
+    PolicyTailBwdParams p{};
+    p.dh1 = dh1; p.dh1_hs = dh1_head_stride; p.w0a = w0_action_cols; p.w0a_hs = w0a_head_stride; p.M = M; p.H = H; p.A = A;
+    p.feat = feat; p.ld_feat = ld_feat; p.eps = eps; p.saved = saved; p.scale = scale; p.ls_min = log_std_min; p.ls_max = log_std_max;
+    p.epsilon = epsilon; p.d_neglogp = d_neglogp; p.dfeat = d_feat; p.ld_dfeat = ld_d_feat; p.h2 = h2; p.w2 = w2; p.dh2 = dh2;
+    p.fin_on = stat_part != nullptr;
+    p.fin = ActorFinalizeParams{stat_part, (M + 3) / 4, M, log_alpha, target_entropy, alpha_grad, stats};
+    const int grid = (M + 3) / 4 + (p.fin_on ? 1 : 0);
+    hipStream_t st = (hipStream_t)stream;
+    switch (H / 256) {
+        case 1: hipLaunchKernelGGL(policy_tail_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(policy_tail_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
+        case 3: hipLaunchKernelGGL(policy_tail_bwd_kernel<3>, dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL(policy_tail_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p); break;
+    }
+    PCRL_CHECK_LAUNCH("policy_tail_bwd_kernel");
+    return PCRL_OK;
 }
 
 extern "C" int pcrl_actor_finalize_f32(const float* stat_part, int32_t M, const float* log_alpha, float target_entropy, float* alpha_grad,

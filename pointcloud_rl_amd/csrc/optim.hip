@@ -24,6 +24,15 @@ struct AdamParams {
     long long t_begin, t_end;
     float tau;
     float* partial;           // [gridDim.x] sum of (scaled) grad^2 per block
+    int main_blocks;          // blocks that sweep the buffer above; one more block (if any) does the rider
+};
+
+// A second, tiny optimizer riding on the launch (SAC's temperature next to the actor: one float, its own betas, moments and
+// step count -- sac.py:192-195 steps them back to back): handled by ONE extra block, element by element.
+struct AdamRider {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq; long long n;
+    float lr, beta1, beta2, eps, grad_scale;
+    const int* step; float* partial;          // partial[0] = sum of (scaled) grad^2
 };
 
 __device__ __forceinline__ void adam_elem(const AdamParams& p, float g_raw, float& m, float& v, float& w,
@@ -35,13 +44,35 @@ __device__ __forceinline__ void adam_elem(const AdamParams& p, float g_raw, floa
     w = w - step_size * (m / (__builtin_sqrtf(v) / bc2_sqrt + p.eps));
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamParams p) {
+__device__ __forceinline__ void adam_rider_block(const AdamRider& r) {
+    const float step = (float)(r.step[0] + 1);
+    const float bc1 = 1.0f - powf(r.beta1, step);
+    const float bc2_sqrt = __builtin_sqrtf(1.0f - powf(r.beta2, step));
+    const float step_size = r.lr / bc1;
+    float gsq = 0.0f;
+    for (long long j = threadIdx.x; j < r.n; j += 256) {
+        const float g = r.grad[j] * r.grad_scale;
+        gsq = __builtin_fmaf(g, g, gsq);
+        const float m = r.beta1 * r.exp_avg[j] + (1.0f - r.beta1) * g;
+        const float v = r.beta2 * r.exp_avg_sq[j] + (1.0f - r.beta2) * g * g;
+        r.exp_avg[j] = m; r.exp_avg_sq[j] = v;
+        r.param[j] = r.param[j] - step_size * (m / (__builtin_sqrtf(v) / bc2_sqrt + r.eps));
+    }
+    for (int off = 32; off > 0; off >>= 1) gsq += __shfl_down(gsq, off, 64);
+    __shared__ float s_rider[4];
+    if ((threadIdx.x & 63) == 0) s_rider[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) r.partial[0] = (s_rider[0] + s_rider[1]) + (s_rider[2] + s_rider[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const AdamRider rider) {
+    if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
     const float step = (float)(p.step[0] + 1);
     const float bc1 = 1.0f - powf(p.beta1, step);
     const float bc2_sqrt = __builtin_sqrtf(1.0f - powf(p.beta2, step));
     const float step_size = p.lr / bc1;
     float gsq = 0.0f;
-    const long long stride = (long long)gridDim.x * blockDim.x * 4;
+    const long long stride = (long long)p.main_blocks * blockDim.x * 4;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < p.n; i += stride) {
         if (i + 3 < p.n) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.grad + i);
@@ -123,21 +154,38 @@ extern "C" int pcrl_adam_workspace_bytes(size_t n, size_t* bytes) {
     return PCRL_OK;
 }
 
-extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
-                                  float lr, float beta1, float beta2, float eps, float grad_scale,
-                                  int32_t* step_counter, float* grad_norm_out,
-                                  float* target, size_t target_begin, size_t target_end, float tau,
-                                  void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream) {
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                       int32_t* step_counter, float* grad_norm_out,
+                       float* target, size_t target_begin, size_t target_end, float tau,
+                       void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
+                       const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return fail(PCRL_E_ARG, "NULL argument");
     if (n == 0) return PCRL_OK;
     if (target && !(target_begin <= target_end && target_end <= n)) return fail(PCRL_E_ARG, "bad Polyak range");
     const int grid = adam_grid((long long)n);
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)grid) return fail(PCRL_E_WORKSPACE, "workspace too small");
+    AdamRider r{};
+    if (rider) {
+        if (!rider->param || !rider->grad || !rider->exp_avg || !rider->exp_avg_sq || !rider->step_counter || !rider->partial || rider->n < 1 || rider->n > 4096)
+            return fail(PCRL_E_ARG, "adam rider: NULL argument or n outside [1, 4096]");
+        r = AdamRider{rider->param, rider->grad, rider->exp_avg, rider->exp_avg_sq, (long long)rider->n, rider->lr, rider->beta1, rider->beta2,
+                      rider->eps, rider->grad_scale, rider->step_counter, rider->partial};
+    }
     hipStream_t st = (hipStream_t)stream;
     AdamParams p{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, grad_scale, step_counter,
-                 target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace)};
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p);
+                 target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace), grid};
+    hipLaunchKernelGGL(adam_kernel, dim3(grid + (rider ? 1 : 0)), dim3(256), 0, st, p, r);
     PCRL_CHECK_LAUNCH("adam_kernel");
+    if (rider) {
+        if (rider_defer) {
+            rider_defer->partial = rider->partial; rider_defer->n_partial = 1;
+            rider_defer->grad_norm_out = rider->grad_norm_out; rider_defer->step_counter = rider->step_counter;
+        } else {
+            hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, rider->partial, 1, rider->grad_norm_out, rider->step_counter);
+            PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
+        }
+    }
     if (defer_finalize) {       // the caller's end-of-step pcrl_gather_scalars_f32 launch sums the partials and advances the step count
         defer_finalize->partial = p.partial; defer_finalize->n_partial = grid;
         defer_finalize->grad_norm_out = grad_norm_out; defer_finalize->step_counter = step_counter;
@@ -146,6 +194,26 @@ extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_av
     hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, st, p.partial, grid, grad_norm_out, step_counter);
     PCRL_CHECK_LAUNCH("gradnorm_finalize_kernel");
     return PCRL_OK;
+}
+
+extern "C" int pcrl_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                  float lr, float beta1, float beta2, float eps, float grad_scale,
+                                  int32_t* step_counter, float* grad_norm_out,
+                                  float* target, size_t target_begin, size_t target_end, float tau,
+                                  void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize, void* stream) {
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, target, target_begin,
+                       target_end, tau, workspace, workspace_bytes, defer_finalize, nullptr, nullptr, stream);
+}
+
+extern "C" int pcrl_adam_step_rider_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                        float lr, float beta1, float beta2, float eps, float grad_scale,
+                                        int32_t* step_counter, float* grad_norm_out,
+                                        float* target, size_t target_begin, size_t target_end, float tau,
+                                        void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
+                                        const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream) {
+    if (!rider) return fail(PCRL_E_ARG, "rider is NULL");
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, target, target_begin,
+                       target_end, tau, workspace, workspace_bytes, defer_finalize, rider, rider_defer, stream);
 }
 
 extern "C" int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream) {

@@ -299,10 +299,27 @@ def adam_workspace_bytes(n):
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, workspace,
-              target=None, target_begin=0, target_end=0, tau=0.0, defer=False):
+              target=None, target_begin=0, target_end=0, tau=0.0, defer=False, rider=None):
     """defer=True: returns an AdamPending that must be passed to gather_scalars(..., pending=[...]) later in the step (it sums
-    the gradient norm and advances the step count); otherwise a second launch does that right away and None is returned."""
+    the gradient norm and advances the step count); otherwise a second launch does that right away and None is returned.
+    rider: dict(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, partial) -- a
+    second small optimizer stepped by one extra workgroup of the same launch; returns (pending, rider's pending) then."""
     pending = _lib.AdamPending() if defer else None
+    if rider is not None:
+        r = _lib.AdamRider(param=rider["param"].data_ptr(), grad=rider["grad"].data_ptr(), exp_avg=rider["exp_avg"].data_ptr(),
+                           exp_avg_sq=rider["exp_avg_sq"].data_ptr(), n=rider["param"].numel(), lr=rider["lr"], beta1=rider["beta1"],
+                           beta2=rider["beta2"], eps=rider["eps"], grad_scale=rider["grad_scale"], step_counter=rider["step_counter"].data_ptr(),
+                           grad_norm_out=rider["grad_norm_out"].data_ptr(), partial=rider["partial"].data_ptr())
+        r_pending = _lib.AdamPending() if defer else None
+        with _span("adam_step"):
+            check(lib().pcrl_adam_step_rider_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
+                                                 ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                                 ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(grad_norm_out),
+                                                 _ptr(target), ctypes.c_size_t(target_begin), ctypes.c_size_t(target_end), ctypes.c_float(tau),
+                                                 _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()),
+                                                 ctypes.byref(pending) if defer else None, ctypes.byref(r), ctypes.byref(r_pending) if defer else None,
+                                                 _stream()))
+        return pending, r_pending
     with _span("adam_step"):
         check(lib().pcrl_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
                                        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
@@ -493,6 +510,29 @@ def q_tail_actor(h2, h2_hs, w2, b2, w_hs, neg_logp, log_alpha, M, H, q, dq, dh2,
         check(lib().pcrl_q_tail_actor_f32(_ptr(h2), ctypes.c_int64(h2_hs), _ptr(w2), _ptr(b2), ctypes.c_int64(w_hs), _ptr(neg_logp), _ptr(log_alpha),
                                           M, H, _ptr(q), ctypes.c_int64(2), _ptr(dq), ctypes.c_int64(2), _ptr(dh2), ctypes.c_int64(M * H),
                                           _ptr(d_neglogp), _ptr(stat_part), _stream()))
+
+
+def q_tail_actor_cols(h2, h2_hs, w2, b2, w_hs, neg_logp, log_alpha, M, H, q, dq, dh2, d_neglogp, stat_part, w0, w0_hs, ld_w0, col0, ncols, cols_out):
+    """q_tail_actor + (extra workgroups) columns [col0, col0 + ncols) of the heads' first-layer weight as cols_out [2, ncols, H]."""
+    assert cols_out.is_contiguous() and cols_out.numel() == 2 * ncols * H
+    with _span("q_tail"):
+        check(lib().pcrl_q_tail_actor_cols_f32(_ptr(h2), ctypes.c_int64(h2_hs), _ptr(w2), _ptr(b2), ctypes.c_int64(w_hs), _ptr(neg_logp), _ptr(log_alpha),
+                                               M, H, _ptr(q), ctypes.c_int64(2), _ptr(dq), ctypes.c_int64(2), _ptr(dh2), ctypes.c_int64(M * H),
+                                               _ptr(d_neglogp), _ptr(stat_part), _ptr(w0), ctypes.c_int64(w0_hs), int(ld_w0), int(col0), int(ncols),
+                                               _ptr(cols_out), _stream()))
+
+
+def policy_tail_bwd(dh1, dh1_hs, w0a, w0a_hs, M, H, A, feat, ld_feat, eps, saved, scale, ls_min, ls_max, epsilon, d_neglogp, d_feat, ld_d_feat,
+                    h2, w2, dh2, finalize=None):
+    """d_action (Q heads' dh1 x action columns) -> TanhGaussianHead backward -> the policy's dh2, one launch; finalize =
+    (stat_part, log_alpha, target_entropy, alpha_grad, stats): one more workgroup does actor_finalize."""
+    _check_f32_vec(scale, A, "scale")
+    fin = finalize or (None, None, 0.0, None, None)
+    with _span("policy_tail_bwd"):
+        check(lib().pcrl_policy_tail_bwd_f32(_ptr(dh1), ctypes.c_int64(dh1_hs), _ptr(w0a), ctypes.c_int64(w0a_hs), M, H, A, _ptr(feat),
+                                             ctypes.c_int64(ld_feat), _ptr(eps), _ptr(saved), _ptr(scale), _f(ls_min), _f(ls_max), _f(epsilon),
+                                             _ptr(d_neglogp), _ptr(d_feat), ctypes.c_int64(ld_d_feat), _ptr(h2), _ptr(w2), _ptr(dh2),
+                                             _ptr(fin[0]), _ptr(fin[1]), _f(fin[2]), _ptr(fin[3]), _ptr(fin[4]), _stream()))
 
 
 def actor_finalize(stat_part, M, log_alpha, target_entropy, alpha_grad, stats):

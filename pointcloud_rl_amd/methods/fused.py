@@ -200,6 +200,7 @@ class FusedStep:
         self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
         self._forked = False
         self.policy_tail_max = int(__import__("os").environ.get("PCRL_POLICY_TAIL_MAX", "4096"))
+        self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -425,10 +426,31 @@ class FusedStep:
             fal = a._flat["alpha"]
             da_h1, da_h2 = self._buf("qa_dh1", 2, Ma, H), self._buf("qa_dh2", 2, Ma, H)
             d_act = self._buf("d_act", 2, Ma, ceil4(A))
+            tail_bwd_done = False
             qa_descs = mlp_forward_descs(self.q, None, 0, XQ_a, ldq, Ma, (qa_h1, qa_h2), 2, q_pi, 1)
             qa_bwd = mlp_backward_descs(self.q, XQ_a, ldq, Ma, qa_h1, qa_h2, dq_pi, (2, 1), 1, da_h1, da_h2, grad=None, dX=d_act,
                                         dx_cols=(F + S, A), ld_dx=ceil4(A))
-            if self.tails:
+            head = a.actor.head
+            dfeat = self._buf("pi_dfeat", Ma, 2 * A)
+            dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
+            if self.tails and self.tail_bwd and Ma * 2 * A <= self.policy_tail_max:
+                # ---- the chain q tail -> dh1 GEMM -> ONE launch for [d_act GEMM, TanhGaussianHead backward, the policy's dh2 GEMM,
+                # actor_finalize] -> the policy's two remaining backward stages (its last layer's dW2 | db2 rides in the first) ----
+                launch_layers(qa_descs[:2])
+                _, n_stat = hip.q_tail_workspace_floats(Ma, H)
+                stat_a = self._buf("qa_tail_stat", n_stat)
+                w0a = self._buf("q_w0_action_cols", 2, A, H)
+                hip.q_tail_actor_cols(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp,
+                                      stat_a, self.q.W(0), self.q.hs, self.Din_q, F + S, A, w0a)
+                launch_layers(*[qa_bwd[1:2]])
+                hip.policy_tail_bwd(da_h1, Ma * H, w0a, A * H, Ma, H, A, feat, 2 * A, eps, saved, self.head_scale, head.log_std_min, head.log_std_max,
+                                    head.epsilon, self.d_nlp, dfeat, 2 * A, p_h2, self.pi.W(2), dp_h2,
+                                    finalize=(stat_a, a.log_alpha, a.target_entropy, fal.grad, self.stats_a))
+                pb = mlp_backward_descs(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
+                hip.gemm_group([pb[0][0]] + pb[1])          # dW2 | db2 of the last layer next to [dW1 | db1, dh1]
+                hip.gemm_group(pb[2])
+                tail_bwd_done = True
+            elif self.tails:
                 launch_layers(qa_descs[:2])
                 _, n_stat = hip.q_tail_workspace_floats(Ma, H)
                 stat_a = self._buf("qa_tail_stat", n_stat)
@@ -439,15 +461,13 @@ class FusedStep:
                 launch_layers(qa_descs)
                 hip.sac_actor_loss(q_pi, 2, nlp, a.log_alpha, a.target_entropy, Ma, 2, dq_pi, 2, self.d_nlp, fal.grad, self.stats_a)
                 launch_layers(*[qa_bwd])
-            head = a.actor.head
-            dfeat = self._buf("pi_dfeat", Ma, 2 * A)
-            hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, self.head_scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
-                                  d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
-            dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
-            mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
+            if not tail_bwd_done:
+                hip.tanh_gaussian_bwd(feat, 2 * A, eps, saved, self.head_scale, Ma, A, head.log_std_min, head.log_std_max, head.epsilon,
+                                      d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
+                mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
             scale = (yield ("finish", [a._actor_alpha_grad] if a.sync_alpha else [fa.grad])) if exchanging else 1.0
-            stats["actor_grad"] = a._optim_step("actor", scale, pending=pending)
-            a._optim_step("alpha", scale if a.sync_alpha else 1.0, pending=pending)
+            # the temperature (one float, its own betas / moments / step count) rides on the actor's optimizer launch
+            stats["actor_grad"] = a._optim_step("actor", scale, pending=pending, rider=("alpha", scale if a.sync_alpha else 1.0))
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
         # one launch gathers every reported scalar (and alpha = exp(log_alpha), sac.py:196) into one array
         names = list(stats.keys())

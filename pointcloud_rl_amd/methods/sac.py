@@ -120,7 +120,15 @@ class HipAdam(torch.optim.Optimizer):
                                           "applies one set of hyper-parameters to its whole flat buffer")
         return sig
 
-    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False):
+    def rider_args(self, grad_scale=1.0):
+        """This (small) optimizer as the rider of another one's launch (hip.adam_step(rider=...))."""
+        g = self.param_groups[0]
+        self.hyper()
+        return dict(param=self.flat.data, grad=self.flat.grad, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=g["lr"], beta1=g["betas"][0],
+                    beta2=g["betas"][1], eps=g["eps"], grad_scale=grad_scale, step_counter=self.step_counter, grad_norm_out=self.grad_norm,
+                    partial=self.workspace)
+
+    def step(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, defer=False, rider=None):
         """defer=True returns the pending second half (gradient norm, step count) for hip.gather_scalars(pending=...).
         lr / betas / eps are kernel arguments: a launch captured in a hipGraph keeps the values it was captured with, which
         is why SAC._run_step drops its graphs when an optimizer's hyper() changes (scheduler, load_state_dict)."""
@@ -130,7 +138,7 @@ class HipAdam(torch.optim.Optimizer):
         self.hyper()
         return hip.adam_step(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1],
                              g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
-                             target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer)
+                             target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer, rider=rider)
 
     def _views(self, flat_tensor):
         return self.flat.views(flat_tensor)
@@ -330,13 +338,23 @@ class SAC(BaseAgent):
         """Sum the flat gradient over the ranks (RCCL); the 1/world factor is applied by the optimizer kernel."""
         return allreduce_sum_(tensor, enabled=self._be_data_parallel)
 
-    def _optim_step(self, name, scale, polyak=False, pending=None):
-        """pending: a list -> the optimizer's second half (gradient norm, step count) is deferred and appended to it."""
+    def _optim_step(self, name, scale, polyak=False, pending=None, rider=None):
+        """pending: a list -> the optimizer's second half (gradient norm, step count) is deferred and appended to it.
+        rider = (name, scale) of a second (small, fused) optimizer stepped by the same launch -- the temperature next to the actor."""
         opt = getattr(self, f"{name}_optim")
         fb = self._flat[name]
+        if rider is not None and not (isinstance(opt, HipAdam) and isinstance(getattr(self, f"{rider[0]}_optim"), HipAdam)
+                                      and self._flat[rider[0]].total <= 4096 and not polyak):
+            self_norm = self._optim_step(name, scale, polyak=polyak, pending=pending)
+            self._optim_step(rider[0], rider[1], pending=pending)
+            return self_norm
         if isinstance(opt, HipAdam):
             defer = pending is not None
-            if polyak and self._target_flat is not None:
+            if rider is not None:
+                pend, r_pend = opt.step(scale, defer=defer, rider=getattr(self, f"{rider[0]}_optim").rider_args(rider[1]))
+                if defer:
+                    pending.append(r_pend)
+            elif polyak and self._target_flat is not None:
                 pend = opt.step(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau, defer=defer)
             else:
                 pend = opt.step(scale, defer=defer)

@@ -128,3 +128,66 @@ def test_policy_tail_fwd(cuda, M, H, A, sampled):
     np.testing.assert_allclose(act.cpu().numpy(), a_ref.numpy(), atol=2e-6, rtol=1e-5)
     np.testing.assert_allclose(act2[:, 5:5 + A].cpu().numpy(), a_ref.numpy(), atol=2e-6, rtol=1e-5)
     np.testing.assert_allclose(nlp.cpu().numpy(), nlp_ref[:, 0].numpy(), atol=2e-4, rtol=2e-5)
+
+
+@pytest.mark.parametrize("M,H,A,K0,col0", [(256, 1024, 6, 56, 50), (130, 512, 22, 220, 196), (7, 256, 3, 12, 8)])
+def test_policy_tail_bwd_equals_the_three_launches_it_replaces(cuda, M, H, A, K0, col0):
+    """pcrl_policy_tail_bwd_f32 (+ the column gather riding on pcrl_q_tail_actor_cols_f32) against autograd of the same chain on the CPU
+    -- d_action = sum_h dh1_h W0_h[:, action columns], TanhGaussianHead's backward, dh2 = (d_feat W2) (.) [h2 > 0] -- and against the
+    launches it replaces (the d_action GEMM's result fed to pcrl_tanh_gaussian_bwd_f32); the folded actor_finalize equals the
+    stand-alone one bit for bit."""
+    from oracle import torch_ref
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(M + A)
+    dh1 = (g.randn(2, M, H) * (g.rand(2, M, H) < 0.5) / 64).astype(np.float32)
+    w0 = (g.randn(2, H, K0) / 8).astype(np.float32)
+    h2q = np.maximum(g.randn(2, M, H), 0).astype(np.float32)
+    w2q, b2q = (g.randn(2, H) / 32).astype(np.float32), g.randn(2).astype(np.float32)
+    nlp = g.randn(M).astype(np.float32)
+    feat_in = (0.5 * g.randn(M, 2 * A)).astype(np.float32)
+    feat_in[:, A:] = np.clip(feat_in[:, A:], -12, 3)                      # some log_std outside the clamp: zero gradient there
+    eps = g.randn(M, A).astype(np.float32)
+    scale, bias = g.uniform(0.5, 2.0, A).astype(np.float32), g.uniform(-0.5, 0.5, A).astype(np.float32)
+    h2p = np.maximum(g.randn(M, H), 0).astype(np.float32)
+    w2p = (g.randn(2 * A, H) / 32).astype(np.float32)
+    log_alpha, target_entropy = np.float32(math.log(0.2)), -float(A)
+    LA = torch.tensor([log_alpha], device=cuda)
+    # forward pieces the backward reads: saved = tanh(u) | std (from the forward head kernel)
+    feat = T(feat_in, cuda)
+    act, nl, saved = torch.empty(M, A, device=cuda), torch.empty(M, device=cuda), torch.empty(M, 2 * A, device=cuda)
+    hip.tanh_gaussian_fwd(feat, 2 * A, T(eps, cuda), T(scale, cuda), T(bias, cuda), M, A, -10.0, 2.0, 1e-6, act, A, nl, saved)
+    # the q tail (actor mode) with the column gather riding along
+    WB = T(np.concatenate([np.concatenate([w2q[h], b2q[h:h + 1], np.zeros(3, np.float32)]) for h in range(2)]), cuda)
+    _, n_stat = hip.q_tail_workspace_floats(M, H)
+    stat = torch.zeros(n_stat, device=cuda)
+    qo, dq, dh2q, dn = torch.empty(M, 2, device=cuda), torch.empty(M, 2, device=cuda), torch.empty(2, M, H, device=cuda), torch.empty(1, device=cuda)
+    W0 = T(w0, cuda)
+    cols = torch.full((2, A, H), float("nan"), device=cuda)
+    hip.q_tail_actor_cols(T(h2q, cuda), M * H, WB, WB[H:], H + 4, T(nlp, cuda), LA, M, H, qo, dq, dh2q, dn, stat, W0, H * K0, K0, col0, A, cols)
+    assert torch.equal(cols, W0[:, :, col0:col0 + A].permute(0, 2, 1).contiguous())
+    qo2, dq2, dh2q2, dn2, stat2 = torch.empty_like(qo), torch.empty_like(dq), torch.empty_like(dh2q), torch.empty_like(dn), torch.zeros_like(stat)
+    hip.q_tail_actor(T(h2q, cuda), M * H, WB, WB[H:], H + 4, T(nlp, cuda), LA, M, H, qo2, dq2, dh2q2, dn2, stat2)
+    assert torch.equal(qo, qo2) and torch.equal(dh2q, dh2q2) and torch.equal(stat, stat2) and torch.equal(dn, dn2)
+    # ---- the fused backward tail ----
+    DH1 = T(dh1, cuda)
+    dfeat, dh2 = torch.empty(M, 2 * A, device=cuda), torch.full((M, H), float("nan"), device=cuda)
+    ag, st = torch.empty(1, device=cuda), torch.empty(3, device=cuda)
+    hip.policy_tail_bwd(DH1, M * H, cols, A * H, M, H, A, feat, 2 * A, T(eps, cuda), saved, T(scale, cuda), -10.0, 2.0, 1e-6, dn, dfeat, 2 * A,
+                        T(h2p, cuda), T(w2p, cuda), dh2, finalize=(stat, LA, target_entropy, ag, st))
+    # the launches it replaces
+    d_act = torch.einsum("hmk,hkj->mj", DH1.double(), W0[:, :, col0:col0 + A].double()).float()
+    dfeat_ref = torch.empty(M, 2 * A, device=cuda)
+    hip.tanh_gaussian_bwd(feat, 2 * A, T(eps, cuda), saved, T(scale, cuda), M, A, -10.0, 2.0, 1e-6, d_act.data_ptr(), None, A, dn, dfeat_ref, 2 * A)
+    tol = dict(atol=2e-6 * float(dfeat_ref.abs().max()), rtol=2e-4)
+    np.testing.assert_allclose(dfeat.cpu().numpy(), dfeat_ref.cpu().numpy(), **tol)
+    dh2_ref = (dfeat_ref.double() @ T(w2p, cuda).double()).float() * (T(h2p, cuda) > 0)
+    np.testing.assert_allclose(dh2.cpu().numpy(), dh2_ref.cpu().numpy(), atol=2e-6 * float(dh2_ref.abs().max()), rtol=2e-4)
+    ag2, st2 = torch.empty(1, device=cuda), torch.empty(3, device=cuda)
+    hip.actor_finalize(stat, M, LA, target_entropy, ag2, st2)
+    assert torch.equal(ag, ag2) and torch.equal(st, st2)
+    # and autograd of the reference's head on the CPU (gaussian.py:83-87; distributions.py:89,116-127) for d(mean | log_std)
+    f_t = torch.from_numpy(feat_in).requires_grad_(True)
+    a_ref, nlp_ref = torch_ref.tanh_gaussian(f_t, torch.from_numpy(eps), torch.from_numpy(scale), torch.from_numpy(bias))
+    (a_ref * d_act.cpu()).sum().backward(retain_graph=True)
+    (nlp_ref[:, 0] * float(dn.item())).sum().backward()
+    np.testing.assert_allclose(dfeat.cpu().numpy(), f_t.grad.numpy(), atol=5e-6 * float(f_t.grad.abs().max()), rtol=5e-4)
