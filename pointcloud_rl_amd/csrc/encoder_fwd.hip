@@ -289,6 +289,18 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                     a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
                     [&](int t) { return a1[t >> 4][t & 15]; });
             PCRL_FSTAMP(4);
+#ifdef PCRL_FWD_ABLATE_TAIL
+            // Development build only (tools/r4_fwd_ablate.sh): LayerNorm-2 and the max-pool REMOVED (the conv2 accumulators are
+            // declared used, nothing is computed from them).  Not a forward pass: an upper bound for what any redesign of those two phases can reach
+            // (profiles/r04_bf16_fwd_ceiling.md).
+            {
+#pragma unroll
+                for (int mb = 0; mb < MB3; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(a2[mb][r]));      // the accumulators count as used: no instruction
+                continue;
+            }
+#endif
             // No ReLU instructions after LayerNorm-2: the pool compares the raw bits as SIGNED integers, where every value <= 0
             // (and -0, and a NaN with the sign bit) sorts below the smallest positive float, i.e. below max(key, 1) -- exactly the
             // lanes the ReLU would have zeroed.  What reaches a key is positive, so the keys' unsigned order is unchanged.

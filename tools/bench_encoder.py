@@ -9,7 +9,7 @@ from pointcloud_rl_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=256); ap.add_argument("--N", type=int, default=1024)
 ap.add_argument("--c1", type=int, default=64); ap.add_argument("--seg", type=int, default=0)
-ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--split", action="store_true"); ap.add_argument("--no-pooled", action="store_true")
+ap.add_argument("--iters", type=int, default=50); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--split", action="store_true"); ap.add_argument("--no-pooled", action="store_true"); ap.add_argument("--fwd-only", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 obs_np = make_obs(a.B, a.N, seed=1, seg=a.seg)
@@ -30,6 +30,8 @@ ms = e0.elapsed_time(e1) / a.iters
 flop = 2.0 * (C * a.c1 + a.c1 * 128 + 128 * 256) * a.B * a.N
 print(f"encoder_fwd B={a.B} N={a.N} C={C} c1={a.c1}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s ({flop/ms/1e9/157.3*100:.1f}% of 157.3 fp32 MFMA peak)")
 
+if a.fwd_only:
+    sys.exit(0)
 if a.split:
     p0, a0 = hip.encoder_fwd(desc, ew, packed)
     p1, a1 = hip.encoder_fwd(desc, ew, packed, split=True)
