@@ -103,6 +103,21 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ w2, float* _
         }
     }
     __syncthreads();
+    // The CENTRED Gram matrix Mc = M - s s^T / C3 = sum_c (W2[c,i] - s_i / C3) (W2[c,j] - s_j / C3): LayerNorm-2's variance is then
+    // var_p = h1_p . Mc h1_p / C3 with no "E z^2 - mu^2" subtraction (W2 columns with a large common component made that difference
+    // cancel down to rounding noise, and the clamp at zero hid it), and Mc h1_p IS the (M h1_p - mu_p s) the data gradient needs.
+    // The column sums first (32 threads, the order the uncentred build used for s), then every thread centres its share of the strips.
+    __shared__ float s_mean[32];
+    if (tid < 32) {
+        const float* strip = tid < 16 ? s_a : s_b;
+        float acc = 0.0f;
+        for (int c = 0; c < kC3; ++c) acc = acc + strip[c * 16 + (tid & 15)];
+        if (ti == 0 && tid >= 16) mimg[kC2 * kC2 + 16 * tj + (tid & 15)] = acc;      // s[16 tj + .] = column sum of W2
+        s_mean[tid] = acc / (float)kC3;
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * kC3 * 16; e += 256) s_strip[e] = s_strip[e] - s_mean[(e >= kC3 * 16 ? 16 : 0) + (e & 15)];
+    __syncthreads();
     const int i = tid >> 4, j = tid & 15;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll 4
@@ -113,11 +128,6 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ w2, float* _
         a3 = __builtin_fmaf(s_a[(c + 3) * 16 + i], s_b[(c + 3) * 16 + j], a3);
     }
     mimg[gram_image_index(kC2, 16 * ti + i, 16 * tj + j)] = (a0 + a1) + (a2 + a3);
-    if (ti == 0 && tid < 16) {                          // s[16 tj + tid] = column sum of W2
-        float acc = 0.0f;
-        for (int c = 0; c < kC3; ++c) acc = acc + s_b[c * 16 + tid];
-        mimg[kC2 * kC2 + 16 * tj + tid] = acc;
-    }
 }
 
 template <int C1, int kC2, int kC3>
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
         for (int mb = 0; mb < MB2; ++mb)       // h1 pieces: behind the loop's loads; M h1 and LayerNorm-1's backward issue no loads
             store_block_pieces(r_ops, s_tr, gop_off(OL.h1(), mb, 0, OL.NP), tile_bytes, a1[mb], l31, half, lane);
         PCRL_GSTAMP(4);
-        // ---- q = M h1; var = h1.q / C3 - mu^2 ------------------------------------------------------------------------------------
+        // ---- q = Mc h1 (Mc = M - s s^T / C3, the centred Gram image: q = M h1 - mu s); var = h1.q / C3 -------------------------------
         f32x16 q[MB2];
         dense_layer_mfma<MB2, kC2 / 8, 2>(
             q, [&](int mb, int tq) { return s_mv[(mb * (kC2 / 8) + tq) * 64 + lane]; },
@@ -470,16 +480,16 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pe = __builtin_fmaf(a1[mb][r], q[mb][r], pe);
             both_halves(pe, lo, hi);
-            const float var = __builtin_fmaxf((lo + hi) / (float)kC3 - mu * mu, 0.0f);
+            const float var = __builtin_fmaxf((lo + hi) / (float)kC3, 0.0f);      // a sum of squares up to rounding: no cancellation
             rstd2 = 1.0f / __builtin_sqrtf(var + p.eps);
         }
         PCRL_GSTAMP(5);
-        // ---- dH1 = rstd2 (gacc - m1 s) - a (q - mu s),  a = rstd2^2 m2,  m2 = rstd2 sum_own dx (z_c - mu) / C3 ------------------------
+        // ---- dH1 = rstd2 (gacc - m1 s) - a q,  q = M h1 - mu s,  a = rstd2^2 m2,  m2 = rstd2 sum_own dx (z_c - mu) / C3 -----------------
         {
             const float m1 = t1 / (float)kC3, m2 = (rstd2 * t2r) / (float)kC3;
             const float a = (rstd2 * rstd2) * m2, vco = rstd2 * m1, uco = a * mu;
             if (half == 0) p.ptc[(long long)b * kC3 + s] = valid ? float4{a, vco, uco, rstd2} : float4{0.0f, 0.0f, 0.0f, 0.0f};
-            const float cs = uco - vco;            // coefficient of s
+            const float cs = -vco;                 // coefficient of s (the a mu s term is inside the centred q)
 #pragma unroll
             for (int mb = 0; mb < MB2; ++mb)
 #pragma unroll

@@ -277,6 +277,36 @@ def test_bwd_small_gamma_large_beta_stays_accurate(cuda):
     assert_grads_close(got, ref)
 
 
+@pytest.mark.parametrize("offset,tol", [(2.0, 2e-5), (20.0, 5e-4)])
+def test_bwd_conv2_columns_with_a_large_common_component(cuda, offset, tol):
+    """LayerNorm-2's variance in the Gram form comes from h1 . Mc h1 with the CENTRED Gram image Mc = M - s s^T / C3 (round 4; the
+    round-3 form E z^2 - mu^2 cancelled when every column of W2 carries a large common offset: z2's channel mean is then >> its
+    spread).  Reference: float64 autograd along the HIP forward's routing; the bound is the usual 2e-5 of each tensor's largest entry
+    at offset 2 and 5e-4 at offset 20, where fp32's own z - mean cancellation (forward and backward alike, |z| ~ 600 against a spread
+    of ~1) is what is left -- the uncentred variance had an ABSOLUTE error of ~0.05 there, i.e. rstd2 off by several per cent."""
+    from oracle import torch_ref
+    B, N = 4, 260
+    obs = make_obs(B, N, seed=91)
+    w = make_encoder_weights(6, 64, 128, 256, seed=13)
+    rng = np.random.RandomState(3)
+    w["w2"] = (w["w2"] + offset * rng.choice([-1.0, 1.0], size=(1, w["w2"].shape[1]))).astype(np.float32)   # column j shifted by +-offset
+    gpool = rng.randn(B, 256).astype(np.float32)
+    got, argmax, pooled, _ = hip_grads(obs, w, gpool, cuda)
+    P = {}
+    for ref_name, k in NAMES.items():
+        t = torch.from_numpy(np.ascontiguousarray(w[k])).double()
+        P[torch_ref.ENC + "conv.mlp." + ref_name] = (t[..., None] if t.ndim == 2 else t).requires_grad_(True)
+    obs_t = {k: torch.from_numpy(v) for k, v in obs.items()}
+    pre = torch_ref.pointnet_prepool(P, {k: (v.double() if v.dtype == torch.float32 else v) for k, v in obs_t.items()})
+    routed = pre.gather(-1, torch.from_numpy(argmax).long()[..., None])[..., 0]
+    assert float((pre.max(-1)[0] - routed).abs().max()) < 50 * tol      # the routing is the maximum up to fp32 rounding of this ill-conditioned layer
+    (routed * torch.from_numpy(gpool).double()).sum().backward()
+    ref = {n: P[torch_ref.ENC + "conv.mlp." + n].grad.float().numpy() for n in NAMES}
+    worst = {n: float(np.abs(got[n].reshape(-1) - ref[n].reshape(-1)).max() / max(np.abs(ref[n]).max(), 1e-6)) for n in NAMES}
+    print(f"offset {offset}: worst rel-to-max error per tensor", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert max(worst.values()) < tol, worst
+
+
 @pytest.mark.parametrize("B,N,extra,c1", [(3, 260, dict(), 64), (4, 300, dict(seg=1), 128), (2, 200, dict(), 32), (260, 120, dict(), 64)])
 def test_split_precision_backward_matches_torch_autograd(cuda, B, N, extra, c1):
     """EXPERIMENTAL pcrl_encoder_{fwd,bwd}_f32split: gradients against fp32 autograd of the restatement at the exact kernel's
