@@ -374,6 +374,11 @@ int pcrl_encoder_fwd_head_f32split(const pcrl_cloud_desc* clouds, const pcrl_aug
  *   out[c] = scale * (op == 0 ? sum : max)_{b < nblk} part[b * blk_stride + c]   for c < ncols. */
 typedef struct pcrl_colsum_job { const float* part; int64_t blk_stride; int32_t nblk, ncols; float* out; float scale; int32_t op; } pcrl_colsum_job;
 int pcrl_colsum_jobs_f32(const pcrl_colsum_job* jobs, int32_t n, void* stream);
+/* The same jobs without a launch of their own: they are copied and run by extra workgroups of the gradient-reduce launch of the NEXT
+ * pcrl_encoder_bwd_{f32,bf16,f32split} / pcrl_encoder_bwd_prepared_f32 call of this host thread (same arithmetic, same order; the
+ * partials must be complete by then and `out` is valid when that call's launches are).  n = 0 withdraws them.  The update step
+ * uses it for the leftovers of pcrl_layernorm_rows_bwd_partials_f32 and pcrl_q_tail_critic_f32, which only the optimizer reads. */
+int pcrl_encoder_bwd_attach_colsum(const pcrl_colsum_job* jobs, int32_t n);
 
 /* ---- head tails: the last Linear of a head fused with what follows it (H = hidden width, multiple of 256) ------------------------
  * pcrl_q_tail_critic_f32: for both Q heads h (second head at + *_head_stride floats):

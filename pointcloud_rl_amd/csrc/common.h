@@ -204,4 +204,47 @@ __host__ __device__ inline float u01_to_range(uint32_t w, float lo, float hi) {
     return lo + (float)(w >> 8) * (1.0f / 16777216.0f) * (hi - lo);
 }
 
+// ---- fixed-order column reductions of per-workgroup partials (pcrl_colsum_jobs_f32; also riding on the encoder backward's reduce
+// launch, pcrl_encoder_bwd_attach_colsum) ----------------------------------------------------------------------------------------
+constexpr int kColsumJobs = 12;
+struct ColsumJob { const float* part; long long blk_stride; int nblk, ncols; float* out; float scale; int op, blk_begin; };   // op 0 sum, 1 max
+struct ColsumParams { ColsumJob job[kColsumJobs]; int n; };
+
+// Block `blk` (of 256 columns) of the job list; tid in [0, 256).
+__device__ __forceinline__ void colsum_block(const ColsumParams& p, int blk, int tid) {
+    int ji = 0;
+#pragma unroll
+    for (int j = 1; j < kColsumJobs; ++j)
+        if (j < p.n && blk >= p.job[j].blk_begin) ji = j;
+    const ColsumJob& jb = p.job[ji];
+    const int col = (blk - jb.blk_begin) * 256 + tid;
+    if (col >= jb.ncols) return;
+    const float* src = jb.part + col;
+    float acc = jb.op ? -INFINITY : 0.0f;
+    int b = 0;
+    for (; b + 16 <= jb.nblk; b += 16) {           // sixteen loads in flight, combined in block order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[(long long)(b + u) * jb.blk_stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = jb.op ? fmaxf(acc, v[u]) : acc + v[u];
+    }
+    for (; b < jb.nblk; ++b) { const float v = src[(long long)b * jb.blk_stride]; acc = jb.op ? fmaxf(acc, v) : acc + v; }
+    jb.out[col] = acc * jb.scale;
+}
+
+// Host: the C-ABI job list -> kernel parameters; returns the number of 256-column blocks (0: nothing to do), -1 on a bad job.
+inline int colsum_fill(const pcrl_colsum_job* jobs, int n, ColsumParams& p) {
+    p = ColsumParams{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const pcrl_colsum_job& s = jobs[i];
+        if (!s.part || !s.out || s.nblk < 0 || s.ncols < 0) return -1;
+        if (s.ncols == 0) continue;
+        p.job[p.n++] = ColsumJob{s.part, s.blk_stride, s.nblk, s.ncols, s.out, s.scale, s.op, blocks};
+        blocks += (s.ncols + 255) / 256;
+    }
+    return blocks;
+}
+
 }  // namespace pcrl

@@ -984,7 +984,12 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_wide_kernel(const B
 // ---- reduce over the clouds (fixed order) and the finish of dW2 -----------------------------------------------------------
 template <int ARITH>      // (one instance per translation unit)
 __global__ __launch_bounds__(1024) void encoder_bwdg_reduce_kernel(const float* __restrict__ pw, int B, int stride, int n_main,
-                                                                    float* __restrict__ grads, float* __restrict__ extra) {
+                                                                    float* __restrict__ grads, float* __restrict__ extra,
+                                                                    const ColsumParams cs, int main_blocks) {
+    if ((int)blockIdx.x >= main_blocks) {      // column-sum jobs riding on this launch (pcrl_encoder_bwd_attach_colsum)
+        if (threadIdx.x < 256) colsum_block(cs, (int)blockIdx.x - main_blocks, (int)threadIdx.x);
+        return;
+    }
     __shared__ float s_part[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + c;
@@ -1112,7 +1117,8 @@ static int launch_bwdg_wide(const BwdParams& p, hipStream_t stream) {
     const GradLayout GL{p.cl.C, C1, C2, C3};
     const GramExtra GX{C2};
     const int stride = GL.total() + GX.total();
-    hipLaunchKernelGGL(encoder_bwdg_reduce_kernel<PCRL_BWDG_ARITH>, dim3((stride + 63) / 64), dim3(1024), 0, stream, p.pw, p.cl.B, stride, GL.total(), p.grads, p.gvu);
+    hipLaunchKernelGGL(encoder_bwdg_reduce_kernel<PCRL_BWDG_ARITH>, dim3((stride + 63) / 64 + p.cs_blocks), dim3(1024), 0, stream, p.pw, p.cl.B, stride, GL.total(), p.grads, p.gvu,
+                       p.cs, (stride + 63) / 64);
     PCRL_BWDG_AFTER("encoder_bwdg_reduce_kernel");
     constexpr int rows = (256 / C2) * 2;
     constexpr size_t fin_lds = sizeof(float) * ((size_t)C2 * C2 + (size_t)rows * C2);
@@ -1152,7 +1158,8 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     const GradLayout GL{p.cl.C, C1, C2, C3};
     const GramExtra GX{C2};
     const int stride = GL.total() + GX.total();
-    hipLaunchKernelGGL(encoder_bwdg_reduce_kernel<PCRL_BWDG_ARITH>, dim3((stride + 63) / 64), dim3(1024), 0, stream, p.pw, p.cl.B, stride, GL.total(), p.grads, p.gvu);
+    hipLaunchKernelGGL(encoder_bwdg_reduce_kernel<PCRL_BWDG_ARITH>, dim3((stride + 63) / 64 + p.cs_blocks), dim3(1024), 0, stream, p.pw, p.cl.B, stride, GL.total(), p.grads, p.gvu,
+                       p.cs, (stride + 63) / 64);
     PCRL_BWDG_AFTER("encoder_bwdg_reduce_kernel");
     {
         constexpr int rows = (256 / C2) * 2;

@@ -99,6 +99,9 @@ struct BwdParams {
     float* mimg;             // [C2*C2 + C2] M = W2^T W2 in A-operand order, then s = W2^T 1 (built by the prep launch)
     int pw_stride;           // floats per cloud in pw (GradLayout.total() [+ C2*C2 + 2*C2 in the Gram form])
     int phase;               // Gram form, host side: 0 whole backward, 1 the prep launch only, 2 everything after it (pcrl_encoder_bwd_prepare_f32)
+    // column-sum jobs riding on the reduce launch (pcrl_encoder_bwd_attach_colsum): cs_blocks extra workgroups behind its own
+    ColsumParams cs;
+    int cs_blocks;
 };
 
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
@@ -1288,21 +1291,45 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     return PCRL_OK;
 }
 
+// pcrl_encoder_bwd_attach_colsum: jobs handed over for the NEXT backward of this host thread
+static thread_local pcrl_colsum_job t_colsum_jobs[kColsumJobs];
+static thread_local int t_colsum_n = 0;
+
+extern "C" int pcrl_encoder_bwd_attach_colsum(const pcrl_colsum_job* jobs, int32_t n) {
+    if (n == 0) { t_colsum_n = 0; return PCRL_OK; }
+    if (!jobs || n < 0 || n > kColsumJobs) return fail(PCRL_E_ARG, "colsum jobs: 0 <= n <= %d", kColsumJobs);
+    ColsumParams probe;
+    if (colsum_fill(jobs, n, probe) < 0) return fail(PCRL_E_ARG, "bad colsum job");
+    for (int i = 0; i < n; ++i) t_colsum_jobs[i] = jobs[i];
+    t_colsum_n = n;
+    return PCRL_OK;
+}
+
 static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
                             const int32_t* argmax, const float* grad_pooled, const float* pooled,
                             float* grads, int32_t* n_active,
                             void* workspace, size_t workspace_bytes, void* stream, int phase = 0) {
+    // the attached column-sum jobs belong to the call that launches the reduce kernel (not to the prepare half); whatever path this
+    // call takes, they are consumed by it
+    pcrl_colsum_job cs_jobs[kColsumJobs];
+    int cs_n = 0;
+    if (phase != 1) {
+        cs_n = t_colsum_n;
+        for (int i = 0; i < cs_n; ++i) cs_jobs[i] = t_colsum_jobs[i];
+        t_colsum_n = 0;
+    }
     if (!clouds || !w || !packed || !argmax || (phase != 1 && (!grad_pooled || !grads))) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
     BwdParams p{};
+    p.cs_blocks = cs_n ? colsum_fill(cs_jobs, cs_n, p.cs) : 0;
     if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
     const GradLayout GL{w->c_in, w->c1, w->c2, w->c3};
     hipStream_t st = (hipStream_t)stream;
     if (p.cl.B == 0) {
         if (phase != 1) PCRL_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * GL.total(), st));
-        return PCRL_OK;
+        return cs_n ? pcrl_colsum_jobs_f32(cs_jobs, cs_n, stream) : PCRL_OK;
     }
     const BwdWorkspace ws = bwd_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
     const BwdgWorkspace wg = bwdg_workspace(p.cl.B, w->c_in, w->c1, w->c2, w->c3);
@@ -1380,6 +1407,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     const int n = GL.total();
     hipLaunchKernelGGL(encoder_bwd_reduce_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, p.pw, p.cl.B, n, grads);
     PCRL_CHECK_LAUNCH("encoder_bwd_reduce_kernel");
+    if (cs_n) { if (int rc2 = pcrl_colsum_jobs_f32(cs_jobs, cs_n, stream)) return rc2; }      // the round-2 kernels: a launch of their own
     if (n_active) PCRL_CHECK_HIP(hipMemcpyAsync(n_active, p.n_act, sizeof(int) * p.cl.B, hipMemcpyDeviceToDevice, st));
     return PCRL_OK;
 }

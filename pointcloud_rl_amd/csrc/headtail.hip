@@ -417,32 +417,8 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_kernel(const PolicyTailPa
     }
 }
 
-// ---- fixed-order column reductions of per-workgroup partials ----------------------------------------------------------------
-constexpr int kColsumJobs = 12;
-struct ColsumJob { const float* part; long long blk_stride; int nblk, ncols; float* out; float scale; int op, blk_begin; };   // op 0 sum, 1 max
-struct ColsumParams { ColsumJob job[kColsumJobs]; int n; };
-
-__global__ __launch_bounds__(256) void colsum_jobs_kernel(const ColsumParams p) {
-    int ji = 0;
-#pragma unroll
-    for (int j = 1; j < kColsumJobs; ++j)
-        if (j < p.n && (int)blockIdx.x >= p.job[j].blk_begin) ji = j;
-    const ColsumJob& jb = p.job[ji];
-    const int col = ((int)blockIdx.x - jb.blk_begin) * 256 + threadIdx.x;
-    if (col >= jb.ncols) return;
-    const float* src = jb.part + col;
-    float acc = jb.op ? -INFINITY : 0.0f;
-    int b = 0;
-    for (; b + 16 <= jb.nblk; b += 16) {           // sixteen loads in flight, combined in block order
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[(long long)(b + u) * jb.blk_stride];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = jb.op ? fmaxf(acc, v[u]) : acc + v[u];
-    }
-    for (; b < jb.nblk; ++b) { const float v = src[(long long)b * jb.blk_stride]; acc = jb.op ? fmaxf(acc, v) : acc + v; }
-    jb.out[col] = acc * jb.scale;
-}
+// ---- fixed-order column reductions of per-workgroup partials (types and the block body: common.h) ---------------------------------
+__global__ __launch_bounds__(256) void colsum_jobs_kernel(const ColsumParams p) { colsum_block(p, (int)blockIdx.x, (int)threadIdx.x); }
 
 }  // namespace pcrl
 
@@ -587,15 +563,9 @@ extern "C" int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, c
 
 extern "C" int pcrl_colsum_jobs_f32(const pcrl_colsum_job* jobs, int32_t n, void* stream) {
     if (!jobs || n < 1 || n > kColsumJobs) return fail(PCRL_E_ARG, "colsum jobs: 1 <= n <= %d", kColsumJobs);
-    ColsumParams p{};
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        const pcrl_colsum_job& s = jobs[i];
-        if (!s.part || !s.out || s.nblk < 0 || s.ncols < 0) return fail(PCRL_E_ARG, "bad colsum job %d", i);
-        if (s.ncols == 0) continue;
-        p.job[p.n++] = ColsumJob{s.part, s.blk_stride, s.nblk, s.ncols, s.out, s.scale, s.op, blocks};
-        blocks += (s.ncols + 255) / 256;
-    }
+    ColsumParams p;
+    const int blocks = colsum_fill(jobs, n, p);
+    if (blocks < 0) return fail(PCRL_E_ARG, "bad colsum job");
     if (blocks == 0) return PCRL_OK;
     hipLaunchKernelGGL(colsum_jobs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("colsum_jobs_kernel");

@@ -480,12 +480,16 @@ def layernorm_rows_bwd_partials(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, ldd
                                                      ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
 
 
-def colsum_jobs(jobs):
-    """jobs: [(part ptr (int), blk_stride, nblk, ncols, out ptr (int), scale, op)] -> out[c] = scale * (sum | max)_b part[b * blk_stride + c]."""
+def colsum_jobs(jobs, attach_to_encoder_bwd=False):
+    """jobs: [(part ptr (int), blk_stride, nblk, ncols, out ptr (int), scale, op)] -> out[c] = scale * (sum | max)_b part[b * blk_stride + c].
+    attach_to_encoder_bwd: no launch -- the jobs ride on the reduce launch of the next encoder_bwd call (pcrl_encoder_bwd_attach_colsum)."""
     arr = (_lib.ColsumJob * len(jobs))()
     for j, (part, stride, nblk, ncols, out, scale, op) in zip(arr, jobs):
         j.part, j.blk_stride, j.nblk, j.ncols, j.out, j.scale, j.op = part, stride, nblk, ncols, out, scale, op
-    check(lib().pcrl_colsum_jobs_f32(arr, len(jobs), _stream()))
+    if attach_to_encoder_bwd:
+        check(lib().pcrl_encoder_bwd_attach_colsum(arr, len(jobs)))
+    else:
+        check(lib().pcrl_colsum_jobs_f32(arr, len(jobs), _stream()))
 
 
 def q_tail_workspace_floats(M, H):

@@ -200,6 +200,7 @@ class FusedStep:
         self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
         self._forked = False
         self.policy_tail_max = int(__import__("os").environ.get("PCRL_POLICY_TAIL_MAX", "4096"))
+        self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
         self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
 
     def _buf(self, name, *shape, dtype=torch.float32):
@@ -385,7 +386,9 @@ class FusedStep:
             sc = self.stats_c.data_ptr()
             for k, (scale_k, op) in enumerate(((1.0 / M, 0), (1.0, 1), (1.0 / M, 0), (1.0 / M, 0))):
                 jobs.append((stat_part.data_ptr() + 4 * k, 4, n_wg, 1, sc + 4 * k, scale_k, op))
-            hip.colsum_jobs(jobs)
+            # nothing before the optimizer reads these sums: they ride on the encoder backward's reduce launch (one node fewer) --
+            # except data-parallel, where the Q heads' range (dW2 | db2 among these sums) starts its all-reduce before that launch
+            hip.colsum_jobs(jobs, attach_to_encoder_bwd=self.attach_colsum and not a._be_data_parallel)
         else:
             launch_layers(q_tgt_descs, q_on_descs)
             # ---- critic loss, backward through heads, feature head and encoder (sac.py:137-148) ----

@@ -191,3 +191,40 @@ def test_policy_tail_bwd_equals_the_three_launches_it_replaces(cuda, M, H, A, K0
     (a_ref * d_act.cpu()).sum().backward(retain_graph=True)
     (nlp_ref[:, 0] * float(dn.item())).sum().backward()
     np.testing.assert_allclose(dfeat.cpu().numpy(), f_t.grad.numpy(), atol=5e-6 * float(f_t.grad.abs().max()), rtol=5e-4)
+
+
+def test_colsum_jobs_attached_to_the_encoder_backward_equal_the_stand_alone_launch(cuda):
+    """pcrl_encoder_bwd_attach_colsum: the jobs run in extra workgroups of the next backward's reduce launch -- same results bit for
+    bit as pcrl_colsum_jobs_f32, the encoder gradient untouched, and the attachment is consumed by that one call."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_encoder_weights, make_obs
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(5)
+    part = T(g.randn(37, 2, 300).astype(np.float32), cuda)
+    outs = [torch.full((300,), float("nan"), device=cuda) for _ in range(4)]
+    jobs = lambda o: [(part.data_ptr(), 600, 37, 300, o[0].data_ptr(), 1.0, 0), (part.data_ptr() + 4 * 300, 600, 37, 257, o[1].data_ptr(), 0.5, 1)]
+    hip.colsum_jobs(jobs(outs[0:2]))
+    obs = make_obs(5, 200, seed=2)
+    w = {k: T(v, cuda) for k, v in make_encoder_weights(6, 64, 128, 256, seed=3).items()}
+    ew, _ = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(6, 64, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    desc, keep = hip.make_cloud_desc({k: T(v, cuda) for k, v in obs.items()})
+    pooled, argmax = hip.encoder_fwd(desc, ew, packed)
+    gp = torch.randn(5, 256, device=cuda)
+    plain = hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled).clone()
+    hip.colsum_jobs(jobs(outs[2:4]), attach_to_encoder_bwd=True)
+    torch.cuda.synchronize()
+    assert torch.isnan(outs[2]).all()                                  # nothing has run yet
+    with_jobs = hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled).clone()
+    assert torch.equal(with_jobs, plain)
+    assert torch.equal(outs[2], outs[0]) and torch.equal(outs[3][:257], outs[1][:257]) and torch.isnan(outs[3][257:]).all()
+    outs[2].fill_(float("nan"))
+    hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled)      # the attachment was consumed: a plain backward again
+    torch.cuda.synchronize()
+    assert torch.isnan(outs[2]).all()
+    # the round-2 kernels (no pooled values given) run the attached jobs as a launch of their own
+    hip.colsum_jobs(jobs(outs[2:4]), attach_to_encoder_bwd=True)
+    hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=None)
+    assert torch.equal(outs[2], outs[0])
