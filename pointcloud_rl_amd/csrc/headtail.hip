@@ -194,6 +194,147 @@ __global__ __launch_bounds__(256) void q_tail_kernel(const QTailParams p) {
     }
 }
 
+// q_tail_kernel for H = 1024 and small batches: the same four rows per workgroup (so the partial-sum layout is unchanged), but
+// SIXTEEN waves -- a row's hidden vector is split over four of them (one 1 KB piece of every operand row per wave instead of four:
+// the dependent-load chain is 4x shorter; at M = 32 the four-wave kernel took 13-14 us for eight workgroups).  The quarter dot
+// products meet in LDS and are added in quarter order.
+__global__ __launch_bounds__(1024) void q_tail_split_kernel(const QTailParams p) {
+    __shared__ float s_dot[4][4][4];               // [row][quarter][q0, q1, qn0, qn1]
+    __shared__ float s_y[4];
+    __shared__ float s_st[4][4];
+    __shared__ float s_db[4][2];
+    extern __shared__ __attribute__((aligned(16))) float s_dw[];          // critic: [4 rows][2][H]
+    const int w16 = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n_row_blocks = (p.M + 3) >> 2;
+    if ((int)blockIdx.x >= n_row_blocks) {         // column-gather workgroups (see q_tail_kernel)
+        const int per_head = p.cg_ncols * p.H;
+        const int i = ((int)blockIdx.x - n_row_blocks) * 1024 + (int)threadIdx.x;
+        if (i < 2 * per_head) {
+            const int h = i / per_head, r = i - h * per_head, j = r / p.H, col = r - j * p.H;
+            p.cg_dst[i] = p.cg_w0[h * p.cg_hs + (long long)col * p.cg_ld + p.cg_col0 + j];
+        }
+        return;
+    }
+    const int row = w16 >> 2, qw = w16 & 3;
+    const int m = blockIdx.x * 4 + row;
+    const bool live = m < p.M;
+    const int mr = live ? m : p.M - 1;
+    const int col = 256 * qw + 4 * lane;
+    const float alpha = expf(p.log_alpha[0]);
+    f32x4 hv[2], wv[2];
+    {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            hv[h] = *reinterpret_cast<const f32x4*>(p.h2 + h * p.h2_hs + (long long)mr * p.H + col);
+            wv[h] = *reinterpret_cast<const f32x4*>(p.w2 + h * p.w_hs + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[h] = __builtin_fmaf(hv[h][e], wv[h][e], v[h]);
+        }
+        if (p.mode == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 tv = *reinterpret_cast<const f32x4*>(p.h2_t + h * p.h2_t_hs + (long long)mr * p.H + col);
+                const f32x4 tw = *reinterpret_cast<const f32x4*>(p.w2_t + h * p.w_t_hs + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[2 + h] = __builtin_fmaf(tv[e], tw[e], v[2 + h]);
+            }
+        }
+        allreduce_add32_x16(v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo, hi;
+            both_halves(v[k], lo, hi);
+            if (lane == 0) s_dot[row][qw][k] = lo + hi;
+        }
+    }
+    __syncthreads();
+    float q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) q[h] = (((s_dot[row][0][h] + s_dot[row][1][h]) + s_dot[row][2][h]) + s_dot[row][3][h]) + p.b2[h * p.w_hs];
+    const bool first = qw == 0 && lane == 0;       // one lane per row reports
+    if (live && qw == 0 && lane < 2) p.q[(long long)m * p.ld_q + lane] = q[lane];
+    float dqv[2];
+    if (p.mode == 0) {
+        float qn[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            qn[h] = (((s_dot[row][0][2 + h] + s_dot[row][1][2 + h]) + s_dot[row][2][2 + h]) + s_dot[row][3][2 + h]) + p.b2_t[h * p.w_t_hs];
+        const float mn = fminf(qn[0], qn[1]) + alpha * p.nlp[mr];
+        const int e = mr / p.rd_div;
+        const float r = p.rewards[e] * p.reward_scale;
+        const float y = p.ignore_dones ? r + p.gamma * mn : r + (1.0f - (p.dones[e] ? 1.0f : 0.0f)) * p.gamma * mn;
+        if (first) s_y[row] = y;
+        __syncthreads();
+        float ybar = 0.0f;
+        const int g0 = (row / p.group) * p.group;
+        for (int a = 0; a < p.group; ++a) ybar += s_y[g0 + a];
+        ybar = p.group > 1 ? ybar / (float)p.group : ybar;
+        const float d0 = q[0] - ybar, d1 = q[1] - ybar;
+        dqv[0] = 2.0f * d0 / (float)p.M; dqv[1] = 2.0f * d1 / (float)p.M;
+        if (live && first) {
+            p.q_target[m] = ybar;
+            p.dq[(long long)m * p.ld_dq] = dqv[0]; p.dq[(long long)m * p.ld_dq + 1] = dqv[1];
+        }
+        if (first) {
+            s_st[row][0] = live ? d0 * d0 + d1 * d1 : 0.0f;
+            s_st[row][1] = live ? fmaxf(fabsf(d0), fabsf(d1)) : 0.0f;
+            s_st[row][2] = live ? fminf(q[0], q[1]) : 0.0f;
+            s_st[row][3] = live ? ybar : 0.0f;
+            s_db[row][0] = live ? dqv[0] : 0.0f; s_db[row][1] = live ? dqv[1] : 0.0f;
+        }
+    } else {
+        const int arg = q[1] < q[0] ? 1 : 0;
+        dqv[0] = arg == 0 ? -1.0f / (float)p.M : 0.0f;
+        dqv[1] = arg == 1 ? -1.0f / (float)p.M : 0.0f;
+        if (live && first) { p.dq[(long long)m * p.ld_dq] = dqv[0]; p.dq[(long long)m * p.ld_dq + 1] = dqv[1]; }
+        if (first) {
+            s_st[row][0] = live ? q[arg] : 0.0f;
+            s_st[row][1] = live ? p.nlp[mr] : 0.0f;
+            s_st[row][2] = 0.0f; s_st[row][3] = 0.0f;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.d_neglogp[0] = -alpha / (float)p.M;
+    }
+    if (live) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = hv[h][e] > 0.0f ? dqv[h] * wv[h][e] : 0.0f;
+            *reinterpret_cast<f32x4*>(p.dh2 + h * p.dh2_hs + (long long)m * p.H + col) = o;
+        }
+    }
+    if (p.mode == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = live ? dqv[h] * hv[h][e] : 0.0f;
+            *reinterpret_cast<f32x4*>(s_dw + (row * 2 + h) * p.H + col) = o;
+        }
+    }
+    __syncthreads();
+    if (p.mode == 0) {
+        for (int i = threadIdx.x; i < 2 * p.H; i += 1024) {
+            const int h = i / p.H, c = i - h * p.H;
+            const float v = ((s_dw[(0 * 2 + h) * p.H + c] + s_dw[(1 * 2 + h) * p.H + c]) + s_dw[(2 * 2 + h) * p.H + c]) + s_dw[(3 * 2 + h) * p.H + c];
+            p.part[((long long)blockIdx.x * 2 + h) * p.part_ld + c] = v;
+        }
+        if (threadIdx.x < 2)
+            p.part[((long long)blockIdx.x * 2 + threadIdx.x) * p.part_ld + p.H] =
+                ((s_db[0][threadIdx.x] + s_db[1][threadIdx.x]) + s_db[2][threadIdx.x]) + s_db[3][threadIdx.x];
+    }
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        float v;
+        if (p.mode == 0 && k == 1) v = fmaxf(fmaxf(s_st[0][1], s_st[1][1]), fmaxf(s_st[2][1], s_st[3][1]));
+        else v = ((s_st[0][k] + s_st[1][k]) + s_st[2][k]) + s_st[3][k];
+        p.stat_part[(long long)blockIdx.x * 4 + k] = v;
+    }
+}
+
 struct ActorFinalizeParams {
     const float* stat_part; int n_wg, M;
     const float* log_alpha; float target_entropy;
@@ -417,6 +558,138 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_kernel(const PolicyTailPa
     }
 }
 
+// policy_tail_bwd_kernel for small batches with H = 1024: one row per workgroup, a quarter of the hidden vector per wave (see
+// policy_tail_fwd_split_kernel); every wave repeats the tiny TanhGaussianHead arithmetic so that one barrier is enough.
+__global__ __launch_bounds__(256) void policy_tail_bwd_split_kernel(const PolicyTailBwdParams p) {
+    __shared__ float s_part[4][32];
+    __shared__ float s_df[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= p.M) {
+        if (wave == 0 && p.fin_on) actor_finalize_wave(p.fin, lane);
+        return;
+    }
+    const int m = blockIdx.x;
+    const int col = 256 * wave + 4 * lane;
+    {
+        f32x4 dv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dv[h] = *reinterpret_cast<const f32x4*>(p.dh1 + h * p.dh1_hs + (long long)m * p.H + col);
+        for (int j0 = 0; j0 < p.A; j0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float s = 0.0f;
+                if (j0 + k < p.A) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w0a + h * p.w0a_hs + (long long)(j0 + k) * p.H + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s = __builtin_fmaf(dv[h][e], wv[e], s);
+                    }
+                }
+                v[k] = s;
+            }
+            allreduce_add32_x16(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float lo, hi;
+                both_halves(v[k], lo, hi);
+                if (lane == 0 && j0 + k < p.A) s_part[wave][j0 + k] = lo + hi;
+            }
+        }
+    }
+    __syncthreads();
+    float g_u = 0.0f, g_ls = 0.0f;
+    if (lane < p.A) {
+        const int j = lane;
+        const float ga = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+        const float t = p.saved[(long long)m * 2 * p.A + j], std = p.saved[(long long)m * 2 * p.A + p.A + j];
+        const float e = p.eps[(long long)m * p.A + j], sc = p.scale[j];
+        const float ls = p.feat[(long long)m * p.ld_feat + p.A + j];
+        const float g_lp = -p.d_neglogp[0];
+        const float omt2 = 1.0f - t * t;
+        const float sq = 2.0f * sc * t * omt2 / (sc * omt2 + p.epsilon);
+        g_u = ga * sc * omt2 + g_lp * sq;
+        const float g_std = g_u * e + g_lp * (-1.0f / std);
+        g_ls = (ls >= p.ls_min && ls <= p.ls_max) ? g_std * std : 0.0f;
+        if (wave == 0) { p.dfeat[(long long)m * p.ld_dfeat + j] = g_u; p.dfeat[(long long)m * p.ld_dfeat + p.A + j] = g_ls; }
+        s_df[wave][j] = g_u; s_df[wave][p.A + j] = g_ls;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int n = 0; n < 2 * p.A; ++n) {
+        const float g = s_df[wave][n];
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, wv[e], acc[e]);
+    }
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)m * p.H + col);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = hv[e] > 0.0f ? acc[e] : 0.0f;
+    *reinterpret_cast<f32x4*>(p.dh2 + (long long)m * p.H + col) = o;
+}
+
+// The same head for SMALL batches with H = 1024: ONE row per workgroup, its four waves take a quarter of the hidden vector each
+// (one 1 KB piece of h2 and of every w2 row per wave instead of four: the dependent-load chain of a wave is 4x shorter and M
+// workgroups instead of M / 4 spread over the chip), partial dot products meet in LDS and are added in wave order.
+__global__ __launch_bounds__(256) void policy_tail_fwd_split_kernel(const PolicyTailParams p) {
+    __shared__ float s_part[4][64];
+    __shared__ float s_feat[64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.x;
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)b * p.H + 256 * wave + 4 * lane);
+    const int n_out = 2 * p.A;
+    for (int n0 = 0; n0 < n_out; n0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int n = min(n0 + k, n_out - 1);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + 256 * wave + 4 * lane);
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(hv[e], wv[e], s);
+            v[k] = s;
+        }
+        allreduce_add32_x16(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float lo, hi;
+            both_halves(v[k], lo, hi);
+            if (lane == 0 && n0 + k < n_out) s_part[wave][n0 + k] = lo + hi;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (lane < n_out) s_feat[lane] = (((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]) + p.b2[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int n = lane; n < n_out; n += 64) p.feat[(long long)b * p.ld_feat + n] = s_feat[n];
+    float lp = 0.0f;
+    if (lane < p.A) {
+        const int j = lane;
+        const float mean = s_feat[j], ls = s_feat[p.A + j];
+        const float std = expf(fminf(fmaxf(ls, p.ls_min), p.ls_max));
+        const float e = p.eps ? p.eps[(long long)b * p.A + j]
+                              : tail_philox_normal((unsigned)(b * p.A + j), (unsigned)p.draw_id, (unsigned)p.step[0], p.seed_lo, p.seed_hi);
+        if (p.eps_out) p.eps_out[(long long)b * p.A + j] = e;
+        const float u = mean + e * std;
+        const float t = tanhf(u);
+        const float sc = p.scale[j];
+        const float a = t * sc + p.bias[j];
+        const float diff = u - mean;
+        lp = -(diff * diff) / (2.0f * (std * std)) - logf(std) - kTailHalfLog2Pi - logf(sc * (1.0f - t * t) + p.epsilon);
+        p.act0[(long long)b * p.ld0 + j] = a;
+        if (p.act1) p.act1[(long long)b * p.ld1 + j] = a;
+        if (p.saved) { p.saved[(long long)b * 2 * p.A + j] = t; p.saved[(long long)b * 2 * p.A + p.A + j] = std; }
+    }
+    lp = wave_sum(lp);
+    if (lane == 0) p.neg_logp[b] = -lp;
+}
+
 // ---- fixed-order column reductions of per-workgroup partials (types and the block body: common.h) ---------------------------------
 __global__ __launch_bounds__(256) void colsum_jobs_kernel(const ColsumParams p) { colsum_block(p, (int)blockIdx.x, (int)threadIdx.x); }
 
@@ -434,6 +707,15 @@ extern "C" int pcrl_q_tail_workspace_floats(int32_t M, int32_t H, size_t* part_f
 
 static int q_tail_launch(const QTailParams& p, hipStream_t st) {
     if (p.H % 256 || p.H < 256 || p.H > 256 * kTailMaxChunks) return fail(PCRL_E_ARG, "head tail: H must be a multiple of 256, <= %d (got %d)", 256 * kTailMaxChunks, p.H);
+    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    if (p.H == 1024 && p.M <= split_max) {         // small batch: a row's hidden vector over four waves
+        const int grid_s = (p.M + 3) / 4 + (p.cg_dst ? (2 * p.cg_ncols * p.H + 1023) / 1024 : 0);
+        const size_t lds_s = p.mode == 0 ? sizeof(float) * 8 * (size_t)p.H : 0;
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(q_tail_split_kernel), sizeof(float) * 8 * 1024)) return rc;
+        hipLaunchKernelGGL(q_tail_split_kernel, dim3(grid_s), dim3(1024), lds_s, st, p);
+        PCRL_CHECK_LAUNCH("q_tail_split_kernel");
+        return PCRL_OK;
+    }
     const int grid = (p.M + 3) / 4 + (p.cg_dst ? (2 * p.cg_ncols * p.H + 255) / 256 : 0);
     const size_t lds = p.mode == 0 ? sizeof(float) * 8 * (size_t)p.H : 0;
     switch (p.H / 256) {
@@ -512,8 +794,14 @@ extern "C" int pcrl_policy_tail_bwd_f32(const float* dh1, int64_t dh1_head_strid
     p.epsilon = epsilon; p.d_neglogp = d_neglogp; p.dfeat = d_feat; p.ld_dfeat = ld_d_feat; p.h2 = h2; p.w2 = w2; p.dh2 = dh2;
     p.fin_on = stat_part != nullptr;
     p.fin = ActorFinalizeParams{stat_part, (M + 3) / 4, M, log_alpha, target_entropy, alpha_grad, stats};
-    const int grid = (M + 3) / 4 + (p.fin_on ? 1 : 0);
     hipStream_t st = (hipStream_t)stream;
+    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    if (H == 1024 && M <= split_max && A <= 32) {
+        hipLaunchKernelGGL(policy_tail_bwd_split_kernel, dim3(M + (p.fin_on ? 1 : 0)), dim3(256), 0, st, p);
+        PCRL_CHECK_LAUNCH("policy_tail_bwd_split_kernel");
+        return PCRL_OK;
+    }
+    const int grid = (M + 3) / 4 + (p.fin_on ? 1 : 0);
     switch (H / 256) {
         case 1: hipLaunchKernelGGL(policy_tail_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, p); break;
         case 2: hipLaunchKernelGGL(policy_tail_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, p); break;
@@ -545,6 +833,12 @@ extern "C" int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, c
     PolicyTailParams p{h2, M, H, w2, b2, A, eps, eps_out, (unsigned)seed, (unsigned)(seed >> 32), step_counter, draw_id, scale, bias,
                        log_std_min, log_std_max, epsilon, feat, ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved};
     hipStream_t st = (hipStream_t)stream;
+    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    if (H == 1024 && M <= split_max) {             // small batch: one row per workgroup, a quarter of the hidden vector per wave
+        hipLaunchKernelGGL(policy_tail_fwd_split_kernel, dim3(M), dim3(256), 0, st, p);
+        PCRL_CHECK_LAUNCH("policy_tail_fwd_split_kernel");
+        return PCRL_OK;
+    }
     const bool wide = M > 512;                     // rows per wave: 4 when the batch fills the chip anyway
     const int grid = wide ? (M + 15) / 16 : (M + 3) / 4;
 #define PCRL_PT_CASE(NC_) \

@@ -199,9 +199,18 @@ class FusedStep:
         # default keeps the step one chain.
         self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
         self._forked = False
-        self.policy_tail_max = int(__import__("os").environ.get("PCRL_POLICY_TAIL_MAX", "4096"))
+        # rows x outputs up to which the policy's last layer runs inside the head kernels (csrc/headtail.hip) instead of as a GEMM + a
+        # separate head launch: 4 096 for the wave-per-row kernels, 16 384 where the row-split kernels apply (H = 1024, <= 512 rows:
+        # K3's 128-cloud share 0.669 -> 0.657 ms, K2's actor phase; K3's full batch stays on the GEMMs)
+        _env_max = __import__("os").environ.get("PCRL_POLICY_TAIL_MAX")
+        self.policy_tail_max = int(_env_max) if _env_max else 4096
+        self.policy_tail_max_split = int(_env_max) if _env_max else 16384
         self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
         self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
+
+    def _policy_tail_fits(self, M):
+        split = self.H == 1024 and M <= 512        # the row-split kernels' domain (headtail.hip: PCRL_TAIL_SPLIT_MAX)
+        return M * 2 * self.A <= (self.policy_tail_max_split if split else self.policy_tail_max)
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -255,7 +264,7 @@ class FusedStep:
         # the head kernel is one wave per row (or four) streaming all 2 A rows of the last layer from L2: a latency chain that
         # beats GEMM + a separate head launch only while rows x outputs is small (K1: 256 x 12 -> 8.6 us; K3: 1 024 x 44 -> 34.5 us
         # against ~13 us for the two launches)
-        if self.tails and M * 2 * A <= self.policy_tail_max:   # two layers as GEMMs, the last one inside the head kernel
+        if self.tails and self._policy_tail_fits(M):   # two layers as GEMMs, the last one inside the head kernel
             launch_layers(mlp_forward_descs(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)[:2])
             eps_in = head._standard_normal(eps) if head.noise_override else None
             hip.policy_tail_fwd(h2, M, H, self.pi.W(2), self.pi.Bv(2), A, eps_in, self.seed, a.critic_optim.step_counter,
@@ -436,7 +445,7 @@ class FusedStep:
             head = a.actor.head
             dfeat = self._buf("pi_dfeat", Ma, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
-            if self.tails and self.tail_bwd and Ma * 2 * A <= self.policy_tail_max:
+            if self.tails and self.tail_bwd and self._policy_tail_fits(Ma):
                 # ---- the chain q tail -> dh1 GEMM -> ONE launch for [d_act GEMM, TanhGaussianHead backward, the policy's dh2 GEMM,
                 # actor_finalize] -> the policy's two remaining backward stages (its last layer's dW2 | db2 rides in the first) ----
                 launch_layers(qa_descs[:2])
