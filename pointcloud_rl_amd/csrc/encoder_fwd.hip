@@ -798,12 +798,16 @@ extern "C" int pcrl_encoder_packed_bytes(int32_t c_in, int32_t c1, int32_t c2, i
     return PCRL_OK;
 }
 
-static void split_plan(int B, int N, int* S, int* tiles_total, int* tiles_per_seg) {
+// min_tiles: tiles a workgroup should at least have.  8 (one per wave) for the bf16 kernel, whose two waves per SIMD overlap vector
+// work with each other's MFMAs; 4 (one per SIMD) for the fp32 / split kernels, where the two waves of a SIMD only take turns on the
+// matrix pipe -- a 32-cloud launch (a rank's share of K1 at 8 GPUs) then spreads over all 256 CUs with one tile per SIMD instead of
+// 128 CUs with two (measured: the actor-phase forward of a 32-cloud step 54.8 -> see DESIGN.md section 4.1).
+static void split_plan(int B, int N, int* S, int* tiles_total, int* tiles_per_seg, int min_tiles = 4) {
     const int tiles = (N + 31) / 32, cus = num_cus();
     int s = 1;
     if (B < cus) {
         s = cus / B;
-        const int max_s = (tiles + 7) / 8;    // keep >= 8 tiles (one per wave) per workgroup
+        const int max_s = (tiles + min_tiles - 1) / min_tiles;
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;
     }
@@ -842,7 +846,8 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     FwdParams p{};
     if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
     if (p.cl.B == 0) return PCRL_OK;
-    split_plan(p.cl.B, p.cl.N, &p.S, &p.tiles_total, &p.tiles_per_seg);
+    static const int min_tiles_f32 = [] { const char* e = getenv("PCRL_FWD_MIN_TILES"); return e ? atoi(e) : 4; }();
+    split_plan(p.cl.B, p.cl.N, &p.S, &p.tiles_total, &p.tiles_per_seg, mode == 1 ? 8 : min_tiles_f32);
     if (p.S > 1) {
         const size_t ws = (size_t)p.cl.B * p.S * w->c3 * sizeof(unsigned long long);
         if (!workspace || workspace_bytes < ws) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, ws);
