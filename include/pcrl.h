@@ -126,6 +126,15 @@ int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3, size_t* b
 /* Re-order the weights into the operand order the forward kernel streams.
  * Must be re-run whenever the weights change (after every optimizer step). */
 int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream);
+/* Column-gather jobs riding on the NEXT pcrl_encoder_pack_weights_f32 launch of this host thread (extra workgroups; the step re-packs
+ * at the start of each phase anyway): columns [col0, col0 + ncols) of `heads` row-major matrices src + h * head_stride [rows][ld]
+ * -> dst [heads][ncols][rows].  The update step uses it for the ACTION columns of the Q heads' first layer (LinearMLP's linear0 over
+ * Visuomotor's [feature | state | action] input, mlp.py:97-100, visuomotor.py:130-144), which pcrl_policy_tail_fwd_fold_f32 and
+ * pcrl_policy_tail_bwd_f32 contract row-wise.  n = 0 withdraws; pcrl_encoder_pack_flush_cols runs jobs still pending (a phase whose
+ * weights needed no re-pack) as a launch of their own. */
+typedef struct pcrl_col_gather { const float* src; int64_t head_stride; int32_t heads, rows, ld, col0, ncols, _pad; float* dst; } pcrl_col_gather;
+int pcrl_encoder_pack_attach_cols(const pcrl_col_gather* jobs, int32_t n);
+int pcrl_encoder_pack_flush_cols(void* stream);
 
 /* Fused PointNet encoder forward, fp32:
  *   preprocess (pointnet.py:49-73) -> [augment] -> conv0+ReLU -> conv1+LN1d+ReLU ->
@@ -427,6 +436,18 @@ int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, const float*
                              const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
                              float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
                              void* stream);
+/* pcrl_policy_tail_fwd_f32 that also finishes the FIRST layer of n_heads Q heads on (s, a) for the action it just formed:
+ *   h1[h][m][:] = relu(pre[h][m][:] + sum_j action[m][j] w0_action_cols[h][j][:])
+ * with pre = [feature | state] W0[:, :F+S]^T + b0 from an earlier GEMM (it does not depend on the action) and w0_action_cols
+ * [n_heads][A][H] from pcrl_encoder_pack_attach_cols: Visuomotor's torch.cat([feature, state, action]) + LinearMLP's linear0 + ReLU
+ * (visuomotor.py:130-144, mlp.py:97-100) without a launch for a K = 50..220 GEMM between the policy and the Q heads' second layer.
+ * pre and h1 may alias.  Built for H = 1024 and M <= 512 (PCRL_E_ARG otherwise: the caller keeps the GEMM). */
+int pcrl_policy_tail_fwd_fold_f32(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
+                             uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
+                             const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
+                             float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
+                             const float* pre, int64_t pre_head_stride, const float* w0_action_cols, int64_t w0a_head_stride,
+                             int32_t n_heads, float* h1, int64_t h1_head_stride, void* stream);
 
 /* ---- update tail ---------------------------------------------------------------------------------
  * Squashed-Gaussian policy head, mode "max-entropy" (TanhGaussianHead + ScaledTanhNormal,

@@ -54,6 +54,11 @@ class AdamRider(ctypes.Structure):
                 ("partial", ctypes.c_void_p)]
 
 
+class ColGather(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("head_stride", ctypes.c_int64), ("heads", ctypes.c_int32), ("rows", ctypes.c_int32),
+                ("ld", ctypes.c_int32), ("col0", ctypes.c_int32), ("ncols", ctypes.c_int32), ("_pad", ctypes.c_int32), ("dst", ctypes.c_void_p)]
+
+
 class LnJob(ctypes.Structure):
     _fields_ = [("x", ctypes.c_void_p), ("ldx", ctypes.c_int64), ("M", ctypes.c_int32), ("n_dst", ctypes.c_int32),
                 ("dst", ctypes.c_void_p * 4), ("ld_dst", ctypes.c_int64 * 4), ("xhat", ctypes.c_void_p), ("rstd", ctypes.c_void_p),

@@ -601,8 +601,25 @@ __global__ __launch_bounds__(256) void encoder_merge_head_kernel(const unsigned 
     feature_head_epilogue(head, b, C3, s_val, threadIdx.x, 256);
 }
 
+// Column-gather jobs riding on the pack launch (pcrl_encoder_pack_attach_cols): columns [col0, col0 + ncols) of `heads` weight
+// matrices src + h * head_stride [rows][ld] written as the compact image dst [heads][ncols][rows] -- the action columns of the Q heads'
+// first layer, which the policy tails contract row-wise (coalesced rows instead of 4-byte loads ld floats apart).
+struct ColGather { const float* src; long long head_stride; int heads, rows, ld, col0, ncols; float* dst; int blk_begin; };
+struct ColGatherList { ColGather job[2]; int n; };
+
 // Weights (reference state_dict layout) -> operand order.  One thread per packed float.
-__global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __restrict__ out) {
+__global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __restrict__ out, const ColGatherList cg, int main_blocks) {
+    if ((int)blockIdx.x >= main_blocks) {
+        const int blk = (int)blockIdx.x - main_blocks;
+        const ColGather& g = (cg.n > 1 && blk >= cg.job[1].blk_begin) ? cg.job[1] : cg.job[0];
+        const int per_head = g.ncols * g.rows;
+        const int e = (blk - g.blk_begin) * 256 + (int)threadIdx.x;
+        if (e < g.heads * per_head) {
+            const int h = e / per_head, r = e - h * per_head, j = r / g.rows, row = r - j * g.rows;
+            g.dst[e] = g.src[h * g.head_stride + (long long)row * g.ld + g.col0 + j];
+        }
+        return;
+    }
     const PackedLayout L{T0, w.c1, w.c2, w.c3};
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= L.total()) return;
@@ -824,6 +841,47 @@ extern "C" int pcrl_encoder_fwd_workspace_bytes(int32_t B, int32_t N, int32_t c3
     return PCRL_OK;
 }
 
+// pcrl_encoder_pack_attach_cols: jobs handed over for the NEXT pack launch of this host thread
+static thread_local ColGatherList t_colgather = {};
+static thread_local int t_colgather_blocks = 0;
+
+__global__ void col_gather_kernel(const ColGatherList cg) {       // the same jobs as a launch of their own (pcrl_encoder_pack_flush_cols)
+    const int blk = (int)blockIdx.x;
+    const ColGather& g = (cg.n > 1 && blk >= cg.job[1].blk_begin) ? cg.job[1] : cg.job[0];
+    const int per_head = g.ncols * g.rows;
+    const int e = (blk - g.blk_begin) * 256 + (int)threadIdx.x;
+    if (e < g.heads * per_head) {
+        const int h = e / per_head, r = e - h * per_head, j = r / g.rows, row = r - j * g.rows;
+        g.dst[e] = g.src[h * g.head_stride + (long long)row * g.ld + g.col0 + j];
+    }
+}
+
+extern "C" int pcrl_encoder_pack_attach_cols(const pcrl_col_gather* jobs, int32_t n) {
+    if (n == 0) { t_colgather.n = 0; t_colgather_blocks = 0; return PCRL_OK; }
+    if (!jobs || n < 0 || n > 2) return fail(PCRL_E_ARG, "column gather: 0 <= n <= 2 jobs");
+    ColGatherList l{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const pcrl_col_gather& j = jobs[i];
+        if (!j.src || !j.dst || j.heads < 1 || j.rows < 1 || j.ncols < 1 || j.col0 < 0 || j.col0 + j.ncols > j.ld)
+            return fail(PCRL_E_ARG, "column gather: bad job %d", i);
+        l.job[l.n++] = ColGather{j.src, j.head_stride, j.heads, j.rows, j.ld, j.col0, j.ncols, j.dst, blocks};
+        blocks += (j.heads * j.ncols * j.rows + 255) / 256;
+    }
+    t_colgather = l; t_colgather_blocks = blocks;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_flush_cols(void* stream) {
+    if (t_colgather.n == 0) return PCRL_OK;
+    const ColGatherList l = t_colgather;
+    const int blocks = t_colgather_blocks;
+    t_colgather.n = 0; t_colgather_blocks = 0;
+    hipLaunchKernelGGL(col_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, l);
+    PCRL_CHECK_LAUNCH("col_gather_kernel");
+    return PCRL_OK;
+}
+
 extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream) {
     if (!w || !packed) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
@@ -831,7 +889,10 @@ extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void
     if (packed_bytes < need) return fail(PCRL_E_WORKSPACE, "packed buffer %zu < %zu bytes", packed_bytes, need);
     const int T0 = (w->c_in + 1) / 2;
     const int total = (int)(need / sizeof(float));
-    hipLaunchKernelGGL(encoder_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *w, T0, (float*)packed);
+    const ColGatherList l = t_colgather;       // attached column-gather jobs ride on this launch and are consumed by it
+    const int extra = t_colgather.n ? t_colgather_blocks : 0;
+    t_colgather.n = 0; t_colgather_blocks = 0;
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3((total + 255) / 256 + extra), dim3(256), 0, (hipStream_t)stream, *w, T0, (float*)packed, l, (total + 255) / 256);
     PCRL_CHECK_LAUNCH("encoder_pack_kernel");
     return PCRL_OK;
 }

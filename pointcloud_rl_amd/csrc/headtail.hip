@@ -477,6 +477,10 @@ struct PolicyTailParams {
     float* feat; long long ld_feat;                // [M][2A] (saved: the backward reads mean | log_std)
     float* act0; long long ld0; float* act1; long long ld1;
     float* neg_logp; float* saved;                 // [M], [M][2A]: tanh(u) | std
+    // fold (split kernel only): the Q heads' FIRST layer finished here -- h1[h][m][:] = relu(pre[h][m][:] + sum_j action[m][j] w0a[h][j][:])
+    // where pre = [feature | state] W0[:, :F+S]^T + b0 came from a GEMM launched earlier (no dependence on the action) and w0a is the
+    // compact image of the action columns (pcrl_encoder_pack_attach_cols).  pre and h1 may be the same buffer.
+    const float* fold_pre; long long fold_pre_hs; const float* fold_w0a; long long fold_w0a_hs; float* fold_h1; long long fold_h1_hs; int fold_heads;
 };
 
 __device__ __forceinline__ float tail_philox_normal(unsigned elem, unsigned draw, unsigned step, unsigned k0, unsigned k1) {
@@ -662,32 +666,51 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_split_kernel(const Policy
         }
     }
     __syncthreads();
-    if (wave != 0) return;
-    if (lane < n_out) s_feat[lane] = (((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]) + p.b2[lane];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int n = lane; n < n_out; n += 64) p.feat[(long long)b * p.ld_feat + n] = s_feat[n];
-    float lp = 0.0f;
-    if (lane < p.A) {
-        const int j = lane;
-        const float mean = s_feat[j], ls = s_feat[p.A + j];
-        const float std = expf(fminf(fmaxf(ls, p.ls_min), p.ls_max));
-        const float e = p.eps ? p.eps[(long long)b * p.A + j]
-                              : tail_philox_normal((unsigned)(b * p.A + j), (unsigned)p.draw_id, (unsigned)p.step[0], p.seed_lo, p.seed_hi);
-        if (p.eps_out) p.eps_out[(long long)b * p.A + j] = e;
-        const float u = mean + e * std;
-        const float t = tanhf(u);
-        const float sc = p.scale[j];
-        const float a = t * sc + p.bias[j];
-        const float diff = u - mean;
-        lp = -(diff * diff) / (2.0f * (std * std)) - logf(std) - kTailHalfLog2Pi - logf(sc * (1.0f - t * t) + p.epsilon);
-        p.act0[(long long)b * p.ld0 + j] = a;
-        if (p.act1) p.act1[(long long)b * p.ld1 + j] = a;
-        if (p.saved) { p.saved[(long long)b * 2 * p.A + j] = t; p.saved[(long long)b * 2 * p.A + p.A + j] = std; }
+    __shared__ float s_act[32];
+    if (wave == 0) {
+        if (lane < n_out) s_feat[lane] = (((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane]) + p.b2[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int n = lane; n < n_out; n += 64) p.feat[(long long)b * p.ld_feat + n] = s_feat[n];
+        float lp = 0.0f;
+        if (lane < p.A) {
+            const int j = lane;
+            const float mean = s_feat[j], ls = s_feat[p.A + j];
+            const float std = expf(fminf(fmaxf(ls, p.ls_min), p.ls_max));
+            const float e = p.eps ? p.eps[(long long)b * p.A + j]
+                                  : tail_philox_normal((unsigned)(b * p.A + j), (unsigned)p.draw_id, (unsigned)p.step[0], p.seed_lo, p.seed_hi);
+            if (p.eps_out) p.eps_out[(long long)b * p.A + j] = e;
+            const float u = mean + e * std;
+            const float t = tanhf(u);
+            const float sc = p.scale[j];
+            const float a = t * sc + p.bias[j];
+            const float diff = u - mean;
+            lp = -(diff * diff) / (2.0f * (std * std)) - logf(std) - kTailHalfLog2Pi - logf(sc * (1.0f - t * t) + p.epsilon);
+            p.act0[(long long)b * p.ld0 + j] = a;
+            if (p.act1) p.act1[(long long)b * p.ld1 + j] = a;
+            if (p.saved) { p.saved[(long long)b * 2 * p.A + j] = t; p.saved[(long long)b * 2 * p.A + p.A + j] = std; }
+            s_act[j] = a;
+        }
+        lp = wave_sum(lp);
+        if (lane == 0) p.neg_logp[b] = -lp;
     }
-    lp = wave_sum(lp);
-    if (lane == 0) p.neg_logp[b] = -lp;
+    if (!p.fold_h1) return;
+    __syncthreads();
+    // ---- the Q heads' first layer for this row, a quarter of the hidden vector per wave ----
+    const int col = 256 * wave + 4 * lane;
+    for (int h = 0; h < p.fold_heads; ++h) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(p.fold_pre + h * p.fold_pre_hs + (long long)b * p.H + col);
+        for (int j = 0; j < p.A; ++j) {
+            const float a = s_act[j];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.fold_w0a + h * p.fold_w0a_hs + (long long)j * p.H + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(a, wv[e], acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.0f ? acc[e] : 0.0f;
+        *reinterpret_cast<f32x4*>(p.fold_h1 + h * p.fold_h1_hs + (long long)b * p.H + col) = acc;
+    }
 }
 
 // ---- fixed-order column reductions of per-workgroup partials (types and the block body: common.h) ---------------------------------
@@ -821,19 +844,51 @@ extern "C" int pcrl_actor_finalize_f32(const float* stat_part, int32_t M, const 
     return PCRL_OK;
 }
 
+static int policy_tail_fwd_impl(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
+                                uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
+                                const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
+                                float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
+                                const float* fold_pre, int64_t fold_pre_hs, const float* fold_w0a, int64_t fold_w0a_hs, int32_t fold_heads,
+                                float* fold_h1, int64_t fold_h1_hs, void* stream);
+
 extern "C" int pcrl_policy_tail_fwd_f32(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
                                         uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
                                         const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
                                         float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
                                         void* stream) {
+    return policy_tail_fwd_impl(h2, M, H, w2, b2, A, eps, seed, step_counter, draw_id, eps_out, scale, bias, log_std_min, log_std_max, epsilon, feat,
+                                ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved, nullptr, 0, nullptr, 0, 0, nullptr, 0, stream);
+}
+
+extern "C" int pcrl_policy_tail_fwd_fold_f32(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
+                                             uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
+                                             const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
+                                             float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
+                                             const float* pre, int64_t pre_head_stride, const float* w0_action_cols, int64_t w0a_head_stride,
+                                             int32_t n_heads, float* h1, int64_t h1_head_stride, void* stream) {
+    if (!pre || !w0_action_cols || !h1 || n_heads < 1 || n_heads > 4) return fail(PCRL_E_ARG, "policy tail fold: NULL argument or n_heads outside [1, 4]");
+    return policy_tail_fwd_impl(h2, M, H, w2, b2, A, eps, seed, step_counter, draw_id, eps_out, scale, bias, log_std_min, log_std_max, epsilon, feat,
+                                ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved, pre, pre_head_stride, w0_action_cols,
+                                w0a_head_stride, n_heads, h1, h1_head_stride, stream);
+}
+
+static int policy_tail_fwd_impl(const float* h2, int32_t M, int32_t H, const float* w2, const float* b2, int32_t A, const float* eps,
+                                uint64_t seed, const int32_t* step_counter, int32_t draw_id, float* eps_out, const float* scale,
+                                const float* bias, float log_std_min, float log_std_max, float epsilon, float* feat, int64_t ld_feat,
+                                float* action, int64_t ld_action, float* action2, int64_t ld_action2, float* neg_logp, float* saved,
+                                const float* fold_pre, int64_t fold_pre_hs, const float* fold_w0a, int64_t fold_w0a_hs, int32_t fold_heads,
+                                float* fold_h1, int64_t fold_h1_hs, void* stream) {
     if (!h2 || !w2 || !b2 || !scale || !bias || !feat || !action || !neg_logp) return fail(PCRL_E_ARG, "NULL argument");
     if (!eps && (!step_counter || !eps_out)) return fail(PCRL_E_ARG, "in-kernel draws need step_counter and eps_out");
     if (M < 1 || A < 1 || 2 * A > 64) return fail(PCRL_E_ARG, "policy tail: 1 <= A <= 32 (got %d)", A);
     if (H % 256 || H < 256 || H > 1024) return fail(PCRL_E_ARG, "policy tail: H must be 256, 512, 768 or 1024 (got %d)", H);
     PolicyTailParams p{h2, M, H, w2, b2, A, eps, eps_out, (unsigned)seed, (unsigned)(seed >> 32), step_counter, draw_id, scale, bias,
-                       log_std_min, log_std_max, epsilon, feat, ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved};
+                       log_std_min, log_std_max, epsilon, feat, ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved,
+                       fold_pre, fold_pre_hs, fold_w0a, fold_w0a_hs, fold_h1, fold_h1_hs, fold_heads};
     hipStream_t st = (hipStream_t)stream;
     static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    if (fold_h1 && !(H == 1024 && M <= split_max && A <= 32))
+        return fail(PCRL_E_ARG, "policy tail fold: built for H = 1024, M <= %d, A <= 32 (got H=%d M=%d A=%d)", split_max, H, M, A);
     if (H == 1024 && M <= split_max) {             // small batch: one row per workgroup, a quarter of the hidden vector per wave
         hipLaunchKernelGGL(policy_tail_fwd_split_kernel, dim3(M), dim3(256), 0, st, p);
         PCRL_CHECK_LAUNCH("policy_tail_fwd_split_kernel");

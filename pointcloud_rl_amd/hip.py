@@ -543,10 +543,37 @@ def actor_finalize(stat_part, M, log_alpha, target_entropy, alpha_grad, stats):
     check(lib().pcrl_actor_finalize_f32(_ptr(stat_part), M, _ptr(log_alpha), _f(target_entropy), _ptr(alpha_grad), _ptr(stats), _stream()))
 
 
+def pack_attach_cols(jobs):
+    """jobs: [(src tensor view at head 0's matrix, head_stride, heads, rows, ld, col0, ncols, dst [heads, ncols, rows])] -- column-gather
+    jobs that ride on the NEXT encoder_pack_weights launch (pcrl_encoder_pack_attach_cols); [] withdraws."""
+    arr = (_lib.ColGather * max(len(jobs), 1))()
+    for a, (src, hs, heads, rows, ld, col0, ncols, dst) in zip(arr, jobs):
+        assert dst.is_contiguous() and dst.numel() == heads * ncols * rows
+        a.src, a.head_stride, a.heads, a.rows, a.ld, a.col0, a.ncols, a.dst = src.data_ptr(), hs, heads, rows, ld, col0, ncols, dst.data_ptr()
+    check(lib().pcrl_encoder_pack_attach_cols(arr, len(jobs)))
+
+
+def pack_flush_cols():
+    """Runs column-gather jobs that are still attached (no pack launch consumed them) as a launch of their own."""
+    check(lib().pcrl_encoder_pack_flush_cols(_stream()))
+
+
 def policy_tail_fwd(h2, M, H, w2, b2, A, eps, seed, step_counter, draw_id, eps_out, scale, bias, ls_min, ls_max, epsilon, feat, action, ld_action,
-                    neg_logp, saved=None, action2_ptr=None, ld_action2=0):
-    """The policy's last Linear + TanhGaussianHead "max-entropy"; eps None: Philox draws in the kernel (written to eps_out)."""
+                    neg_logp, saved=None, action2_ptr=None, ld_action2=0, fold=None):
+    """The policy's last Linear + TanhGaussianHead "max-entropy"; eps None: Philox draws in the kernel (written to eps_out).
+    fold = (pre, pre_head_stride, w0_action_cols, w0a_head_stride, n_heads, h1, h1_head_stride): also the Q heads' first layer on the
+    action just formed (pcrl_policy_tail_fwd_fold_f32; H = 1024 and M <= 512 only)."""
     _check_f32_vec(scale, A, "scale"), _check_f32_vec(bias, A, "bias")
+    if fold is not None:
+        pre, pre_hs, w0a, w0a_hs, n_heads, h1, h1_hs = fold
+        with _span("policy_tail"):
+            check(lib().pcrl_policy_tail_fwd_fold_f32(_ptr(h2), M, H, _ptr(w2), _ptr(b2), A, _ptr(eps), ctypes.c_uint64(seed & (2 ** 64 - 1)),
+                                                      _ptr(step_counter), int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), _f(ls_min), _f(ls_max),
+                                                      _f(epsilon), _ptr(feat), ctypes.c_int64(2 * A), _ptr(action), ctypes.c_int64(ld_action),
+                                                      ctypes.c_void_p(action2_ptr) if action2_ptr else None, ctypes.c_int64(ld_action2),
+                                                      _ptr(neg_logp), _ptr(saved), _ptr(pre), ctypes.c_int64(pre_hs), _ptr(w0a),
+                                                      ctypes.c_int64(w0a_hs), int(n_heads), _ptr(h1), ctypes.c_int64(h1_hs), _stream()))
+        return
     with _span("policy_tail"):
         check(lib().pcrl_policy_tail_fwd_f32(_ptr(h2), M, H, _ptr(w2), _ptr(b2), A, _ptr(eps), ctypes.c_uint64(seed & (2 ** 64 - 1)), _ptr(step_counter),
                                              int(draw_id), _ptr(eps_out), _ptr(scale), _ptr(bias), _f(ls_min), _f(ls_max), _f(epsilon), _ptr(feat),

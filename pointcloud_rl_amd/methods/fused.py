@@ -205,6 +205,8 @@ class FusedStep:
         _env_max = __import__("os").environ.get("PCRL_POLICY_TAIL_MAX")
         self.policy_tail_max = int(_env_max) if _env_max else 4096
         self.policy_tail_max_split = int(_env_max) if _env_max else 16384
+        self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
+        self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
         self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
         self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
 
@@ -251,8 +253,17 @@ class FusedStep:
                                      fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps, ranges)
         return head, out
 
-    def _actor_forward(self, XA, M, tag, act_dst, ld_act, save):
-        """Actor MLP + TanhGaussianHead mode="max-entropy"; the action goes straight into the Q input."""
+    def _fold_fits(self, M, group=1):
+        """The Q heads' first layer finished inside the policy tail (pcrl_policy_tail_fwd_fold_f32): where the row-split tail runs."""
+        # Measured on MI355X (tools/r4_ab6.sh, same box, initial training state): a rank's 32-cloud share of K1 (A = 6) 0.3318 -> 0.3275 ms,
+        # K1 itself 0.8440 -> 0.8459 (neutral: one launch and two graph nodes fewer, the tail 2.3 us longer), K3's 128-cloud share
+        # (A = 22: 44 KB of action columns per row) 0.6753 -> 0.6807 -- so only for small action spaces.
+        return (self.tails and self.fold_q0 and self.H == 1024 and M <= 512 and self.A <= self.fold_max_a and self._policy_tail_fits(M)
+                and group in (1, 2, 4))
+
+    def _actor_forward(self, XA, M, tag, act_dst, ld_act, save, extra_l0=(), fold=None):
+        """Actor MLP + TanhGaussianHead mode="max-entropy"; the action goes straight into the Q input.  extra_l0: GEMM descriptors
+        that share the launch of the actor's first layer; fold: see hip.policy_tail_fwd."""
         a, A, H = self.a, self.A, self.H
         h1, h2 = self._buf(f"pi_h1_{tag}", 1, M, H), self._buf(f"pi_h2_{tag}", 1, M, H)
         feat = self._buf(f"pi_out_{tag}", M, 2 * A)
@@ -265,12 +276,15 @@ class FusedStep:
         # beats GEMM + a separate head launch only while rows x outputs is small (K1: 256 x 12 -> 8.6 us; K3: 1 024 x 44 -> 34.5 us
         # against ~13 us for the two launches)
         if self.tails and self._policy_tail_fits(M):   # two layers as GEMMs, the last one inside the head kernel
-            launch_layers(mlp_forward_descs(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)[:2])
+            descs = mlp_forward_descs(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
+            hip.gemm_group([descs[0]] + list(extra_l0))
+            hip.gemm_group([descs[1]])
             eps_in = head._standard_normal(eps) if head.noise_override else None
             hip.policy_tail_fwd(h2, M, H, self.pi.W(2), self.pi.Bv(2), A, eps_in, self.seed, a.critic_optim.step_counter,
                                 0 if tag == "n" else 1, eps, self.head_scale, self.head_bias, head.log_std_min, head.log_std_max,
-                                head.epsilon, feat, act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act)
+                                head.epsilon, feat, act, A, nlp, saved, action2_ptr=act_dst, ld_action2=ld_act, fold=fold)
             return feat, (eps_in if eps_in is not None else eps), saved, nlp, h1, h2
+        assert not extra_l0 and fold is None
         mlp_forward(self.pi, None, 0, XA, self.lda, M, (h1, h2), 2 * A, feat, 0)
         if head.noise_override:          # parity tests inject the draws
             eps = head._standard_normal(eps)
@@ -340,6 +354,13 @@ class FusedStep:
         XA_n, XQ_n, XQ_o = self._buf("XA_n", M, lda), self._buf("XQ_n", M, ldq), self._buf("XQ_o", M, ldq)
         job_n = lambda begin: (begin, M, "n", [(XA_n, 0, lda), (XQ_n, 0, ldq)], False, [(state_n, XA_n, F, repeat), (state_n, XQ_n, F, repeat)])
         job_o = lambda begin: (begin, M, "o", [(XQ_o, 0, ldq)], True, [(state_o, XQ_o, F, repeat), (actions, XQ_o, F + S, repeat)])
+        # The Q heads' first layer on (s', a') is finished by the policy tail (it needs a' only through the action columns): the compact
+        # image of the TARGET heads' action columns rides on the re-pack launch that heads this phase
+        fold_c = self._fold_fits(M, group)
+        tgt = a._target_flat.data
+        if fold_c:
+            w0a_t = self._buf("q_w0_action_cols_target", 2, A, H)
+            hip.pack_attach_cols([(self.q.W(0, tgt, -self.q_base), self.q.hs, 2, H, self.Din_q, F + S, A, w0a_t)])
         if both is not None:              # s and s' sit back to back (DeviceReplay's staging): one launch of 2 M clouds
             head, ((xhat, rstd), _) = self._feature_jobs([job_o(0), job_n(M)])
             pooled_all, argmax_all, _ = enc.encode_raw(both, head=head)
@@ -352,15 +373,25 @@ class FusedStep:
             head_o, ((xhat, rstd),) = self._feature_jobs([job_o(0)])
             pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o, head=head_o)
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
+        if fold_c:
+            hip.pack_flush_cols()            # (a phase whose weights needed no re-pack: the gather as a launch of its own)
         prepared = self._fork_prepare(enc, ctx_o, argmax_o)
-        _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)
-        tgt = a._target_flat.data
         q_h1, q_h2 = self._buf("q_h1", 2, M, H), self._buf("q_h2", 2, M, H)
         q = self._buf("q", M, 2)
         q_tgt_descs = mlp_forward_descs(self.q, tgt, -self.q_base, XQ_n, ldq, M, (qn_h1, qn_h2), 2, q_next, 1)
         q_on_descs = mlp_forward_descs(self.q, None, 0, XQ_o, ldq, M, (q_h1, q_h2), 2, q, 1)
+        if fold_c:
+            # one launch: the actor's first layer on s', the online heads' first layer on (s, a) -- neither needs the actor's output --
+            # and the action-free part of the target heads' first layer, pre = [feature | state] W0[:, :F+S]^T + b0 (no ReLU yet)
+            hs, k0 = self.q.hs, self.Din_q
+            pre_t = hip.gemm_desc(XQ_n, self.q.W(0, tgt, -self.q_base), qn_h1, M, H, F + S, (ldq, 1), (1, k0), H,
+                                  bias=self.q.Bv(0, tgt, -self.q_base), batch=2, batch_strides=(0, hs, M * H, hs, 0))
+            _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False, extra_l0=[pre_t, q_on_descs[0]],
+                                                       fold=(qn_h1, M * H, w0a_t, A * H, 2, qn_h1, M * H))
+        else:
+            _, _, _, nlp_n, _, _ = self._actor_forward(XA_n, M, "n", XQ_n.data_ptr() + 4 * (F + S), ldq, save=False)
         q_target, dq = self._buf("q_target", M), self._buf("dq", M, 2)
         dones_u8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones.to(torch.uint8)
         reward_scale = a.reward_scale if a.metric_prefix == "sac" else 1.0
@@ -371,11 +402,15 @@ class FusedStep:
         ws = self._buf("ln_ws", ((M + 3) // 4) * 2 * F)
         bwd_stages = mlp_backward_descs(self.q, XQ_o, ldq, M, q_h1, q_h2, dq, (2, 1), 1, dh1, dh2, grad=fc.grad, dX=dX0, dx_cols=(0, F),
                                         ld_dx=ceil4(F))
+        assert not fold_c or (self.tails and group in (1, 2, 4))
         if self.tails and group in (1, 2, 4):
             # ---- two layers as GEMMs; the last layer of the four heads, the TD target / critic loss (sac.py:125-157) and the first
             # backward stage in ONE launch; its per-workgroup partials (dW2, db2, the logged statistics) are reduced by the same
             # column-sum launch that finishes the feature LayerNorm's backward ----
-            launch_layers(q_tgt_descs[:2], q_on_descs[:2])
+            if fold_c:
+                launch_layers(q_tgt_descs[1:2], q_on_descs[1:2])
+            else:
+                launch_layers(q_tgt_descs[:2], q_on_descs[:2])
             n_part, n_stat = hip.q_tail_workspace_floats(M, H)
             part, stat_part = self._buf("q_tail_part", n_part), self._buf("q_tail_stat", n_stat)
             hs = self.q.hs
@@ -430,9 +465,20 @@ class FusedStep:
             Ma = M if actor_obs is None else vis_a["xyz"].shape[0]
             XA_a, XQ_a = self._buf("XA_a", Ma, lda), self._buf("XQ_a", Ma, ldq)
             head_a, _ = self._feature_jobs([(0, Ma, "a", [(XA_a, 0, lda), (XQ_a, 0, ldq)], False, [(state_a, XA_a, F), (state_a, XQ_a, F)])])
+            fold_a = self._fold_fits(Ma)
+            w0a = self._buf("q_w0_action_cols", 2, A, H)
+            if fold_a:                       # the ONLINE heads' action columns (just updated by the critic's optimizer) ride on this phase's re-pack
+                hip.pack_attach_cols([(self.q.W(0), self.q.hs, 2, H, self.Din_q, F + S, A, w0a)])
             pooled_a, _, _ = enc.encode_raw(vis_a, head=head_a)      # updated encoder weights, no gradient
-            feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             qa_h1, qa_h2 = self._buf("qa_h1", 2, Ma, H), self._buf("qa_h2", 2, Ma, H)
+            if fold_a:
+                hip.pack_flush_cols()
+                pre_a = hip.gemm_desc(XQ_a, self.q.W(0), qa_h1, Ma, H, F + S, (ldq, 1), (1, self.Din_q), H, bias=self.q.Bv(0), batch=2,
+                                      batch_strides=(0, self.q.hs, Ma * H, self.q.hs, 0))
+                feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True, extra_l0=[pre_a],
+                                                                        fold=(qa_h1, Ma * H, w0a, A * H, 2, qa_h1, Ma * H))
+            else:
+                feat, eps, saved, nlp, p_h1, p_h2 = self._actor_forward(XA_a, Ma, "a", XQ_a.data_ptr() + 4 * (F + S), ldq, save=True)
             q_pi = self._buf("q_pi", Ma, 2)
             dq_pi = self._buf("dq_pi", Ma, 2)
             fal = a._flat["alpha"]
@@ -448,12 +494,14 @@ class FusedStep:
             if self.tails and self.tail_bwd and self._policy_tail_fits(Ma):
                 # ---- the chain q tail -> dh1 GEMM -> ONE launch for [d_act GEMM, TanhGaussianHead backward, the policy's dh2 GEMM,
                 # actor_finalize] -> the policy's two remaining backward stages (its last layer's dW2 | db2 rides in the first) ----
-                launch_layers(qa_descs[:2])
+                launch_layers(qa_descs[1:2] if fold_a else qa_descs[:2])
                 _, n_stat = hip.q_tail_workspace_floats(Ma, H)
                 stat_a = self._buf("qa_tail_stat", n_stat)
-                w0a = self._buf("q_w0_action_cols", 2, A, H)
-                hip.q_tail_actor_cols(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp,
-                                      stat_a, self.q.W(0), self.q.hs, self.Din_q, F + S, A, w0a)
+                if fold_a:                   # the action-column image is already there (this phase's re-pack launch)
+                    hip.q_tail_actor(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp, stat_a)
+                else:
+                    hip.q_tail_actor_cols(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp,
+                                          stat_a, self.q.W(0), self.q.hs, self.Din_q, F + S, A, w0a)
                 launch_layers(*[qa_bwd[1:2]])
                 hip.policy_tail_bwd(da_h1, Ma * H, w0a, A * H, Ma, H, A, feat, 2 * A, eps, saved, self.head_scale, head.log_std_min, head.log_std_max,
                                     head.epsilon, self.d_nlp, dfeat, 2 * A, p_h2, self.pi.W(2), dp_h2,
@@ -463,7 +511,7 @@ class FusedStep:
                 hip.gemm_group(pb[2])
                 tail_bwd_done = True
             elif self.tails:
-                launch_layers(qa_descs[:2])
+                launch_layers(qa_descs[1:2] if fold_a else qa_descs[:2])
                 _, n_stat = hip.q_tail_workspace_floats(Ma, H)
                 stat_a = self._buf("qa_tail_stat", n_stat)
                 hip.q_tail_actor(qa_h2, Ma * H, self.q.W(2), self.q.Bv(2), self.q.hs, nlp, a.log_alpha, Ma, H, q_pi, dq_pi, da_h2, self.d_nlp, stat_a)

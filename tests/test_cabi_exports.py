@@ -52,7 +52,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     pairs = [("pcrl_feat_seg", _lib.FeatSeg), ("pcrl_cloud_desc", _lib.CloudDesc), ("pcrl_aug_desc", _lib.AugDesc),
              ("pcrl_encoder_weights", _lib.EncoderWeights), ("pcrl_gemm_desc", _lib.GemmDesc), ("pcrl_ln_job", _lib.LnJob),
              ("pcrl_gather_seg", _lib.GatherSeg), ("pcrl_adam_pending", _lib.AdamPending), ("pcrl_colsum_job", _lib.ColsumJob),
-             ("pcrl_adam_rider", _lib.AdamRider)]
+             ("pcrl_adam_rider", _lib.AdamRider), ("pcrl_col_gather", _lib.ColGather)]
     lines = []
     for cname, cls in pairs:
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

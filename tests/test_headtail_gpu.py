@@ -228,3 +228,63 @@ def test_colsum_jobs_attached_to_the_encoder_backward_equal_the_stand_alone_laun
     hip.colsum_jobs(jobs(outs[2:4]), attach_to_encoder_bwd=True)
     hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=None)
     assert torch.equal(outs[2], outs[0])
+
+
+@pytest.mark.parametrize("M,A,K0,col0", [(256, 6, 56, 50), (40, 22, 220, 196)])
+def test_policy_tail_fold_finishes_the_q_heads_first_layer(cuda, M, A, K0, col0):
+    """pcrl_policy_tail_fwd_fold_f32: besides the policy head, h1[h] = relu(pre[h] + action W0_h[:, action columns]^T) for the Q heads --
+    against relu([feature | state | action] W0^T + b0) computed whole in float64; the column image comes from a gather job riding on a
+    pack launch (pcrl_encoder_pack_attach_cols) and, when no pack follows, from pcrl_encoder_pack_flush_cols; without the fold the
+    same launch returns exactly the plain tail's outputs."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_encoder_weights
+    from pointcloud_rl_amd import hip
+    H = 1024
+    g = np.random.RandomState(M + A)
+    h2 = np.maximum(g.randn(M, H), 0).astype(np.float32)
+    w2, b2 = (g.randn(2 * A, H) / 32).astype(np.float32), (0.1 * g.randn(2 * A)).astype(np.float32)
+    eps = g.randn(M, A).astype(np.float32)
+    scale, bias = g.uniform(0.5, 2.0, A).astype(np.float32), g.uniform(-0.5, 0.5, A).astype(np.float32)
+    w0 = (g.randn(2, H, K0) / 8).astype(np.float32)
+    b0 = (0.1 * g.randn(2, H)).astype(np.float32)
+    xq = g.randn(M, K0).astype(np.float32)                       # [feature | state | (action columns: overwritten by the tail)]
+    W0, XQ = T(w0, cuda), T(xq, cuda)
+    # the column image: riding on a pack launch, and through the flush
+    cols = torch.full((2, A, H), float("nan"), device=cuda)
+    hip.pack_attach_cols([(W0, H * K0, 2, H, K0, col0, A, cols)])
+    w = {k: T(v, cuda) for k, v in make_encoder_weights(6, 64, 128, 256, seed=3).items()}
+    ew, _ = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(6, 64, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    want_cols = W0[:, :, col0:col0 + A].permute(0, 2, 1).contiguous()
+    assert torch.equal(cols, want_cols)
+    ref_packed = torch.empty_like(packed)
+    hip.encoder_pack_weights(ew, ref_packed)                     # nothing attached any more: a plain pack, same image
+    assert torch.equal(packed, ref_packed)
+    cols2 = torch.full((2, A, H), float("nan"), device=cuda)
+    hip.pack_attach_cols([(W0, H * K0, 2, H, K0, col0, A, cols2)])
+    hip.pack_flush_cols()
+    assert torch.equal(cols2, want_cols)
+    hip.pack_flush_cols()                                        # nothing pending: no-op
+    # pre = [feature | state] W0[:, :col0]^T + b0 (what the GEMM ahead of the tail leaves)
+    pre = (torch.einsum("mk,hnk->hmn", XQ[:, :col0].double(), W0[:, :, :col0].double()) + T(b0, cuda).double()[:, None, :]).float().contiguous()
+    outs = {}
+    for fold in (False, True):
+        feat = torch.empty(M, 2 * A, device=cuda)
+        act, act2 = torch.empty(M, A, device=cuda), XQ.clone()
+        nlp, saved, eps_out = torch.empty(M, device=cuda), torch.empty(M, 2 * A, device=cuda), torch.empty(M, A, device=cuda)
+        h1 = pre.clone()
+        step = torch.zeros(1, dtype=torch.int32, device=cuda)
+        hip.policy_tail_fwd(T(h2, cuda), M, H, T(w2, cuda), T(b2, cuda), A, T(eps, cuda), 7, step, 1, eps_out, T(scale, cuda), T(bias, cuda), -10.0, 2.0,
+                            1e-6, feat, act, A, nlp, saved, action2_ptr=act2.data_ptr() + 4 * col0, ld_action2=K0,
+                            fold=(h1, M * H, cols, A * H, 2, h1, M * H) if fold else None)
+        outs[fold] = (feat, act, nlp, saved, act2, h1)
+    for a_, b_ in zip(outs[False][:5], outs[True][:5]):
+        assert torch.equal(a_, b_)
+    act2, h1 = outs[True][4], outs[True][5]
+    assert torch.equal(act2[:, col0:col0 + A], outs[True][1])
+    z = torch.einsum("mk,hnk->hmn", act2[:, :col0 + A].double(), W0[:, :, :col0 + A].double()) + T(b0, cuda).double()[:, None, :]
+    want = torch.relu(z).float()
+    np.testing.assert_allclose(h1.cpu().numpy(), want.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert torch.equal(outs[False][5], pre)                      # without the fold the buffer is left alone
