@@ -97,6 +97,34 @@ class PcrlError(RuntimeError):
 
 
 _lib = None
+RUNTIME_LINKS = os.path.join(_HERE, "_hiprt")
+
+
+def ensure_runtime_links():
+    """Create pointcloud_rl_amd/_hiprt (machine-local, idempotent): symlinks to the HIP runtime torch's wheel bundles, which
+    libpcrl_hip.so searches first (RPATH $ORIGIN/_hiprt, csrc/Makefile) -- so that a process holds ONE HIP runtime whether it maps
+    the library before or after `import torch`.  Without torch installed nothing is created and the library uses /opt/rocm's.
+    torch is located, not imported.  Returns the directory or None."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return None
+    src = os.path.join(os.path.dirname(spec.origin), "lib")
+    if not os.path.exists(os.path.join(src, "libamdhip64.so")):
+        return None
+    marker = os.path.join(RUNTIME_LINKS, "libamdhip64.so.7")
+    if os.path.islink(marker) and os.path.realpath(marker) == os.path.realpath(os.path.join(src, "libamdhip64.so")):
+        return RUNTIME_LINKS
+    os.makedirs(RUNTIME_LINKS, exist_ok=True)
+    for name in os.listdir(RUNTIME_LINKS):            # a stale set (another torch): start over
+        path = os.path.join(RUNTIME_LINKS, name)
+        if os.path.islink(path):
+            os.unlink(path)
+    for name in sorted(os.listdir(src)):
+        if ".so" in name and os.path.isfile(os.path.join(src, name)):
+            os.symlink(os.path.join(src, name), os.path.join(RUNTIME_LINKS, name))
+    os.symlink(os.path.join(src, "libamdhip64.so"), marker)      # the name libpcrl_hip.so asks for (its NEEDED entry is the soname)
+    return RUNTIME_LINKS
 
 
 def lib():
@@ -111,6 +139,10 @@ def lib():
         # library (linked against /opt/rocm's) loaded before torch, kernels launched here fail with "no ROCm-capable device
         # is detected" while torch's own work runs (seen with build() followed by smoke() in one process on the GPU box).
         import torch  # noqa: F401
+        try:
+            ensure_runtime_links()       # for embedders that map the library themselves, possibly before torch
+        except OSError:
+            pass                         # a read-only tree: the torch-first order above is what keeps this process on one runtime
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.pcrl_last_error.restype = ctypes.c_char_p
     return _lib
@@ -119,3 +151,9 @@ def lib():
 def check(rc):
     if rc != 0:
         raise PcrlError(f"pcrl error {rc}: {lib().pcrl_last_error().decode(errors='replace')}")
+
+
+if __name__ == "__main__":
+    import sys
+    if "--link-runtime" in sys.argv:
+        print("HIP runtime links:", ensure_runtime_links() or "torch not found: libpcrl_hip.so will use /opt/rocm's runtime")

@@ -80,3 +80,53 @@ def test_binding_loads_torch_before_the_library():
     out = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+_ORDER_PROBE = """
+import ctypes, json, os, sys
+sys.path.insert(0, {root!r})
+from pointcloud_rl_amd import _lib
+links = _lib.ensure_runtime_links()                  # what `make` / the first _lib.lib() of a machine leaves behind
+assert 'torch' not in sys.modules
+def runtimes():
+    return sorted({{l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}})
+lib = ctypes.CDLL(_lib.LIB_PATH)                     # an embedder maps the library itself, BEFORE torch
+first = runtimes()
+import torch
+both = runtimes()
+out = dict(links=links, first=first, both=both, torch_lib=os.path.join(os.path.dirname(torch.__file__), 'lib'), version=lib.pcrl_version())
+if {gpu}:
+    lib.pcrl_last_error.restype = ctypes.c_char_p
+    t, s_ = torch.zeros(1000, device='cuda'), torch.arange(1000, device='cuda', dtype=torch.float32)
+    rc = lib.pcrl_polyak_f32(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(s_.data_ptr()), ctypes.c_size_t(1000), ctypes.c_float(0.25),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    out.update(rc=rc, err=(lib.pcrl_last_error() or b'').decode(), ok=bool(torch.equal(t, 0.25 * s_)), torch_ok=float((s_ * 2).sum()) == 999000.0)
+print('ORDER_JSON ' + json.dumps(out))
+"""
+
+
+def _order_probe(gpu):
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", _ORDER_PROBE.format(root=ROOT, gpu=gpu)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("ORDER_JSON ")][0].split(" ", 1)[1])
+
+
+def test_mapping_the_library_before_torch_leaves_one_hip_runtime():
+    """libpcrl_hip.so searches pointcloud_rl_amd/_hiprt first (RPATH; symlinks to the runtime torch's wheel bundles, made by `make` /
+    _lib.ensure_runtime_links): mapped BEFORE `import torch` it brings in torch's own libamdhip64, and torch then re-uses that
+    mapping -- one HIP runtime in the process whatever the load order (round 3: /opt/rocm's came first and torch added a second)."""
+    d = _order_probe(gpu=False)
+    assert d["links"] and d["version"] >= 100
+    assert len(d["first"]) == 1 and d["first"][0].startswith(d["torch_lib"]), d
+    assert d["both"] == d["first"], d
+
+
+@pytest.mark.gpu
+def test_library_mapped_before_torch_still_launches(cuda):
+    d = _order_probe(gpu=True)
+    assert d["both"] == d["first"] and len(d["first"]) == 1, d
+    assert d["rc"] == 0 and d["ok"] and d["torch_ok"], d
