@@ -1,9 +1,10 @@
-"""Copies what tools/r3_measure.sh left under gpurun_out/r3m (and gpurun_out/pmc) into profiles/ (tracked), named per round.
-    python tools/fold_r3m.py [round prefix, default r03]"""
+"""Copies what tools/r3_measure.sh / tools/r4_measure.sh left under gpurun_out/<dir> (and gpurun_out/pmc) into profiles/ (tracked),
+named per round.    python tools/fold_r3m.py [round prefix, default r03] [source dir under gpurun_out, default r3m]"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
-src, dst = os.path.join(ROOT, "gpurun_out", "r3m"), os.path.join(ROOT, "profiles")
+srcdir = sys.argv[2] if len(sys.argv) > 2 else "r3m"
+src, dst = os.path.join(ROOT, "gpurun_out", srcdir), os.path.join(ROOT, "profiles")
 
 
 def last_json_line(path):
@@ -28,4 +29,12 @@ for wl in ("k1", "k2", "k3", "k4"):
 for a, b in (("pmc_summary.txt", f"{rnd}_pmc_encoder_kernels_raw.txt"), ("membound.md", f"{rnd}_membound_kernels.md")):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
-subprocess.call([sys.executable, os.path.join(ROOT, "tools", "fold_profiles.py"), "r3m", rnd])
+for name in sorted(os.listdir(src)) if os.path.isdir(src) else []:
+    if name.startswith("timeline_") and name.endswith(".txt"):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{rnd}_{name}"))
+for wl in ("k1", "k2", "k4"):
+    p = os.path.join(ROOT, "gpurun_out", "pmc", f"traffic_{wl}.json")
+    if os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(src):
+        shutil.copy(p, os.path.join(dst, f"{rnd}_pmc_traffic_{wl}.json"))
+if srcdir == "r3m":
+    subprocess.call([sys.executable, os.path.join(ROOT, "tools", "fold_profiles.py"), "r3m", rnd])
