@@ -1,4 +1,6 @@
 #!/bin/bash
+# (Record of a round-4 experiment: PCRL_BWD_WGRAD_PERSIST selected a persistent-accumulator wgrad kernel that measured slower and was
+# not kept -- DESIGN.md section 8; with the shipped library both settings run the same kernel.)
 set -u
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q -x -k "bwd or update_parameters or k2_full" 2>&1 | tail -3
