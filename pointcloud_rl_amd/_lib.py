@@ -115,16 +115,23 @@ def ensure_runtime_links():
     marker = os.path.join(RUNTIME_LINKS, "libamdhip64.so.7")
     if os.path.islink(marker) and os.path.realpath(marker) == os.path.realpath(os.path.join(src, "libamdhip64.so")):
         return RUNTIME_LINKS
-    os.makedirs(RUNTIME_LINKS, exist_ok=True)
-    for name in os.listdir(RUNTIME_LINKS):            # a stale set (another torch): start over
-        path = os.path.join(RUNTIME_LINKS, name)
-        if os.path.islink(path):
-            os.unlink(path)
+    # Built aside and moved into place in one rename: the ranks of a multi-GPU launch may all get here at once on a fresh machine,
+    # and a loader must never see a half-made directory.
+    import shutil
+    tmp = f"{RUNTIME_LINKS}.tmp.{os.getpid()}"
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
     for name in sorted(os.listdir(src)):
         if ".so" in name and os.path.isfile(os.path.join(src, name)):
-            os.symlink(os.path.join(src, name), os.path.join(RUNTIME_LINKS, name))
-    os.symlink(os.path.join(src, "libamdhip64.so"), marker)      # the name libpcrl_hip.so asks for (its NEEDED entry is the soname)
-    return RUNTIME_LINKS
+            os.symlink(os.path.join(src, name), os.path.join(tmp, name))
+    os.symlink(os.path.join(src, "libamdhip64.so"), os.path.join(tmp, "libamdhip64.so.7"))   # the name libpcrl_hip.so asks for (NEEDED = the soname)
+    if os.path.isdir(RUNTIME_LINKS):                  # a stale set (another torch installation): replace it
+        shutil.rmtree(RUNTIME_LINKS, ignore_errors=True)
+    try:
+        os.rename(tmp, RUNTIME_LINKS)
+    except OSError:                                   # another process won the race: its directory is as good as this one
+        shutil.rmtree(tmp, ignore_errors=True)
+    return RUNTIME_LINKS if os.path.islink(marker) else None
 
 
 def lib():
