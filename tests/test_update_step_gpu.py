@@ -371,3 +371,47 @@ def test_separate_backbones_repack_their_own_encoders(cuda):
         fresh.load_state_dict(e.state_dict())
         with torch.no_grad():
             assert torch.equal(e(obs), fresh(obs))
+
+
+@pytest.mark.parametrize("kind", ["sac", "drq"])
+def test_round4_launch_cuts_equal_the_launches_they_replace(cuda, monkeypatch, kind):
+    """Heads 1 024 wide (where the row-split tails, the backward tail, the first-layer fold and the riding column sums / temperature
+    apply): four updates with every round-4 fusion switched OFF (the round-3 launch sequence) against the default, same injected
+    noise.  The fusions only re-associate sums, so metrics agree to 2e-5 and parameters to 2e-6 (Adam's first steps: 1e-3 per step)."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A = 8, 64, 6
+    g = torch.Generator().manual_seed(3)
+    rows = B * (2 if kind == "drq" else 1)
+    eps = [[torch.randn(rows, A, generator=g), torch.randn(B, A, generator=g)] for _ in range(4)]
+    jit = [[torch.empty(rows, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)] for _ in range(4)]
+
+    def run(off):
+        for k in ("PCRL_TAIL_BWD", "PCRL_FOLD_Q0", "PCRL_ATTACH_COLSUM"):
+            monkeypatch.setenv(k, "0" if off else "1")
+        cfg = configs.drq_dmc(6, A, B, head_hidden=1024) if kind == "drq" else configs.sac_dmc(6, A, B, head_hidden=1024)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        mem = SyntheticReplay(B, N, A, seed=4, device=cuda)
+        rets = []
+        for u in range(1, 5):
+            agent.actor.head.noise_override = [e.to(cuda) for e in eps[u - 1][:2 if u % 2 == 0 else 1]]
+            if kind == "drq":
+                agent.obs_aug[0].noise_override = [j.to(cuda) for j in jit[u - 1]]
+            rets.append(agent.update_parameters(mem, u))
+        f = agent._fused
+        assert f is not None and f.tail_bwd == (not off) and f.fold_q0 == (not off)
+        assert f._fold_fits(rows, 2 if kind == "drq" else 1) == (not off)
+        return agent, rets
+
+    base, rets_b = run(off=True)
+    new, rets_n = run(off=False)
+    for rb, rn in zip(rets_b, rets_n):
+        assert rb.keys() == rn.keys()
+        for k in rb:
+            assert abs(rb[k] - rn[k]) <= 2e-5 * max(1.0, abs(rb[k])), (k, rb[k], rn[k])
+    for (n, p), (_, q) in zip(base.named_parameters(), new.named_parameters()):
+        err = (p - q).abs()
+        assert (err <= 2e-6).float().mean() >= 0.999 and err.max() <= 2.1e-3, (n, float(err.max()))
