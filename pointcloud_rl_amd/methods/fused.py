@@ -204,15 +204,19 @@ class FusedStep:
         # K3's 128-cloud share 0.669 -> 0.657 ms, K2's actor phase; K3's full batch stays on the GEMMs)
         _env_max = __import__("os").environ.get("PCRL_POLICY_TAIL_MAX")
         self.policy_tail_max = int(_env_max) if _env_max else 4096
-        self.policy_tail_max_split = int(_env_max) if _env_max else 16384
+        # forward tail: every row streams the 2A rows of the last layer (0.55 us per MB of them at M x 2A x 4 KB) against ~15.5 us for
+        # GEMM + head launch: 8 192 row-outputs (K3's 128-cloud share 5 632: 10.6 us; K2's actor phase 11 264: 25.6 us -> stays on the
+        # GEMM).  The backward tail replaces FOUR launches (~28 us) and still wins there: 16 384.
+        self.policy_tail_max_split = int(_env_max) if _env_max else 8192
+        self.policy_tail_bwd_max_split = int(_env_max) if _env_max else 16384
         self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
         self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
         self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
         self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
 
-    def _policy_tail_fits(self, M):
+    def _policy_tail_fits(self, M, bwd=False):
         split = self.H == 1024 and M <= 512        # the row-split kernels' domain (headtail.hip: PCRL_TAIL_SPLIT_MAX)
-        return M * 2 * self.A <= (self.policy_tail_max_split if split else self.policy_tail_max)
+        return M * 2 * self.A <= ((self.policy_tail_bwd_max_split if bwd else self.policy_tail_max_split) if split else self.policy_tail_max)
 
     def _buf(self, name, *shape, dtype=torch.float32):
         key = (name,) + shape
@@ -491,7 +495,7 @@ class FusedStep:
             head = a.actor.head
             dfeat = self._buf("pi_dfeat", Ma, 2 * A)
             dp_h1, dp_h2 = self._buf("pi_dh1", 1, Ma, H), self._buf("pi_dh2", 1, Ma, H)
-            if self.tails and self.tail_bwd and self._policy_tail_fits(Ma):
+            if self.tails and self.tail_bwd and self._policy_tail_fits(Ma, bwd=True):
                 # ---- the chain q tail -> dh1 GEMM -> ONE launch for [d_act GEMM, TanhGaussianHead backward, the policy's dh2 GEMM,
                 # actor_finalize] -> the policy's two remaining backward stages (its last layer's dW2 | db2 rides in the first) ----
                 launch_layers(qa_descs[1:2] if fold_a else qa_descs[:2])

@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q -x -k "tail or update_parameters or round4 or graph_replay" 2>&1 | tail -2
+one() { env $1 python bench.py $2 --warmup 30 --steps 300 --no-cpu-baseline --no-experimental --no-extra-workloads 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f steps/s  %.4f ms' % (d['value'], d['ms_per_step']), {k:(v['launches'], round(v['avg_ms']*1e3,1)) for k,v in d['kernels_ms'].items() if 'tail' in k or 'tanh' in k})"; }
+for rep in 1 2 3; do
+for cfg in "PCRL_POLICY_TAIL_MAX=16384" "PCRL_NONE=1"; do
+  echo "== $cfg (rep $rep)"
+  echo -n " k2      "; one "$cfg" "--workload k2"
+  echo -n " k3 b128 "; one "$cfg" "--workload k3 --batch 128"
+done
+done
