@@ -29,7 +29,14 @@
 //   reduce (fixed order over the clouds), finalize (dW2 = S - 1 v^T + 1 u^T - W2 G).
 #pragma once
 
+#ifndef PCRL_BWDG_MSPLIT
+#define PCRL_BWDG_MSPLIT 1    // q = Mc h1 on the bf16 matrix cores as a three-term split (round 4); 0: the fp32 MFMA chain of round 3
+#endif
+
 namespace pcrl {
+
+// floats of the Gram image the points kernel stages in LDS: the three bf16 term images (3 x C2^2 / 2) or the fp32 image (C2^2)
+__host__ __device__ constexpr int bwdg_m_lds_floats(int c2) { return PCRL_BWDG_MSPLIT ? 3 * c2 * c2 / 2 : c2 * c2; }
 
 struct GramExtra {      // what a cloud's pw row holds behind the reference-ordered gradients
     int C2;
@@ -127,7 +134,26 @@ __device__ __forceinline__ void gram_tile(const float* __restrict__ w2, float* _
         a2 = __builtin_fmaf(s_a[(c + 2) * 16 + i], s_b[(c + 2) * 16 + j], a2);
         a3 = __builtin_fmaf(s_a[(c + 3) * 16 + i], s_b[(c + 3) * 16 + j], a3);
     }
-    mimg[gram_image_index(kC2, 16 * ti + i, 16 * tj + j)] = (a0 + a1) + (a2 + a3);
+    const float v = (a0 + a1) + (a2 + a3);
+    mimg[gram_image_index(kC2, 16 * ti + i, 16 * tj + j)] = v;
+#if PCRL_BWDG_MSPLIT
+    // The same entry as three bf16 terms (truncation: hi + mid + lo = v exactly), in the A-operand order of v_mfma_f32_32x32x16_bf16 that
+    // dense_layer_split streams (the order of the pack kernel's split images: [row block][16-channel group][lane][8]): q = Mc h1 then
+    // costs 192 bf16 MFMAs of 32 cycles instead of 256 fp32 ones of 64, to ~3 x 2^-24 of |Mc||h1| per product (encoder_common.h).
+    {
+        const int row = 16 * ti + i, col = 16 * tj + j;
+        const int a = col >> 5, bb = col & 31, h = (bb >> 2) & 1, R = 16 * a + (bb & 3) + 4 * (bb >> 3);     // col = acc_chan(R, h)
+        const int e = ((((row >> 5) * (kC2 / 16) + (R >> 3)) * 64 + h * 32 + (row & 31)) << 3) + (R & 7);
+        unsigned short* img = reinterpret_cast<unsigned short*>(mimg + kC2 * kC2 + kC2);
+        float x = v;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned top = f2u(x) & 0xFFFF0000u;
+            img[k * kC2 * kC2 + e] = (unsigned short)(top >> 16);
+            x = x - u2f(top);
+        }
+    }
+#endif
 }
 
 template <int C1, int kC2, int kC3>
@@ -296,11 +322,15 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
     float* s_w0 = s_b0 + C1;
     float* s_sv = s_w0 + MB1 * T0 * 64;                                            // [kC2] column sums of W2
     float* s_m = s_sv + kC2;                                                       // [kC2 * kC2] M image
-    float* s_tr = s_m + kC2 * kC2 + (threadIdx.x >> 6) * kTrFloats;                // this wave's transposition scratch
+    float* s_tr = s_m + bwdg_m_lds_floats(kC2) + (threadIdx.x >> 6) * kTrFloats;   // this wave's transposition scratch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     {
+#if PCRL_BWDG_MSPLIT
+        stage_to_lds<64 * NW, 3 * kC2 * kC2 / 8>(reinterpret_cast<f32x4*>(s_m), reinterpret_cast<const f32x4*>(p.mimg + kC2 * kC2 + kC2), tid);
+#else
         stage_to_lds<64 * NW, kC2 * kC2 / 4>(reinterpret_cast<f32x4*>(s_m), reinterpret_cast<const f32x4*>(p.mimg), tid);
+#endif
         for (int i = tid; i < kC2; i += 64 * NW) s_sv[i] = p.mimg[kC2 * kC2 + i];
         for (int i = tid; i < MB1 * T0 * 64; i += 64 * NW) s_w0[i] = p.packed[L.w0() + i];
         for (int i = tid; i < C1; i += 64 * NW) s_b0[i] = p.packed[L.b0() + i];
@@ -469,9 +499,15 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
         PCRL_GSTAMP(4);
         // ---- q = Mc h1 (Mc = M - s s^T / C3, the centred Gram image: q = M h1 - mu s); var = h1.q / C3 -------------------------------
         f32x16 q[MB2];
+#if PCRL_BWDG_MSPLIT
+        dense_layer_split<MB2, kC2 / 16>(
+            q, [&](int k, int mb, int g) { return s_mv[k * (kC2 * kC2 / 8) + (mb * (kC2 / 16) + g) * 64 + lane]; },
+            [&](int t) { return a1[t >> 4][t & 15]; });
+#else
         dense_layer_mfma<MB2, kC2 / 8, 2>(
             q, [&](int mb, int tq) { return s_mv[(mb * (kC2 / 8) + tq) * 64 + lane]; },
             [&](int t) { return a1[t >> 4][t & 15]; });
+#endif
         float rstd2;
         {
             float pe = 0.0f, lo, hi;
@@ -1047,7 +1083,7 @@ __global__ __launch_bounds__(256) void encoder_bwdg_finish_kernel(const float* _
 
 static size_t bwdg_lds_bytes_points(int T0, int C1, int kC2, int kC3) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)(kMaxTileModeClouds + 8) +
-           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + kC2 + (size_t)kC2 * kC2 + 4 * 8 * 33 * 4);
+           sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + kC2 + (size_t)bwdg_m_lds_floats(kC2) + 4 * 8 * 33 * 4);
 }
 
 struct BwdgWorkspace {
@@ -1072,7 +1108,7 @@ static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     w.n1part = al(w.chc + sizeof(float) * (size_t)B * kC3);
     w.gvu = al(w.n1part + sizeof(float) * (size_t)B * bwdg_tpc(kC3) * kC2 * 2);
     w.mimg = al(w.gvu + sizeof(float) * (size_t)GX.total());
-    w.total = al(w.mimg + sizeof(float) * ((size_t)kC2 * kC2 + kC2));
+    w.total = al(w.mimg + sizeof(float) * ((size_t)kC2 * kC2 + kC2 + 3 * (size_t)kC2 * kC2 / 2));     // fp32 image, s, three bf16 term images
     return w;
 }
 
