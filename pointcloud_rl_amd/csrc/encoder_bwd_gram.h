@@ -29,6 +29,9 @@
 //   reduce (fixed order over the clouds), finalize (dW2 = S - 1 v^T + 1 u^T - W2 G).
 #pragma once
 
+#ifndef PCRL_BWDG_DH0SPLIT
+#define PCRL_BWDG_DH0SPLIT 1  // dH0 = W1^T dz1 as a three-term bf16 split in the exact-fp32 mode too (K1 stand-alone 138.5 -> 135.3 us)
+#endif
 #ifndef PCRL_BWDG_MSPLIT
 #define PCRL_BWDG_MSPLIT 1    // q = Mc h1 on the bf16 matrix cores as a three-term split (round 4); 0: the fp32 MFMA chain of round 3
 #endif
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(64 * kBwdgWaves, 1) void encoder_bwdg_points_kernel
         PCRL_GSTAMP(7);
         // ---- dH0 = W1^T dz1 ; ReLU backward ----------------------------------------------------
         f32x16 d0[MB1];
-        if (SPLIT)
+        if (SPLIT || PCRL_BWDG_DH0SPLIT)      // a purely linear layer (no decision depends on it): three-term bf16 split in either mode
             dense_layer_split<MB1, kC2 / 16>(
                 d0, [&](int k, int mb, int g) { return buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1ts(k) + (mb * (kC2 / 16) + g) * 256)); },
                 [&](int t) { return q[t >> 4][t & 15]; });
