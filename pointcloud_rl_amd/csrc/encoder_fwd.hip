@@ -37,7 +37,21 @@ struct HeadParams {
 // as floats at s_val[2 c] (the low words of the max-pool keys, which the caller has just read out) and may use s_val[2 f + 1]
 // (the high words) for y.  Fixed order: lane l sums channels l, l + 64, ... then a DPP/swizzle butterfly; same arithmetic as
 // layernorm_rows_fwd_kernel afterwards.  Must be entered by all threads; ends with every output written.
-__device__ __forceinline__ void feature_head_epilogue(const HeadParams& h, int cloud, int C3, float* s_val, int tid, int nthreads) {
+constexpr int kHeadFC = 8;
+__device__ __forceinline__ void feature_head_load_weights(const HeadParams& h, int C3, int f0, int lane, float (&wv)[kHeadFC][4]) {
+#pragma unroll
+    for (int k = 0; k < kHeadFC; ++k) {
+        const int f = f0 + k < h.F ? f0 + k : h.F - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[k][j] = lane + 64 * j < C3 ? h.weight[(long long)f * C3 + lane + 64 * j] : 0.0f;
+    }
+}
+
+// `first`: the weights of the wave's FIRST chunk of features (f0 = 8 wave), fetched by the caller before it had the pooled values
+// (encoder_merge_head_kernel: under the partial keys' round trip), or NULL.
+template <bool HAS_FIRST>
+__device__ __forceinline__ void feature_head_epilogue_t(const HeadParams& h, int cloud, int C3, float* s_val, int tid, int nthreads,
+                                                        const float (&first)[kHeadFC][4]) {
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
     // wave 0's LayerNorm parameters are fetched now, under the dot products' loads
     float gam[4] = {0.f, 0.f, 0.f, 0.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
@@ -50,18 +64,20 @@ __device__ __forceinline__ void feature_head_epilogue(const HeadParams& h, int c
     {
         // a wave takes eight consecutive features at a time: their 32 weight loads per lane are all in flight together (one
         // feature after the other paid an L2 round trip each: +10 us per cloud), then eight butterflies advance side by side
-        constexpr int FC = 8;
+        constexpr int FC = kHeadFC;
         float pv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv[j] = lane + 64 * j < C3 ? s_val[2 * (lane + 64 * j)] : 0.0f;
         for (int f0 = wave * FC; f0 < h.F; f0 += nwaves * FC) {
             float wv[FC][4];
             const float bias_l = (lane < FC && f0 + lane < h.F) ? h.bias[f0 + lane] : 0.0f;
+            if (HAS_FIRST && f0 == wave * FC) {
 #pragma unroll
-            for (int k = 0; k < FC; ++k) {
-                const int f = f0 + k < h.F ? f0 + k : h.F - 1;
+                for (int k = 0; k < FC; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wv[k][j] = lane + 64 * j < C3 ? h.weight[(long long)f * C3 + lane + 64 * j] : 0.0f;
+                    for (int j = 0; j < 4; ++j) wv[k][j] = first[k][j];
+            } else {
+                feature_head_load_weights(h, C3, f0, lane, wv);
             }
             float acc[FC];
 #pragma unroll
@@ -115,6 +131,11 @@ __device__ __forceinline__ void feature_head_epilogue(const HeadParams& h, int c
         if (rg.cat_src[c])
             for (int f = lane; f < rg.cat_n[c]; f += 64)
                 rg.cat_dst[c][(long long)row * rg.cat_ldd[c] + f] = rg.cat_src[c][(long long)(row / rg.cat_div[c]) * rg.cat_lds[c] + f];
+}
+
+__device__ __forceinline__ void feature_head_epilogue(const HeadParams& h, int cloud, int C3, float* s_val, int tid, int nthreads) {
+    const float none[kHeadFC][4] = {};
+    feature_head_epilogue_t<false>(h, cloud, C3, s_val, tid, nthreads, none);
 }
 
 struct FwdParams {
@@ -582,15 +603,24 @@ __global__ void encoder_merge_kernel(const unsigned long long* __restrict__ part
 }
 
 // The same merge for launches with a feature head: one workgroup per cloud (thread c owns channel c), then the head.
-__global__ __launch_bounds__(256) void encoder_merge_head_kernel(const unsigned long long* __restrict__ partial, int S, int C3,
-                                                                 float* __restrict__ pooled, int* __restrict__ argmax, const HeadParams head) {
+// NT threads: 256 without a feature head; 1 024 with one, so that every wave has ONE chunk of eight features (F <= 128) whose weights
+// it requests first thing -- they do not depend on the keys -- and the keys arrive eight segments at a time instead of one by one.
+template <int NT>
+__global__ __launch_bounds__(NT) void encoder_merge_head_kernel(const unsigned long long* __restrict__ partial, int S, int C3,
+                                                                float* __restrict__ pooled, int* __restrict__ argmax, const HeadParams head) {
     __shared__ float s_val[2 * 256];
     const int b = blockIdx.x, c = threadIdx.x;
+    float first[kHeadFC][4];
+    const bool early = head.weight != nullptr && (int)(threadIdx.x >> 6) * kHeadFC < head.F;
+    if (early) feature_head_load_weights(head, C3, (int)(threadIdx.x >> 6) * kHeadFC, threadIdx.x & 63, first);
     if (c < C3) {
         unsigned long long key = 0ull;
-        for (int s = 0; s < S; ++s) {
-            const unsigned long long k = partial[((long long)b * S + s) * C3 + c];
-            key = k > key ? k : key;
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            unsigned long long k[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) k[i] = partial[((long long)b * S + min(s0 + i, S - 1)) * C3 + c];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) key = k[i] > key ? k[i] : key;
         }
         unsigned vb = (unsigned)(key >> 32);
         if (vb > 0x7F800000u) vb = 0x7FC00000u;
@@ -598,7 +628,8 @@ __global__ __launch_bounds__(256) void encoder_merge_head_kernel(const unsigned 
         argmax[(long long)b * C3 + c] = (int)~(unsigned)key;
         s_val[2 * c] = u2f(vb);
     }
-    feature_head_epilogue(head, b, C3, s_val, threadIdx.x, 256);
+    if (head.weight) feature_head_epilogue_t<true>(head, b, C3, s_val, threadIdx.x, NT, first);    // (a wave without a first chunk has no chunk at all)
+    else feature_head_epilogue(head, b, C3, s_val, threadIdx.x, NT);
 }
 
 // Column-gather jobs riding on the pack launch (pcrl_encoder_pack_attach_cols): columns [col0, col0 + ncols) of `heads` weight
@@ -961,7 +992,9 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
     if (p.S > 1 && head) {
-        hipLaunchKernelGGL(encoder_merge_head_kernel, dim3(p.cl.B), dim3(256), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
+        static const int merge_nt = [] { const char* e = getenv("PCRL_MERGE_NT"); return e ? atoi(e) : 1024; }();
+        if (p.head.weight && merge_nt == 1024) hipLaunchKernelGGL(encoder_merge_head_kernel<1024>, dim3(p.cl.B), dim3(1024), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
+        else hipLaunchKernelGGL(encoder_merge_head_kernel<256>, dim3(p.cl.B), dim3(256), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
         PCRL_CHECK_LAUNCH("encoder_merge_head_kernel");
     } else if (p.S > 1) {
         const long long n = (long long)p.cl.B * w->c3;

@@ -564,6 +564,9 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_kernel(const PolicyTailPa
 
 // policy_tail_bwd_kernel for small batches with H = 1024: one row per workgroup, a quarter of the hidden vector per wave (see
 // policy_tail_fwd_split_kernel); every wave repeats the tiny TanhGaussianHead arithmetic so that one barrier is enough.
+// A8 = ceil(A / 8) when all operand pieces of a phase are requested at once (8 A8 rows of both heads' action columns, then 16 A8 rows of
+// w2 -- the second batch is issued before the barrier, under the TanhGaussianHead arithmetic); 0 = the loops, for A > 24.
+template <int A8>
 __global__ __launch_bounds__(256) void policy_tail_bwd_split_kernel(const PolicyTailBwdParams p) {
     __shared__ float s_part[4][32];
     __shared__ float s_df[4][64];
@@ -574,31 +577,72 @@ __global__ __launch_bounds__(256) void policy_tail_bwd_split_kernel(const Policy
     }
     const int m = blockIdx.x;
     const int col = 256 * wave + 4 * lane;
+    constexpr int RA = A8 > 0 ? 8 * A8 : 1, RW = A8 > 0 ? 16 * A8 : 1;
+    f32x4 w2v[RW];
+    f32x4 hv;
     {
         f32x4 dv[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) dv[h] = *reinterpret_cast<const f32x4*>(p.dh1 + h * p.dh1_hs + (long long)m * p.H + col);
-        for (int j0 = 0; j0 < p.A; j0 += 16) {
-            float v[16];
+        if constexpr (A8 > 0) {
+            f32x4 wa[2][RA];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float s = 0.0f;
-                if (j0 + k < p.A) {
+            for (int k = 0; k < RA; ++k)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w0a + h * p.w0a_hs + (long long)(j0 + k) * p.H + col);
+                for (int h = 0; h < 2; ++h)
+                    wa[h][k] = *reinterpret_cast<const f32x4*>(p.w0a + h * p.w0a_hs + (long long)min(k, p.A - 1) * p.H + col);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s = __builtin_fmaf(dv[h][e], wv[e], s);
+            for (int j0 = 0; j0 < RA; j0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float s = 0.0f;
+                    if (j0 + k < RA) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(dv[h][e], wa[h][j0 + k < RA ? j0 + k : 0][e], s);
                     }
+                    v[k] = s;
                 }
-                v[k] = s;
-            }
-            allreduce_add32_x16(v);
+                allreduce_add32_x16(v);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                float lo, hi;
-                both_halves(v[k], lo, hi);
-                if (lane == 0 && j0 + k < p.A) s_part[wave][j0 + k] = lo + hi;
+                for (int k = 0; k < 16; ++k) {
+                    float lo, hi;
+                    both_halves(v[k], lo, hi);
+                    if (lane == 0 && j0 + k < p.A) s_part[wave][j0 + k] = lo + hi;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the second phase's operands: nothing below depends on them until the last loop
+#pragma unroll
+            for (int n = 0; n < RW; ++n) w2v[n] = *reinterpret_cast<const f32x4*>(p.w2 + (long long)min(n, 2 * p.A - 1) * p.H + col);
+            hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)m * p.H + col);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            for (int j0 = 0; j0 < p.A; j0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float s = 0.0f;
+                    if (j0 + k < p.A) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w0a + h * p.w0a_hs + (long long)(j0 + k) * p.H + col);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(dv[h][e], wv[e], s);
+                        }
+                    }
+                    v[k] = s;
+                }
+                allreduce_add32_x16(v);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    float lo, hi;
+                    both_halves(v[k], lo, hi);
+                    if (lane == 0 && j0 + k < p.A) s_part[wave][j0 + k] = lo + hi;
+                }
             }
         }
     }
@@ -623,13 +667,24 @@ __global__ __launch_bounds__(256) void policy_tail_bwd_split_kernel(const Policy
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     f32x4 acc = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int n = 0; n < 2 * p.A; ++n) {
-        const float g = s_df[wave][n];
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + col);
+    if constexpr (A8 > 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, wv[e], acc[e]);
+        for (int n = 0; n < RW; ++n) {
+            if (n < 2 * p.A) {
+                const float g = s_df[wave][n];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, w2v[n][e], acc[e]);
+            }
+        }
+    } else {
+        for (int n = 0; n < 2 * p.A; ++n) {
+            const float g = s_df[wave][n];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, wv[e], acc[e]);
+        }
+        hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)m * p.H + col);
     }
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)m * p.H + col);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = hv[e] > 0.0f ? acc[e] : 0.0f;
@@ -639,6 +694,10 @@ __global__ __launch_bounds__(256) void policy_tail_bwd_split_kernel(const Policy
 // The same head for SMALL batches with H = 1024: ONE row per workgroup, its four waves take a quarter of the hidden vector each
 // (one 1 KB piece of h2 and of every w2 row per wave instead of four: the dependent-load chain of a wave is 4x shorter and M
 // workgroups instead of M / 4 spread over the chip), partial dot products meet in LDS and are added in wave order.
+// G = groups of sixteen outputs whose w2 pieces are ALL requested before the first dot product (G * 16 >= 2 A; 64 registers per group):
+// the groups were G dependent L2 round trips, one behind the other, in a kernel that is nothing but latency (A = 22: 16.5 us for 23 MFLOP).
+// G = 0: the loop, one group in flight (2 A > 48).  Same sums in the same order either way.
+template <int G>
 __global__ __launch_bounds__(256) void policy_tail_fwd_split_kernel(const PolicyTailParams p) {
     __shared__ float s_part[4][64];
     __shared__ float s_feat[64];
@@ -646,23 +705,65 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_split_kernel(const Policy
     const int b = blockIdx.x;
     const f32x4 hv = *reinterpret_cast<const f32x4*>(p.h2 + (long long)b * p.H + 256 * wave + 4 * lane);
     const int n_out = 2 * p.A;
-    for (int n0 = 0; n0 < n_out; n0 += 16) {
-        float v[16];
+    // the fold's operands (G = 1, i.e. A <= 8, two heads): requested with everything else instead of 2 A dependent round trips at the end
+    constexpr int FJ = G == 1 ? 8 : 1;
+    f32x4 fw[2][FJ], fpre[2];
+    const bool fold_early = G == 1 && p.fold_h1 && p.fold_heads <= 2;
+    if (fold_early) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int n = min(n0 + k, n_out - 1);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + 256 * wave + 4 * lane);
-            float s = 0.0f;
+        for (int h = 0; h < 2; ++h) {
+            const int hh = min(h, p.fold_heads - 1);
+            fpre[h] = *reinterpret_cast<const f32x4*>(p.fold_pre + hh * p.fold_pre_hs + (long long)b * p.H + 256 * wave + 4 * lane);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_fmaf(hv[e], wv[e], s);
-            v[k] = s;
+            for (int j = 0; j < FJ; ++j)
+                fw[h][j] = *reinterpret_cast<const f32x4*>(p.fold_w0a + hh * p.fold_w0a_hs + (long long)min(j, p.A - 1) * p.H + 256 * wave + 4 * lane);
         }
-        allreduce_add32_x16(v);
+    }
+    if constexpr (G > 0) {
+        f32x4 wv[G][16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            float lo, hi;
-            both_halves(v[k], lo, hi);
-            if (lane == 0 && n0 + k < n_out) s_part[wave][n0 + k] = lo + hi;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                wv[g][k] = *reinterpret_cast<const f32x4*>(p.w2 + (long long)min(16 * g + k, n_out - 1) * p.H + 256 * wave + 4 * lane);
+        __builtin_amdgcn_sched_barrier(0);      // the scheduler would sink every load to its first use ("operand rings are pinned")
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_fmaf(hv[e], wv[g][k][e], s);
+                v[k] = s;
+            }
+            allreduce_add32_x16(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float lo, hi;
+                both_halves(v[k], lo, hi);
+                if (lane == 0 && 16 * g + k < n_out) s_part[wave][16 * g + k] = lo + hi;
+            }
+        }
+    } else {
+        for (int n0 = 0; n0 < n_out; n0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int n = min(n0 + k, n_out - 1);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(p.w2 + (long long)n * p.H + 256 * wave + 4 * lane);
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_fmaf(hv[e], wv[e], s);
+                v[k] = s;
+            }
+            allreduce_add32_x16(v);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float lo, hi;
+                both_halves(v[k], lo, hi);
+                if (lane == 0 && n0 + k < n_out) s_part[wave][n0 + k] = lo + hi;
+            }
         }
     }
     __syncthreads();
@@ -699,6 +800,25 @@ __global__ __launch_bounds__(256) void policy_tail_fwd_split_kernel(const Policy
     __syncthreads();
     // ---- the Q heads' first layer for this row, a quarter of the hidden vector per wave ----
     const int col = 256 * wave + 4 * lane;
+    if (fold_early) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h >= p.fold_heads) break;
+            f32x4 acc = fpre[h];
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                if (j < p.A) {
+                    const float a = s_act[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(a, fw[h][j][e], acc[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = acc[e] > 0.0f ? acc[e] : 0.0f;
+            *reinterpret_cast<f32x4*>(p.fold_h1 + h * p.fold_h1_hs + (long long)b * p.H + col) = acc;
+        }
+        return;
+    }
     for (int h = 0; h < p.fold_heads; ++h) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(p.fold_pre + h * p.fold_pre_hs + (long long)b * p.H + col);
         for (int j = 0; j < p.A; ++j) {
@@ -820,7 +940,13 @@ extern "C" int pcrl_policy_tail_bwd_f32(const float* dh1, int64_t dh1_head_strid
     hipStream_t st = (hipStream_t)stream;
     static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
     if (H == 1024 && M <= split_max && A <= 32) {
-        hipLaunchKernelGGL(policy_tail_bwd_split_kernel, dim3(M + (p.fin_on ? 1 : 0)), dim3(256), 0, st, p);
+        static const bool prefetch = [] { const char* e = getenv("PCRL_TAIL_PREFETCH"); return !e || atoi(e) != 0; }();
+        const dim3 g(M + (p.fin_on ? 1 : 0));
+        const int a8 = prefetch ? (A + 7) / 8 : 0;
+        if (a8 == 1) hipLaunchKernelGGL(policy_tail_bwd_split_kernel<1>, g, dim3(256), 0, st, p);
+        else if (a8 == 2) hipLaunchKernelGGL(policy_tail_bwd_split_kernel<2>, g, dim3(256), 0, st, p);
+        else if (a8 == 3) hipLaunchKernelGGL(policy_tail_bwd_split_kernel<3>, g, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(policy_tail_bwd_split_kernel<0>, g, dim3(256), 0, st, p);
         PCRL_CHECK_LAUNCH("policy_tail_bwd_split_kernel");
         return PCRL_OK;
     }
@@ -890,7 +1016,12 @@ static int policy_tail_fwd_impl(const float* h2, int32_t M, int32_t H, const flo
     if (fold_h1 && !(H == 1024 && M <= split_max && A <= 32))
         return fail(PCRL_E_ARG, "policy tail fold: built for H = 1024, M <= %d, A <= 32 (got H=%d M=%d A=%d)", split_max, H, M, A);
     if (H == 1024 && M <= split_max) {             // small batch: one row per workgroup, a quarter of the hidden vector per wave
-        hipLaunchKernelGGL(policy_tail_fwd_split_kernel, dim3(M), dim3(256), 0, st, p);
+        static const bool prefetch = [] { const char* e = getenv("PCRL_TAIL_PREFETCH"); return !e || atoi(e) != 0; }();
+        const int groups = (2 * A + 15) / 16;
+        if (prefetch && groups == 1) hipLaunchKernelGGL(policy_tail_fwd_split_kernel<1>, dim3(M), dim3(256), 0, st, p);
+        else if (prefetch && groups == 2) hipLaunchKernelGGL(policy_tail_fwd_split_kernel<2>, dim3(M), dim3(256), 0, st, p);
+        else if (prefetch && groups == 3) hipLaunchKernelGGL(policy_tail_fwd_split_kernel<3>, dim3(M), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(policy_tail_fwd_split_kernel<0>, dim3(M), dim3(256), 0, st, p);
         PCRL_CHECK_LAUNCH("policy_tail_fwd_split_kernel");
         return PCRL_OK;
     }

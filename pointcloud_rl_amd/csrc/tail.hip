@@ -214,19 +214,34 @@ struct ScalarListParams {
     float* host_out;      // optional pinned host mirror of the n values (slots pre-filled with 0xFFFFFFFF by the host)
 };
 __global__ __launch_bounds__(256) void gather_scalars_kernel(const ScalarListParams p) {
-    __shared__ float s_part[4];
-    for (int f = 0; f < p.n_fin; ++f) {
-        // thread t sums partial[t], partial[t + 256], ... then a fixed-order tree (the order gradnorm_finalize_kernel uses)
-        float s = 0.0f;
-        for (int i = threadIdx.x; i < p.n_partial[f]; i += 256) s += p.partial[f][i];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (p.norm[f]) p.norm[f][0] = __builtin_sqrtf((s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
-            p.step[f][0] += 1;
+    // The partials were written by the previous launch on every XCD: each load is a miss.  All of them (every optimizer's, eight per
+    // thread at a time) are requested before the first sum; thread t still adds partial[t], partial[t + 256], ... in that order, then the
+    // fixed-order tree gradnorm_finalize_kernel uses.
+    __shared__ float s_part[kMaxFinalize][4];
+    float s[kMaxFinalize];
+#pragma unroll
+    for (int f = 0; f < kMaxFinalize; ++f) {
+        s[f] = 0.0f;
+        if (f < p.n_fin) {
+            const int n = p.n_partial[f];
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = threadIdx.x + 256 * k; v[k] = i < n ? p.partial[f][i] : 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if ((int)threadIdx.x + 256 * k < n) s[f] += v[k];
+            for (int i = threadIdx.x + 2048; i < n; i += 256) s[f] += p.partial[f][i];
         }
+    }
+#pragma unroll
+    for (int f = 0; f < kMaxFinalize; ++f) {
+        for (int off = 32; off > 0; off >>= 1) s[f] += __shfl_down(s[f], off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = s[f];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.n_fin) {
+        const int f = threadIdx.x;
+        if (p.norm[f]) p.norm[f][0] = __builtin_sqrtf((s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]));
+        p.step[f][0] += 1;
     }
     __threadfence_block();
     __syncthreads();

@@ -102,7 +102,8 @@ def test_q_tail_actor_and_finalize(cuda, M, H):
     np.testing.assert_allclose(st.cpu().numpy(), [aloss.item(), ent.item(), alpha_loss.item()], rtol=3e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("M,H,A,sampled", [(256, 1024, 6, False), (130, 1024, 22, False), (40, 256, 3, True)])
+@pytest.mark.parametrize("M,H,A,sampled", [(256, 1024, 6, False), (130, 1024, 22, False), (40, 256, 3, True), (64, 1024, 12, False),
+                                            (48, 1024, 30, False)])
 def test_policy_tail_fwd(cuda, M, H, A, sampled):
     from oracle import torch_ref
     from pointcloud_rl_amd import hip
@@ -130,7 +131,8 @@ def test_policy_tail_fwd(cuda, M, H, A, sampled):
     np.testing.assert_allclose(nlp.cpu().numpy(), nlp_ref[:, 0].numpy(), atol=2e-4, rtol=2e-5)
 
 
-@pytest.mark.parametrize("M,H,A,K0,col0", [(256, 1024, 6, 56, 50), (130, 512, 22, 220, 196), (7, 256, 3, 12, 8)])
+@pytest.mark.parametrize("M,H,A,K0,col0", [(256, 1024, 6, 56, 50), (130, 512, 22, 220, 196), (7, 256, 3, 12, 8), (130, 1024, 22, 220, 196),
+                                           (64, 1024, 12, 120, 100), (48, 1024, 30, 100, 64)])
 def test_policy_tail_bwd_equals_the_three_launches_it_replaces(cuda, M, H, A, K0, col0):
     """pcrl_policy_tail_bwd_f32 (+ the column gather riding on pcrl_q_tail_actor_cols_f32) against autograd of the same chain on the CPU
     -- d_action = sum_h dh1_h W0_h[:, action columns], TanhGaussianHead's backward, dh2 = (d_feat W2) (.) [h2 > 0] -- and against the
@@ -230,7 +232,7 @@ def test_colsum_jobs_attached_to_the_encoder_backward_equal_the_stand_alone_laun
     assert torch.equal(outs[2], outs[0])
 
 
-@pytest.mark.parametrize("M,A,K0,col0", [(256, 6, 56, 50), (40, 22, 220, 196)])
+@pytest.mark.parametrize("M,A,K0,col0", [(256, 6, 56, 50), (40, 22, 220, 196), (33, 3, 40, 30), (64, 12, 120, 100)])
 def test_policy_tail_fold_finishes_the_q_heads_first_layer(cuda, M, A, K0, col0):
     """pcrl_policy_tail_fwd_fold_f32: besides the policy head, h1[h] = relu(pre[h] + action W0_h[:, action columns]^T) for the Q heads --
     against relu([feature | state | action] W0^T + b0) computed whole in float64; the column image comes from a gather job riding on a
