@@ -135,6 +135,15 @@ int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, s
 typedef struct pcrl_col_gather { const float* src; int64_t head_stride; int32_t heads, rows, ld, col0, ncols, _pad; float* dst; } pcrl_col_gather;
 int pcrl_encoder_pack_attach_cols(const pcrl_col_gather* jobs, int32_t n);
 int pcrl_encoder_pack_flush_cols(void* stream);
+/* The same re-pack (with whatever column-gather jobs are attached at that moment) handed to this host thread's NEXT replay sampling
+ * launch (pcrl_replay_sample_gather / _state / pcrl_replay_gather) instead of a launch of its own: it runs as extra workgroups of that
+ * launch -- the step's first launch (ReplayMemory.sample, replay_buffer.py:297-322) reads nothing the pack writes, and the encoder
+ * forward that needs the image (pointnet.py:148-151) comes after it on the stream.  pcrl_encoder_pack_flush_pending launches a job no
+ * sampling launch has taken (the replay had nothing to gather, or was not this library's) and is a no-op otherwise; a second attach
+ * while one is pending is an error. */
+int pcrl_encoder_pack_attach_to_gather(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes);
+int pcrl_encoder_pack_flush_pending(void* stream);
+int pcrl_encoder_pack_drop_pending(void);     /* forget a pending job without running it (the caller's capture was aborted) */
 
 /* Fused PointNet encoder forward, fp32:
  *   preprocess (pointnet.py:49-73) -> [augment] -> conv0+ReLU -> conv1+LN1d+ReLU ->

@@ -17,6 +17,7 @@
 // followed by one ds_max_u64 on a {value bits, ~point index} key per winning lane, which
 // gives torch's first-index tie rule for free and merges the 8 waves of the workgroup.
 #include "encoder_common.h"
+#include "encoder_pack.h"
 
 namespace pcrl {
 
@@ -632,122 +633,7 @@ __global__ __launch_bounds__(NT) void encoder_merge_head_kernel(const unsigned l
     else feature_head_epilogue(head, b, C3, s_val, threadIdx.x, NT);
 }
 
-// Column-gather jobs riding on the pack launch (pcrl_encoder_pack_attach_cols): columns [col0, col0 + ncols) of `heads` weight
-// matrices src + h * head_stride [rows][ld] written as the compact image dst [heads][ncols][rows] -- the action columns of the Q heads'
-// first layer, which the policy tails contract row-wise (coalesced rows instead of 4-byte loads ld floats apart).
-struct ColGather { const float* src; long long head_stride; int heads, rows, ld, col0, ncols; float* dst; int blk_begin; };
-struct ColGatherList { ColGather job[2]; int n; };
-
-// Weights (reference state_dict layout) -> operand order.  One thread per packed float.
-__global__ void encoder_pack_kernel(pcrl_encoder_weights w, int T0, float* __restrict__ out, const ColGatherList cg, int main_blocks) {
-    if ((int)blockIdx.x >= main_blocks) {
-        const int blk = (int)blockIdx.x - main_blocks;
-        const ColGather& g = (cg.n > 1 && blk >= cg.job[1].blk_begin) ? cg.job[1] : cg.job[0];
-        const int per_head = g.ncols * g.rows;
-        const int e = (blk - g.blk_begin) * 256 + (int)threadIdx.x;
-        if (e < g.heads * per_head) {
-            const int h = e / per_head, r = e - h * per_head, j = r / g.rows, row = r - j * g.rows;
-            g.dst[e] = g.src[h * g.head_stride + (long long)row * g.ld + g.col0 + j];
-        }
-        return;
-    }
-    const PackedLayout L{T0, w.c1, w.c2, w.c3};
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.total()) return;
-    float v = 0.0f;
-    if (i < L.b0()) {                       // conv0: [mb][t][lane], natural k order, zero padded
-        const int e = i - L.w0(), ln = e & 63, t = (e >> 6) % T0, mb = (e >> 6) / T0;
-        const int row = 32 * mb + (ln & 31), k = 2 * t + (ln >> 5);
-        v = k < w.c_in ? w.w0[row * w.c_in + k] : 0.0f;
-    } else if (i < L.b0() + w.c1) {
-        v = w.b0[i - L.b0()];
-    } else if (i >= L.w1() && i < L.ln1()) { // conv1: [mb][tq][lane][4]
-        const int e = i - L.w1(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
-        const int TQ = w.c1 / 8, tq = q % TQ, mb = q / TQ;
-        v = w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(4 * tq + j, ln >> 5)];
-    } else if (i >= L.ln1() && i < L.ln1() + 2 * w.c2) {
-        const int e = i - L.ln1();
-        v = (e & 1) ? w.be1[e >> 1] : w.g1[e >> 1];
-    } else if (i >= L.w2() && i < L.ln2()) { // conv2: [mb][tq][lane][4]
-        const int e = i - L.w2(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
-        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
-        v = w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(4 * tq + j, ln >> 5)];
-    } else if (i >= L.ln2() && i < L.ln2() + 2 * w.c3) {
-        const int e = i - L.ln2();
-        v = (e & 1) ? w.be2[e >> 1] : w.g2[e >> 1];
-    } else if (i >= L.w2t() && i < L.w1t()) { // conv2 transposed (dX GEMM of the backward): rows = c2, k = c3
-        const int e = i - L.w2t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
-        const int TQ = w.c3 / 8, tq = q % TQ, mb = q / TQ;
-        v = w.w2[acc_chan(4 * tq + j, ln >> 5) * w.c2 + 32 * mb + (ln & 31)];
-    } else if (i >= L.w1t() && i < L.w1t() + w.c1 * w.c2) { // conv1 transposed: rows = c1, k = c2
-        const int e = i - L.w1t(), j = e & 3, ln = (e >> 2) & 63, q = e >> 8;
-        const int TQ = w.c2 / 8, tq = q % TQ, mb = q / TQ;
-        v = w.w1[acc_chan(4 * tq + j, ln >> 5) * w.c1 + 32 * mb + (ln & 31)];
-    } else if (i >= L.w1b() && i < L.w1b() + w.c1 * w.c2 / 2) {   // conv1, bf16: [mb][g][lane][8], two elements per slot
-        unsigned bits = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int e = 2 * (i - L.w1b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-            const int G = w.c1 / 16, g = q % G, mb = q / G;
-            bits |= bf16_rne_bits(w.w1[(32 * mb + (ln & 31)) * w.c1 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
-        }
-        v = u2f(bits);
-    } else if (i >= L.w2b() && i < L.w2b() + w.c2 * w.c3 / 2) {   // conv2, bf16
-        unsigned bits = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int e = 2 * (i - L.w2b()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-            const int G = w.c2 / 16, g = q % G, mb = q / G;
-            bits |= bf16_rne_bits(w.w2[(32 * mb + (ln & 31)) * w.c2 + acc_chan(8 * g + r, ln >> 5)]) << (16 * k);
-        }
-        v = u2f(bits);
-    } else if (i >= L.w2tb() && i < L.w2tb() + w.c2 * w.c3 / 2) {  // conv2 transposed, bf16: rows = c2, k = c3
-        unsigned bits = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int e = 2 * (i - L.w2tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-            const int G = w.c3 / 16, g = q % G, mb = q / G;
-            bits |= bf16_rne_bits(w.w2[acc_chan(8 * g + r, ln >> 5) * w.c2 + 32 * mb + (ln & 31)]) << (16 * k);
-        }
-        v = u2f(bits);
-    } else if (i >= L.w1tb() && i < L.w1tb() + w.c1 * w.c2 / 2) {  // conv1 transposed, bf16: rows = c1, k = c2
-        unsigned bits = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int e = 2 * (i - L.w1tb()) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-            const int G = w.c2 / 16, g = q % G, mb = q / G;
-            bits |= bf16_rne_bits(w.w1[acc_chan(8 * g + r, ln >> 5) * w.c1 + 32 * mb + (ln & 31)]) << (16 * k);
-        }
-        v = u2f(bits);
-    }
-    else {
-        // split images: three bf16 terms of every weight, same element order as the bf16 images
-        for (int layer = 1; layer <= 2; ++layer) {
-            const int in_c = layer == 1 ? w.c1 : w.c2;                   // the layer's input channels = row length of its weight
-            const int out_c = layer == 1 ? w.c2 : w.c3;
-            const int n_img = in_c * out_c / 2;
-            const float* src = layer == 1 ? w.w1 : w.w2;
-            for (int term = 0; term < 3; ++term) {
-                const int base = layer == 1 ? L.w1s(term) : L.w2s(term);         // forward: rows = outputs, contraction over inputs
-                const int base_t = layer == 1 ? L.w1ts(term) : L.w2ts(term);     // transposed: rows = inputs, contraction over outputs
-                if (i >= base && i < base + n_img) {
-                    unsigned bits = 0;
-                    for (int k = 0; k < 2; ++k) {
-                        const int e = 2 * (i - base) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-                        const int G = in_c / 16, g = q % G, mb = q / G;
-                        bits |= bf16_split_bits(src[(32 * mb + (ln & 31)) * in_c + acc_chan(8 * g + r, ln >> 5)], term) << (16 * k);
-                    }
-                    v = u2f(bits);
-                } else if (i >= base_t && i < base_t + n_img) {
-                    unsigned bits = 0;
-                    for (int k = 0; k < 2; ++k) {
-                        const int e = 2 * (i - base_t) + k, r = e & 7, ln = (e >> 3) & 63, q = e >> 9;
-                        const int G = out_c / 16, g = q % G, mb = q / G;
-                        bits |= bf16_split_bits(src[acc_chan(8 * g + r, ln >> 5) * in_c + 32 * mb + (ln & 31)], term) << (16 * k);
-                    }
-                    v = u2f(bits);
-                }
-            }
-        }
-    }
-    out[i] = v;
-}
+__global__ __launch_bounds__(256) void encoder_pack_kernel(const PackJob j) { encoder_pack_block(j, (int)blockIdx.x, (int)threadIdx.x); }
 
 int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, int expect_channels, CloudParams* out) {
     if (!clouds) return fail(PCRL_E_ARG, "clouds is NULL");
@@ -913,17 +799,55 @@ extern "C" int pcrl_encoder_pack_flush_cols(void* stream) {
     return PCRL_OK;
 }
 
-extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream) {
+// The pack launch's work as a job (consumes the attached column gathers).
+static int make_pack_job(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, PackJob* job) {
     if (!w || !packed) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
     if (packed_bytes < need) return fail(PCRL_E_WORKSPACE, "packed buffer %zu < %zu bytes", packed_bytes, need);
-    const int T0 = (w->c_in + 1) / 2;
     const int total = (int)(need / sizeof(float));
-    const ColGatherList l = t_colgather;       // attached column-gather jobs ride on this launch and are consumed by it
     const int extra = t_colgather.n ? t_colgather_blocks : 0;
-    t_colgather.n = 0; t_colgather_blocks = 0;
-    hipLaunchKernelGGL(encoder_pack_kernel, dim3((total + 255) / 256 + extra), dim3(256), 0, (hipStream_t)stream, *w, T0, (float*)packed, l, (total + 255) / 256);
+    *job = PackJob{*w, (w->c_in + 1) / 2, static_cast<float*>(packed), t_colgather, (total + 255) / 256, (total + 255) / 256 + extra};
+    t_colgather.n = 0; t_colgather_blocks = 0;       // attached column-gather jobs ride on this job and are consumed by it
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_weights_f32(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes, void* stream) {
+    PackJob job;
+    if (int rc = make_pack_job(w, packed, packed_bytes, &job)) return rc;
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3(job.total_blocks), dim3(256), 0, (hipStream_t)stream, job);
+    PCRL_CHECK_LAUNCH("encoder_pack_kernel");
+    return PCRL_OK;
+}
+
+// pcrl_encoder_pack_attach_to_gather: the same job, handed to this host thread's NEXT replay sampling launch
+static thread_local PackJob t_pending_pack = {};
+static thread_local bool t_pending_pack_on = false;
+
+bool pcrl::take_pending_pack(PackJob* job) {
+    if (!t_pending_pack_on) return false;
+    *job = t_pending_pack;
+    t_pending_pack_on = false;
+    return true;
+}
+
+extern "C" int pcrl_encoder_pack_attach_to_gather(const pcrl_encoder_weights* w, void* packed, size_t packed_bytes) {
+    if (t_pending_pack_on) return fail(PCRL_E_ARG, "a pack job is already pending: flush it first (pcrl_encoder_pack_flush_pending)");
+    PackJob job;
+    if (int rc = make_pack_job(w, packed, packed_bytes, &job)) return rc;
+    t_pending_pack = job; t_pending_pack_on = true;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_drop_pending(void) {
+    t_pending_pack_on = false;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_encoder_pack_flush_pending(void* stream) {
+    PackJob job;
+    if (!pcrl::take_pending_pack(&job)) return PCRL_OK;
+    hipLaunchKernelGGL(encoder_pack_kernel, dim3(job.total_blocks), dim3(256), 0, (hipStream_t)stream, job);
     PCRL_CHECK_LAUNCH("encoder_pack_kernel");
     return PCRL_OK;
 }

@@ -220,7 +220,19 @@ __global__ __launch_bounds__(1024) void q_tail_split_kernel(const QTailParams p)
     const bool live = m < p.M;
     const int mr = live ? m : p.M - 1;
     const int col = 256 * qw + 4 * lane;
-    const float alpha = expf(p.log_alpha[0]);
+    // every scalar the row needs after the barriers is requested now, with the operand pieces (behind a barrier each would be a
+    // round trip of its own: nlp was written by the previous launch, on another XCD)
+    const float log_alpha_v = p.log_alpha[0];
+    const float b2v[2] = {p.b2[0], p.b2[p.w_hs]};
+    float b2tv[2] = {0.0f, 0.0f}, nlp_v = 0.0f, rew_v = 0.0f;
+    bool done_v = false;
+    if (p.mode == 0) {
+        b2tv[0] = p.b2_t[0]; b2tv[1] = p.b2_t[p.w_t_hs];
+        rew_v = p.rewards[mr / p.rd_div];
+        done_v = !p.ignore_dones && p.dones[mr / p.rd_div] != 0;
+    }
+    nlp_v = p.nlp[mr];
+    const float alpha = expf(log_alpha_v);
     f32x4 hv[2], wv[2];
     {
         float v[16];
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(1024) void q_tail_split_kernel(const QTailParams p)
     __syncthreads();
     float q[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) q[h] = (((s_dot[row][0][h] + s_dot[row][1][h]) + s_dot[row][2][h]) + s_dot[row][3][h]) + p.b2[h * p.w_hs];
+    for (int h = 0; h < 2; ++h) q[h] = (((s_dot[row][0][h] + s_dot[row][1][h]) + s_dot[row][2][h]) + s_dot[row][3][h]) + b2v[h];
     const bool first = qw == 0 && lane == 0;       // one lane per row reports
     if (live && qw == 0 && lane < 2) p.q[(long long)m * p.ld_q + lane] = q[lane];
     float dqv[2];
@@ -261,11 +273,10 @@ __global__ __launch_bounds__(1024) void q_tail_split_kernel(const QTailParams p)
         float qn[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            qn[h] = (((s_dot[row][0][2 + h] + s_dot[row][1][2 + h]) + s_dot[row][2][2 + h]) + s_dot[row][3][2 + h]) + p.b2_t[h * p.w_t_hs];
-        const float mn = fminf(qn[0], qn[1]) + alpha * p.nlp[mr];
-        const int e = mr / p.rd_div;
-        const float r = p.rewards[e] * p.reward_scale;
-        const float y = p.ignore_dones ? r + p.gamma * mn : r + (1.0f - (p.dones[e] ? 1.0f : 0.0f)) * p.gamma * mn;
+            qn[h] = (((s_dot[row][0][2 + h] + s_dot[row][1][2 + h]) + s_dot[row][2][2 + h]) + s_dot[row][3][2 + h]) + b2tv[h];
+        const float mn = fminf(qn[0], qn[1]) + alpha * nlp_v;
+        const float r = rew_v * p.reward_scale;
+        const float y = p.ignore_dones ? r + p.gamma * mn : r + (1.0f - (done_v ? 1.0f : 0.0f)) * p.gamma * mn;
         if (first) s_y[row] = y;
         __syncthreads();
         float ybar = 0.0f;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(1024) void q_tail_split_kernel(const QTailParams p)
         if (live && first) { p.dq[(long long)m * p.ld_dq] = dqv[0]; p.dq[(long long)m * p.ld_dq + 1] = dqv[1]; }
         if (first) {
             s_st[row][0] = live ? q[arg] : 0.0f;
-            s_st[row][1] = live ? p.nlp[mr] : 0.0f;
+            s_st[row][1] = live ? nlp_v : 0.0f;
             s_st[row][2] = 0.0f; s_st[row][3] = 0.0f;
         }
         if (blockIdx.x == 0 && threadIdx.x == 0) p.d_neglogp[0] = -alpha / (float)p.M;

@@ -4,6 +4,7 @@
 // host->device copy of 2*B clouds per step (pyrl/env/replay_buffer.py:297-322; pyrl/utils/data/
 // dict_array.py:308-318; sac.py:104).  HBM-bound: row_bytes read + row_bytes written per sampled row.
 #include "common.h"
+#include "encoder_pack.h"
 
 namespace pcrl {
 
@@ -17,6 +18,7 @@ struct GatherParams {
     int* idx_out; unsigned size, seed_lo, seed_hi, draw_lo, draw_hi;
     // state != NULL: draw and size come from device memory ({draw, size, ticket, B row tickets}); the last workgroup advances draw
     unsigned long long* state;
+    int n_y;              // grid rows that gather (1 + number of large keys); rows beyond them run an attached encoder pack job
 };
 
 // Copies nbytes (any alignment) with the 256 threads of the workgroup; the aligned path keeps four 16-byte loads of a thread in
@@ -45,8 +47,13 @@ __device__ __forceinline__ void gather_copy_row(const unsigned char* src, unsign
 // dones, robot state ... -- a workgroup per (row, key) for 4-byte rows was most of the launch's workgroups), workgroup (b, y > 0) the
 // row of the y-th large key (the point-cloud tensors).
 constexpr long long kGatherSmall = 1024;
-__global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p, const int n_segs) {
+__global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p, const int n_segs, const PackJob pack) {
     const int b = blockIdx.x, seg = blockIdx.y;
+    if (seg >= p.n_y) {                 // the encoder's re-pack riding on this launch (pcrl_encoder_pack_attach_to_gather): reads no sampled row
+        const int blk = (seg - p.n_y) * (int)gridDim.x + b;
+        if (blk < pack.total_blocks) encoder_pack_block(pack, blk, (int)threadIdx.x);
+        return;
+    }
     long long row;
     if (p.idx) {
         row = p.idx[b];
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void replay_gather_kernel(const GatherParams p
             // tickets are device-scope atomics, and the plain stores below only have to be visible to the NEXT launch.)
             __syncthreads();
             if (threadIdx.x == 0) {
-                if (atomicAdd(p.state + 3 + b, 1ull) == (unsigned long long)gridDim.y - 1) {
+                if (atomicAdd(p.state + 3 + b, 1ull) == (unsigned long long)p.n_y - 1) {
                     p.state[3 + b] = 0ull;
                     if (atomicAdd(p.state + 2, 1ull) == (unsigned long long)gridDim.x - 1) {
                         p.state[2] = 0ull;
@@ -113,7 +120,10 @@ static int gather_launch(const pcrl_gather_seg* segs, int32_t n_segs, GatherPara
     }
     int n_large = 0;
     for (int i = 0; i < n_segs; ++i) n_large += segs[i].row_bytes >= kGatherSmall ? 1 : 0;
-    hipLaunchKernelGGL(replay_gather_kernel, dim3(p.B, 1 + n_large), dim3(256), 0, (hipStream_t)stream, p, n_segs);
+    p.n_y = 1 + n_large;
+    PackJob pack{};
+    const int pack_rows = take_pending_pack(&pack) ? (pack.total_blocks + p.B - 1) / p.B : 0;     // this thread's pending pack job, if any
+    hipLaunchKernelGGL(replay_gather_kernel, dim3(p.B, p.n_y + pack_rows), dim3(256), 0, (hipStream_t)stream, p, n_segs, pack);
     PCRL_CHECK_LAUNCH("replay_gather_kernel");
     return PCRL_OK;
 }

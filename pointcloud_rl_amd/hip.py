@@ -144,6 +144,22 @@ def encoder_pack_weights(ew, packed):
     check(lib().pcrl_encoder_pack_weights_f32(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size()), _stream()))
 
 
+def encoder_pack_attach_to_gather(ew, packed):
+    """The re-pack (with the column-gather jobs attached so far) rides on this thread's NEXT replay sampling launch
+    (pcrl_encoder_pack_attach_to_gather); follow the sampling launch with encoder_pack_flush_pending()."""
+    check(lib().pcrl_encoder_pack_attach_to_gather(ctypes.byref(ew), _ptr(packed), ctypes.c_size_t(packed.numel() * packed.element_size())))
+
+
+def encoder_pack_drop_pending():
+    """Forgets a pending pack job without running it (an aborted capture): the caller invalidates the image it stood for."""
+    check(lib().pcrl_encoder_pack_drop_pending())
+
+
+def encoder_pack_flush_pending():
+    """Launches a pack job no sampling launch has taken; no-op otherwise (pcrl_encoder_pack_flush_pending)."""
+    check(lib().pcrl_encoder_pack_flush_pending(_stream()))
+
+
 def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None,
                   point_index=None, color=None):
     """color: dict(order=[4 step ids in application order], factors=[brightness, contrast, saturation, hue] (None: skip),

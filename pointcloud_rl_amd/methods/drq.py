@@ -127,6 +127,9 @@ class DrQ(SAC):
         return (obs, next_obs, batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), dict(
             group=self.num_aug, repeat=self.num_aug, actor_obs=first_augmentation(obs, B, self.num_aug) if do_actor else None)
 
+    def _entry_shape(self):
+        return (self.batch_size * self.num_aug, self.num_aug) if not self.svea else (self.batch_size, 1)
+
     def update_parameters(self, memory, updates):
         """SAC's, with the jitter augmentations told where the step's device draw counter lives: a replay whose sampling is one
         device launch (`DeviceReplay.graph_sampling`) advances `state[0]` once per sample -- the Philox offset of every jitter

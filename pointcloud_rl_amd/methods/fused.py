@@ -213,6 +213,9 @@ class FusedStep:
         self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
         self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
         self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
+        # the critic phase's re-pack (+ the target heads' action-column image) as extra workgroups of the replay's sampling launch
+        self.entry_pack = __import__("os").environ.get("PCRL_ENTRY_PACK", "1") == "1"
+        self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
         split = self.H == 1024 and M <= 512        # the row-split kernels' domain (headtail.hip: PCRL_TAIL_SPLIT_MAX)
@@ -256,6 +259,24 @@ class FusedStep:
         head = hip.make_feature_head(fc.data[off[pre + "0.weight"]:], fc.data[off[pre + "0.bias"]:], fc.data[off[pre + "1.weight"]:],
                                      fc.data[off[pre + "1.bias"]:], F, self.a.encoder.final_mlp[1].eps, ranges)
         return head, out
+
+    def _target_cols_job(self, M):
+        a, A, H = self.a, self.A, self.H
+        w0a_t = self._buf("q_w0_action_cols_target", 2, A, H)
+        return w0a_t, (self.q.W(0, a._target_flat.data, -self.q_base), self.q.hs, 2, H, self.Din_q, self.F + self.S, A, w0a_t)
+
+    def attach_entry(self, M, group=1):
+        """Called by the agent right BEFORE the replay's sampling launch of a captured step (M rows, DrQ's group): what heads the critic
+        phase -- the encoder's re-pack and, with the first-layer fold, the image of the target heads' action columns -- is handed to that
+        launch as extra workgroups (pcrl_encoder_pack_attach_to_gather; it depends on nothing the sampling writes).  The caller follows
+        the sampling launch with `hip.encoder_pack_flush_pending()`."""
+        if not self.entry_pack:
+            return
+        if self._fold_fits(M, group):
+            hip.pack_attach_cols([self._target_cols_job(M)[1]])
+            self._entry_cols = (M, group)
+        # (an image that is current takes no job: the attached columns then wait for the critic phase's pack_flush_cols)
+        self.a.encoder.attach_pack_to_gather()
 
     def _fold_fits(self, M, group=1):
         """The Q heads' first layer finished inside the policy tail (pcrl_policy_tail_fwd_fold_f32): where the row-split tail runs."""
@@ -363,8 +384,10 @@ class FusedStep:
         fold_c = self._fold_fits(M, group)
         tgt = a._target_flat.data
         if fold_c:
-            w0a_t = self._buf("q_w0_action_cols_target", 2, A, H)
-            hip.pack_attach_cols([(self.q.W(0, tgt, -self.q_base), self.q.hs, 2, H, self.Din_q, F + S, A, w0a_t)])
+            w0a_t, job = self._target_cols_job(M)
+            if self._entry_cols != (M, group):       # (else: attach_entry() put it on the replay's sampling launch)
+                hip.pack_attach_cols([job])
+        self._entry_cols = None
         if both is not None:              # s and s' sit back to back (DeviceReplay's staging): one launch of 2 M clouds
             head, ((xhat, rstd), _) = self._feature_jobs([job_o(0), job_n(M)])
             pooled_all, argmax_all, _ = enc.encode_raw(both, head=head)

@@ -555,6 +555,10 @@ class SAC(BaseAgent):
     def _fused_args(self, batch, do_actor, polyak):
         return (batch["obs"], batch["next_obs"], batch["actions"], batch["rewards"], batch["dones"], do_actor, polyak), {}
 
+    def _entry_shape(self):
+        """(rows of the critic phase, group) of a step on `batch_size` samples: FusedStep.attach_entry's arguments."""
+        return self.batch_size, 1
+
     def _run_step(self, batch, updates, sampler=None):
         """batch: the sampled batch, or a callable `fetch(launch=True)` returning it -- then `sampler` is the replay it samples
         from, and when that replay's sampling is one host-free launch (`DeviceReplay.graph_sampling`) the launch becomes the
@@ -602,7 +606,19 @@ class SAC(BaseAgent):
             batch = self._to_static(staged if sampler is not None else fetch())
             if sampler is not None:
                 assert self._aliases_static(staged), "captured sampling must write the tensors the captured step reads"
-            pre = (lambda: sampler.launch_sample(self.batch_size)) if sampler is not None else None
+            pre = None
+            if sampler is not None:
+                def pre():
+                    # the critic phase's re-pack rides on the sampling launch (it reads nothing that launch writes)
+                    if self._fused is not None:
+                        self._fused.attach_entry(*self._entry_shape())
+                    try:
+                        sampler.launch_sample(self.batch_size)
+                    except Exception:
+                        hip.encoder_pack_drop_pending()
+                        self.encoder.invalidate_packed()
+                        raise
+                    hip.encoder_pack_flush_pending()       # no-op when the sampling launch took the job
             torch.cuda.synchronize()
             quiesce_before_capture()               # RCCL's watchdog must have no eager work left to poll while this thread captures
             self._graph_sampler[key] = sampler
@@ -669,6 +685,11 @@ class SAC(BaseAgent):
             t.calls, t._slot = c, sl
         if self._fused is not None:
             self._fused._forked = False
+            self._fused._entry_cols = None
+        # the aborted pass recorded its re-pack (and the job it may have handed to the sampling launch) into a graph that is thrown away
+        hip.encoder_pack_drop_pending()
+        for enc in {id(e): e for owners in self._packed_owners.values() for e in owners}.values():
+            enc.invalidate_packed()
 
     def _invalidate_packed_after_replay(self):
         """A replayed step updated the encoder weights through raw pointers (no autograd version bump) and re-packs only

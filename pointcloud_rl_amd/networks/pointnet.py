@@ -147,7 +147,7 @@ class PointNet(ExtendedModule):
         """Call after the weights were modified outside autograd's version tracking (fused optimizer)."""
         self._packed_key = None
 
-    def _weights_desc(self):
+    def _pack_if_stale(self, to_gather=False):
         params = self.conv.kernel_params()
         if not params[0].is_cuda:
             raise RuntimeError("pointcloud_rl_amd.PointNet runs on MI355X only: move the module to a CUDA/HIP device "
@@ -159,9 +159,22 @@ class PointNet(ExtendedModule):
             self._packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=params[0].device)
             self._packed_key = None
         if key != self._packed_key:
-            hip.encoder_pack_weights(ew, self._packed)
+            if to_gather:
+                hip.encoder_pack_attach_to_gather(ew, self._packed)
+            else:
+                hip.encoder_pack_weights(ew, self._packed)
             self._packed_key = key
-        return ew, self._packed
+            return ew, self._packed, True
+        return ew, self._packed, False
+
+    def _weights_desc(self):
+        return self._pack_if_stale()[:2]
+
+    def attach_pack_to_gather(self):
+        """The re-pack a forward would start with, handed to this thread's NEXT replay sampling launch instead (with the column-gather
+        jobs attached so far; `hip.encoder_pack_attach_to_gather`): True if the image was stale and a job is now pending -- the caller
+        issues the sampling launch and then `hip.encoder_pack_flush_pending()`; False if the image is current (nothing pending)."""
+        return self._pack_if_stale(to_gather=True)[2]
 
     def _workspace(self, kind, B=None):
         """Scratch is cached per kind and grown on demand (never shrunk)."""

@@ -468,18 +468,81 @@ def test_state_driven_sampling_launch_equals_the_explicit_one_and_counts_itself(
     assert mem.state[:3].tolist() == [6, 70, 0] and int(mem.state[3:].abs().sum()) == 0 and mem.draws == 6
 
 
-def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda):
+def test_pack_job_rides_on_the_replay_sampling_launch(cuda):
+    """pcrl_encoder_pack_attach_to_gather: the encoder's re-pack and the column-gather jobs attached to it run as extra workgroups of the
+    next replay sampling launch -- same image, same columns, same sampled rows as the separate launches; the flush afterwards is a no-op;
+    a job no sampling launch takes is run by the flush; a dropped job never runs."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import make_encoder_weights
+    from pointcloud_rl_amd import hip
+    from pointcloud_rl_amd.replay import DeviceReplay
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    cap, N, A, B, H, K0, col0 = 64, 96, 6, 24, 1024, 56, 50
+    w = {k: torch.from_numpy(v).to(cuda) for k, v in make_encoder_weights(6, 64, 128, 256, seed=3).items()}
+    ew, _ = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    n_packed = hip.encoder_packed_bytes(6, 64, 128, 256) // 4
+    want = torch.empty(n_packed, device=cuda)
+    hip.encoder_pack_weights(ew, want)
+    W0 = torch.randn(2, H, K0, device=cuda)
+    want_cols = W0[:, :, col0:col0 + A].permute(0, 2, 1).contiguous()
+
+    def replay():
+        mem = DeviceReplay(cap, device=cuda, seed=21)
+        mem.push_batch(make_batch_np(40, N, A, seed=3))
+        return mem
+    plain, riding = replay(), replay()
+    for call in range(3):
+        plain.sample(B)
+        packed = torch.full((n_packed,), float("nan"), device=cuda)
+        cols = torch.full((2, A, H), float("nan"), device=cuda)
+        hip.pack_attach_cols([(W0, H * K0, 2, H, K0, col0, A, cols)])
+        hip.encoder_pack_attach_to_gather(ew, packed)
+        torch.cuda.synchronize()
+        assert torch.isnan(packed).all() and torch.isnan(cols).all()          # nothing has run yet
+        riding.sample(B)                                                       # ... this launch carries both
+        torch.cuda.synchronize()
+        assert torch.equal(packed, want) and torch.equal(cols, want_cols)
+        fa, fb = plain._stage(B)[0], riding._stage(B)[0]
+        for k in fa:
+            assert torch.equal(fa[k], fb[k]), k
+        assert plain.state.tolist() == riding.state.tolist()
+        packed.fill_(float("nan"))
+        hip.encoder_pack_flush_pending()                                       # taken already: no launch
+        hip.pack_flush_cols()
+        torch.cuda.synchronize()
+        assert torch.isnan(packed).all()
+    packed = torch.full((n_packed,), float("nan"), device=cuda)
+    hip.encoder_pack_attach_to_gather(ew, packed)
+    with pytest.raises(RuntimeError, match="already pending"):
+        hip.encoder_pack_attach_to_gather(ew, packed)
+    hip.encoder_pack_flush_pending()                                           # no sampling launch came: a launch of its own
+    torch.cuda.synchronize()
+    assert torch.equal(packed, want)
+    packed.fill_(float("nan"))
+    hip.encoder_pack_attach_to_gather(ew, packed)
+    hip.encoder_pack_drop_pending()
+    riding.sample(B)
+    hip.encoder_pack_flush_pending()
+    torch.cuda.synchronize()
+    assert torch.isnan(packed).all()
+
+
+@pytest.mark.parametrize("head_hidden,A,entry_pack", [(64, 4, "1"), (1024, 6, "1"), (1024, 6, "0")])
+def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda, monkeypatch, head_hidden, A, entry_pack):
     """With a DeviceReplay that draws its rows on the device, the sampling launch is the first node of the captured step and
     the metrics come back through the pinned mirror's flag (no copy node, no stream synchronisation): every returned metric and
-    every parameter equal the eager run's bit for bit, and the replay counted every call."""
+    every parameter equal the eager run's bit for bit, and the replay counted every call.  The sampling launch also carries the critic
+    phase's re-pack (heads 1 024 wide, A <= 8: with the target heads' action-column image; PCRL_ENTRY_PACK=0: the separate launches)."""
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent
     from pointcloud_rl_amd.replay import DeviceReplay
     from pointcloud_rl_amd.synthetic import make_batch_np
-    B, N, A, steps = 8, 64, 4, 12
+    monkeypatch.setenv("PCRL_ENTRY_PACK", entry_pack)
+    B, N, steps = 8, 64, 12
 
     def run(graphs):
-        cfg = configs.sac_dmc(6, A, B, head_hidden=64)
+        cfg = configs.sac_dmc(6, A, B, head_hidden=head_hidden)
         cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
         torch.manual_seed(0)
         agent = build_agent(cfg).to(cuda)
