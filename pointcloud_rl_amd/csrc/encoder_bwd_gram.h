@@ -644,28 +644,87 @@ __device__ __forceinline__ void wgrad_blocks_stream(const __amdgpu_buffer_rsrc_t
 }
 
 // ---- wgrad: per cloud --------------------------------------------------------------------------------------------------
-// Two 32 x 32 blocks of G that share their A operand: sum over slots of (a_slot h1[32 mb + i][slot]) h1[32 nb + j][slot], both
-// operands from the LDS copy of the cloud's h1 pieces; the reads of the next octet are issued before this octet's MFMAs.
-__device__ __forceinline__ void gram_pair(const f32x4* s_h1, const f32x4* s_a4, int mb, int nb0, int n_oct, int lane, f32x16 (&acc)[2]) {
+// One or two 32 x 32 blocks of G = sum over slots of (a_slot h1[32 mb + i][slot]) h1[32 nb + j][slot], every operand from the LDS copy of
+// the cloud's h1 pieces; the reads of the next octet are issued before this octet's MFMAs.  G is symmetric: only blocks with mb <= nb are
+// formed (10 of 16 at c2 = 128; the others are stored as their mirror images), two per task -- (mbA, nbA) and (mbB, nbB), mbB < 0: one block.
+__device__ __forceinline__ void gram_blocks(const f32x4* s_h1, const f32x4* s_a4, int mbA, int nbA, int mbB, int nbB, int n_oct, int lane,
+                                            f32x16 (&acc)[2]) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     if (n_oct == 0) return;
-    const f32x4* a4 = s_h1 + mb * n_oct * 64 + lane;
-    const f32x4* b40 = s_h1 + nb0 * n_oct * 64 + lane;
-    const f32x4* b41 = b40 + n_oct * 64;
+    const bool two = mbB >= 0;
+    const f32x4* a40 = s_h1 + mbA * n_oct * 64 + lane;
+    const f32x4* b40 = s_h1 + nbA * n_oct * 64 + lane;
+    const f32x4* a41 = two ? s_h1 + mbB * n_oct * 64 + lane : a40;
+    const f32x4* b41 = two ? s_h1 + nbB * n_oct * 64 + lane : b40;
     const f32x4* sc = s_a4 + (lane >> 5);
-    f32x4 a = a4[0], s4 = sc[0], b0 = b40[0], b1 = b41[0];
+    f32x4 a0 = a40[0], a1 = a41[0], s4 = sc[0], b0 = b40[0], b1 = b41[0];
     for (int qo = 0; qo < n_oct; ++qo) {
-        const f32x4 as = a * s4, c0 = b0, c1 = b1;
-        if (qo + 1 < n_oct) { a = a4[(qo + 1) * 64]; s4 = sc[2 * (qo + 1)]; b0 = b40[(qo + 1) * 64]; b1 = b41[(qo + 1) * 64]; }
+        const f32x4 as0 = a0 * s4, as1 = a1 * s4, c0 = b0, c1 = b1;
+        if (qo + 1 < n_oct) {
+            a0 = a40[(qo + 1) * 64]; a1 = a41[(qo + 1) * 64]; s4 = sc[2 * (qo + 1)]; b0 = b40[(qo + 1) * 64]; b1 = b41[(qo + 1) * 64];
+        }
+        if (two) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], c0[j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[j], c1[j], acc[1], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[j], c0[j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(as1[j], c1[j], acc[1], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(as0[j], c0[j], acc[0], 0, 0, 0);
         }
     }
+}
+
+// The mirror image of an off-diagonal block of the symmetric G: D tile (mb, nb) -> rows 32 nb .., columns 32 mb .. of the row-major matrix.
+// A lane holds column j of the tile, i.e. row j of the mirror image, as four runs of four consecutive columns: four 16-byte stores.
+__device__ __forceinline__ void store_tile_mirrored(float* out, int ld, int mb, int nb, const f32x16& acc, int lane) {
+    float* row = out + (long long)(32 * nb + (lane & 31)) * ld + 32 * mb + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(row + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+}
+
+// The wgrad kernel's task lists: task[8 part + wave] = up to kWgradMaxTasks codes (kind << 5 | index; kind 1: dW1 task, 2: pair of G blocks,
+// 3: single G block, 4: dW0 block; 0 ends the list).  Built on the host (make_wgrad_sched), a kernel argument.
+constexpr int kWgradMaxTasks = 8;
+struct alignas(8) WgradSched { unsigned char task[64][kWgradMaxTasks]; };
+
+// The upper-triangle blocks of G as tasks: pairs that share their row block first, then the left-over diagonal blocks one by one (they
+// are the short tasks the schedule below uses to level the waves).  code = mbA | nbA << 4 | (mbB + 1) << 8 | nbB << 12.
+template <int MB2>
+struct GramTasks {
+    static_assert(MB2 == 2 || MB2 == 4, "G task tables are written for c2 = 64 and c2 = 128");
+    static constexpr int n_pairs = MB2 == 4 ? 4 : 1, n_single = MB2 == 4 ? 2 : 1;
+    __host__ __device__ static constexpr int pair(int t) {
+        return MB2 == 4 ? (t == 0 ? (0 | 0 << 4 | 1 << 8 | 1 << 12) : t == 1 ? (0 | 2 << 4 | 1 << 8 | 3 << 12)
+                           : t == 2 ? (1 | 2 << 4 | 2 << 8 | 3 << 12) : (2 | 2 << 4 | 3 << 8 | 3 << 12))
+                        : (0 | 0 << 4 | 1 << 8 | 1 << 12);
+    }
+    __host__ __device__ static constexpr int single(int t) { return MB2 == 4 ? (t == 0 ? (1 | 1 << 4) : (3 | 3 << 4)) : (1 | 1 << 4); }
+};
+
+// Longest task first, each to the least loaded of the cloud's 8 P waves (ties: the lowest wave): dW1 tasks (W1NB blocks, both operands
+// from L2), G pairs (LDS-fed), dW0 blocks (L2-fed), single G blocks.  Which wave forms a block changes no result.
+template <int MB1, int MB2, int W1NB>
+static void make_wgrad_sched(int P, WgradSched* sched) {
+    typedef GramTasks<MB2> GT;
+    const int G8 = 8 * P;
+    float load[64];
+    int n[64];
+    for (int w = 0; w < 64; ++w) { load[w] = 0.0f; n[w] = 0; for (int i = 0; i < kWgradMaxTasks; ++i) sched->task[w][i] = 0; }
+    auto give = [&](int kind, int idx, float cost) {
+        int best = 0;
+        for (int w = 1; w < G8; ++w) if (load[w] < load[best]) best = w;
+        load[best] += cost;
+        if (n[best] < kWgradMaxTasks) sched->task[best][n[best]++] = (unsigned char)(kind << 5 | idx);
+    };
+    for (int u = 0; u < MB2 * MB1 / W1NB; ++u) give(1, u, 1.3f * W1NB);
+    for (int t = 0; t < GT::n_pairs; ++t) give(2, t, 2.0f);
+    for (int t = 0; t < MB1; ++t) give(4, t, 1.3f);
+    for (int t = 0; t < GT::n_single; ++t) give(3, t, 1.0f);
 }
 
 // conv0.weight [C1][C] and conv0.bias (column C of the x|1 operand), row block mb: wgrad_conv0 of encoder_bwd_impl.h with the
@@ -687,7 +746,7 @@ __device__ __forceinline__ void wgrad_conv0_pipelined(const BwdParams& p, const 
 }
 
 template <int C1, int kC2, int kC3>
-__global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdParams p) {
+__global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdParams p, const WgradSched sched) {
     constexpr int MB1 = C1 / 32, MB2 = kC2 / 32;
     constexpr OpsLayoutG OL{C1 / 32, kC2 / 32, bwdg_np(kC3)};
     constexpr GramExtra GX{kC2};
@@ -764,35 +823,44 @@ __global__ __launch_bounds__(512, 1) void encoder_bwdg_wgrad_kernel(const BwdPar
         }
         __syncthreads();       // the scaled row coefficients are read by whichever wave takes the channel's S chunk
         PCRL_WSTAMP(1);
-        // MFMA tasks, dealt kind by kind over the 8 P waves of the cloud's P workgroups so that every wave gets its share of each
-        // kind (at the K1 shape: one dW1 block, one pair of G blocks, a dW0 block for two of them) instead of whole rounds of one kind:
-        // the L2-fed blocks (dW1, dW0) of one wave then overlap the LDS-fed ones of the wave it shares its SIMD with
+        // MFMA tasks of the cloud, spread over the 8 P waves of its P workgroups.
         // dW1: two column blocks per task share the dz1 operand (three loads per eight MFMAs instead of four): wgrad kernel 47.4 -> 43.8 us
         // at K1, 296 -> 254 us at 1 024 x 1 200 clouds with c1 = 128
         constexpr int W1NB = PCRL_BWDG_W1NB(MB1);
-        constexpr int nGp = MB2 * (MB2 / 2), nW1 = MB2 * MB1 / W1NB, nW0 = MB1;
-        const int g = part * 8 + wave, G8 = 8 * P;
-        // (the list [dW1 blocks | G pairs | dW0 blocks] is dealt round-robin: kind k starts at the wave after the previous kind's last)
-        const int gG = (g + G8 - nW1 % G8) % G8, g0 = (g + 2 * G8 - (nW1 + nGp) % G8) % G8;
-        for (int u = g; u < nW1; u += G8) {
-            f32x16 acc[W1NB];
-            constexpr int per_row = MB1 / W1NB;
-            // both operands stream from L2: six octets in flight (three left the matrix pipe waiting two thirds of the time)
-            wgrad_blocks_stream<W1NB, PCRL_BWDG_WRING>(r_ops, 4u * (unsigned)(OL.dz1() + (u / per_row) * OL.blk()),
-                                                       4u * (unsigned)(OL.h0() + W1NB * (u % per_row) * OL.blk()), 4u * (unsigned)OL.blk(), n_oct, lane, acc);
+        typedef GramTasks<MB2> GT;
+        // this wave's tasks: make_wgrad_sched (host) -- longest task first, each to the least loaded of the cloud's 8 P waves
+        unsigned long long mine;                      // the wave's whole list in one load (a kernel-argument read per task would be a round trip each)
+        __builtin_memcpy(&mine, sched.task[part * 8 + wave], 8);
+        static_assert(kWgradMaxTasks == 8, "a wave's list is read as one 64-bit word");
+        for (int i = 0; i < kWgradMaxTasks; ++i) {
+            const int task = (int)((mine >> (8 * i)) & 0xFFull), kind = task >> 5, code = task & 31;
+            if (kind == 0) break;
+            if (kind == 1) {
+                const int u = code;
+                f32x16 acc[W1NB];
+                constexpr int per_row = MB1 / W1NB;
+                // both operands stream from L2: six octets in flight (three left the matrix pipe waiting two thirds of the time)
+                wgrad_blocks_stream<W1NB, PCRL_BWDG_WRING>(r_ops, 4u * (unsigned)(OL.dz1() + (u / per_row) * OL.blk()),
+                                                           4u * (unsigned)(OL.h0() + W1NB * (u % per_row) * OL.blk()), 4u * (unsigned)OL.blk(), n_oct, lane, acc);
 #pragma unroll
-            for (int n = 0; n < W1NB; ++n) store_tile(pw + GL.w1(), C1, u / per_row, W1NB * (u % per_row) + n, C1, acc[n], lane);
+                for (int n = 0; n < W1NB; ++n) store_tile(pw + GL.w1(), C1, u / per_row, W1NB * (u % per_row) + n, C1, acc[n], lane);
+            } else if (kind == 2 || kind == 3) {
+                f32x16 acc[2];
+                const int gc = kind == 2 ? GT::pair(code) : GT::single(code);
+                const int mbA = gc & 15, nbA = (gc >> 4) & 15, mbB = ((gc >> 8) & 15) - 1, nbB = (gc >> 12) & 15;
+                gram_blocks(s_h1, s_a4, mbA, nbA, mbB, nbB, n_oct, lane, acc);
+                store_tile(px + GX.G(), kC2, mbA, nbA, kC2, acc[0], lane);
+                if (mbA != nbA) store_tile_mirrored(px + GX.G(), kC2, mbA, nbA, acc[0], lane);
+                if (mbB >= 0) {
+                    store_tile(px + GX.G(), kC2, mbB, nbB, kC2, acc[1], lane);
+                    if (mbB != nbB) store_tile_mirrored(px + GX.G(), kC2, mbB, nbB, acc[1], lane);
+                }
+            } else {
+                wgrad_conv0_pipelined(p, r_ops, OL.blk(), pw, GL, OL.dz0(), OL.xb(), code, n_oct, lane);
+            }
         }
         PCRL_WSTAMP(2);
-        for (int t = gG; t < nGp; t += G8) {
-            f32x16 acc[2];
-            const int mb = t / (MB2 / 2), nb0 = 2 * (t % (MB2 / 2));
-            gram_pair(s_h1, s_a4, mb, nb0, n_oct, lane, acc);
-            store_tile(px + GX.G(), kC2, mb, nb0, kC2, acc[0], lane);
-            store_tile(px + GX.G(), kC2, mb, nb0 + 1, kC2, acc[1], lane);
-        }
         PCRL_WSTAMP(3);
-        for (int t = g0; t < nW0; t += G8) wgrad_conv0_pipelined(p, r_ops, OL.blk(), pw, GL, OL.dz0(), OL.xb(), t, n_oct, lane);
         PCRL_WSTAMP(4);
         // What needs only the LDS copy -- v, u (2 C2 dot products over the active slots; as MFMA blocks they cost C2 / 32 blocks for two
         // useful rows) and the sparse rows of dW2, S[c][j] = (rstd2 dx)_c h1[slot(c)][j] -- is cut into 1 024-element chunks that the
@@ -1192,7 +1260,9 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     constexpr size_t wgrad_lds = (size_t)(C2 / 32) * 32 * 64 * sizeof(f32x4) + 3 * 64 * sizeof(f32x4) + 256 * 4 + (size_t)C3 * 8 + 16;
     auto wgrad = encoder_bwdg_wgrad_kernel<C1, C2, C3>;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(wgrad), wgrad_lds)) return rc;
-    hipLaunchKernelGGL(wgrad, dim3(min(p.cl.B, num_cus()) * p.parts), dim3(512), wgrad_lds, stream, p);
+    WgradSched sched;
+    make_wgrad_sched<C1 / 32, C2 / 32, PCRL_BWDG_W1NB(C1 / 32)>(p.parts, &sched);
+    hipLaunchKernelGGL(wgrad, dim3(min(p.cl.B, num_cus()) * p.parts), dim3(512), wgrad_lds, stream, p, sched);
     PCRL_BWDG_AFTER("encoder_bwdg_wgrad_kernel");
     const GradLayout GL{p.cl.C, C1, C2, C3};
     const GramExtra GX{C2};
