@@ -1,7 +1,7 @@
 #!/bin/bash
-# Same-box A/B of two builds of the encoder backward's wgrad kernel: _ab/libpcrl_hip_base.so (all 16 blocks of G as 8 pairs, tasks dealt
-# kind by kind round-robin) against the shipped library (G's 10 blocks on and above the block diagonal, mirrored by the finish kernel;
-# longest task first to the least loaded wave).
+# Same-box A/B of two builds of the encoder backward: _ab/libpcrl_hip_base.so (the previous build) against the shipped library.  Used for
+# (i) the wgrad kernel with the 10 upper blocks of the symmetric G and the longest-task-first schedule, (ii) the points kernel whose tile loop
+# requests the next tile's point index / owned-channel word / point ahead of time.
 set -u
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q -x -k "bwd or update or fullsize or integration" 2>&1 | tail -3
