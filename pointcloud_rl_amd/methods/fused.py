@@ -204,10 +204,11 @@ class FusedStep:
         # K3's 128-cloud share 0.669 -> 0.657 ms, K2's actor phase; K3's full batch stays on the GEMMs)
         _env_max = __import__("os").environ.get("PCRL_POLICY_TAIL_MAX")
         self.policy_tail_max = int(_env_max) if _env_max else 4096
-        # forward tail: every row streams the 2A rows of the last layer (0.55 us per MB of them at M x 2A x 4 KB) against ~15.5 us for
-        # GEMM + head launch: 8 192 row-outputs (K3's 128-cloud share 5 632: 10.6 us; K2's actor phase 11 264: 25.6 us -> stays on the
-        # GEMM).  The backward tail replaces FOUR launches (~28 us) and still wins there: 16 384.
-        self.policy_tail_max_split = int(_env_max) if _env_max else 8192
+        # forward tail: every row streams the 2A rows of the last layer against ~15.5 us for GEMM + head launch.  With one group of sixteen
+        # outputs in flight the limit was 8 192 row-outputs (K2's actor phase, 11 264, took 25.6 us); with every piece requested at once
+        # (policy_tail_fwd_split_kernel<G>, A <= 24) all of the row-split domain pays: 512 rows x 48 outputs (K2's 512-row critic phase
+        # 12.0 us, its step 0.9873 -> 0.9772 ms, tools/r4_ab15.sh).  The backward tail replaces FOUR launches (~28 us): 16 384.
+        self.policy_tail_max_split = int(_env_max) if _env_max else int(__import__("os").environ.get("PCRL_TAIL_FWD_MAX_SPLIT", "24576"))
         self.policy_tail_bwd_max_split = int(_env_max) if _env_max else 16384
         self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
         self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
