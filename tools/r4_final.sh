@@ -17,4 +17,4 @@ for wl in k2 k4 k1; do
   timeout 600 python bench.py --gpus 2 --backend gloo --share-gpu --workload $wl --steps 6 --warmup 5 --no-cpu-baseline --no-extra-workloads --replay-capacity 512 2> $OUT/dp_$wl.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['config']['exchange'], d['config']['batch_per_gpu'])" || tail -5 $OUT/dp_$wl.err
 done
 echo "== two ranks, default k1 line with its extras (gloo, shared GPU)"
-( time timeout 900 python bench.py --gpus 2 --backend gloo --share-gpu --steps 6 --warmup 5 --replay-capacity 512 --extra-steps 6 2> $OUT/dp_extras.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], [k for k in d if k.startswith('config')], d.get('extras_error'))" ) 2>&1 | tail -4
+( time timeout 900 python bench.py --gpus 2 --backend gloo --share-gpu --steps 6 --warmup 5 --replay-capacity 512 --extra-steps 6 2> $OUT/dp_extras.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], [k for k in d if k.startswith('config')], d.get('extras_error'))" ) 2>&1 | tail -5
