@@ -293,6 +293,11 @@ int pcrl_augment_xyz_f32(const float* xyz_in, float* xyz_out, int32_t B, int32_t
 int pcrl_affine_sample_f32(float* mat, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
                            const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset,
                            const uint64_t* offset_ptr, void* stream);
+/* Two draws of the same transform in ONE launch -- DrQ augments obs and next_obs with independent draws back to back (drq.py:62-75): mat
+ * from (seed, offset), mat2 from (seed2, offset2), each exactly what pcrl_affine_sample_f32 writes for those arguments. */
+int pcrl_affine_sample_pair_f32(float* mat, float* mat2, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                                const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset, uint64_t seed2,
+                                uint64_t offset2, const uint64_t* offset_ptr, void* stream);
 /* ColorJitterPoints on a [B,3,N] uint8 tensor (strides in elements).  pcrl_color_contrast_mean_u8 applies the steps that
  * precede the contrast step and returns each cloud's mean grayscale value at that point (mean_out [B] f32; the
  * reduction over the N points of a cloud is the one thing the fused encoder load cannot do on the fly);

@@ -6,9 +6,11 @@ returns the observation as an `AugmentedObs` carrying the parameters; the encode
 them while loading points (include/pcrl.h, pcrl_aug_desc).  `materialize()` runs the stand-alone
 kernel for consumers other than the encoder.
 """
+import os
 from collections.abc import Sequence
 
 import numpy as np
+
 import torch
 
 from .networks.pointnet import AugmentedObs, batch_rows
@@ -121,7 +123,7 @@ class RandomJitterPoints(_PointAug):
         """shared_counter: device int64 [1] tensor that changes exactly once per update step before the step's encoder launches
         (None: every call advances its own counter, as outside update steps)."""
         assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1)
-        self._shared, self._slot = shared_counter, 0
+        self._shared, self._slot, self._predrawn = shared_counter, 0, None
 
     def __repr__(self):
         return f"{type(self).__name__}(jitter_range={self.jitter_range},"
@@ -271,6 +273,8 @@ class GlobalRotScaleTrans(_PointAug):
         self.seed = int(seed) if seed is not None else int(torch.initial_seed() & 0x7FFFFFFFFFFFFFFF)
         self.calls = 0
         self._shared, self._slot, self._mats = None, 0, {}
+        self._predrawn = None                  # (rows, slot) of matrices the previous call's launch has already drawn
+        self.pair_draws = os.environ.get("PCRL_AFFINE_PAIR", "1") == "1"
 
     def sample_matrix(self, batch_size, device):
         mat = torch.zeros([batch_size, 3, 4], device=device)
@@ -304,12 +308,20 @@ class GlobalRotScaleTrans(_PointAug):
             from . import hip
             self._slot += 1
             rows = batch_rows(data)
-            key = (rows, self._slot)
-            if key not in self._mats:          # persistent output buffers: a captured launch keeps writing the same memory
-                self._mats[key] = torch.empty(rows, 3, 4, dtype=torch.float32, device=data["xyz"].device)
-            mat = hip.affine_sample(self._mats[key], self.rot_axis, self.rot_range, self.scale_ratio_range,
-                                    None if self.translation_range is None else self.translation_range.tolist(), self.shift_height,
-                                    (self.seed + 0x9E3779B97F4A7C15 * self._slot) & 0x7FFFFFFFFFFFFFFF, offset=self.calls, offset_tensor=self._shared)
+            buf = lambda slot: self._mats.setdefault((rows, slot), torch.empty(rows, 3, 4, dtype=torch.float32, device=data["xyz"].device))
+            seed_of = lambda slot: (self.seed + 0x9E3779B97F4A7C15 * slot) & 0x7FFFFFFFFFFFFFFF
+            mat = buf(self._slot)              # persistent output buffers: a captured launch keeps writing the same memory
+            if self._predrawn == (rows, self._slot):
+                pass                           # drawn by the previous call's launch
+            else:
+                # the first call of a step also draws for the second (DrQ augments obs and next_obs back to back, drq.py:62-75): one
+                # launch instead of two; a second call that never comes costs nothing but the unused matrices
+                pair = self.pair_draws and self._slot == 1
+                hip.affine_sample(mat, self.rot_axis, self.rot_range, self.scale_ratio_range,
+                                  None if self.translation_range is None else self.translation_range.tolist(), self.shift_height,
+                                  seed_of(self._slot), offset=self.calls, offset_tensor=self._shared,
+                                  second=(buf(2), seed_of(2), self.calls + 1) if pair else None)
+                self._predrawn = (rows, 2) if pair else None
             self.calls += 1
             out.aug["affine"] = mat
             return out

@@ -153,14 +153,19 @@ struct AffineSampleParams {
     float* mat; int B, rot_axis, has_rot, has_scale, has_trans, shift_height;
     float rot_lo, rot_hi, scale_lo, scale_hi, trans[3];
     unsigned long long seed, offset; const unsigned long long* offset_ptr;
+    // a SECOND draw of the same transform in the same launch (blocks past the first draw's: pcrl_affine_sample_pair_f32), or NULL
+    float* mat2; unsigned long long seed2, offset2;
 };
 __global__ __launch_bounds__(256) void affine_sample_kernel(const AffineSampleParams p) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int per_draw = (p.B + 255) / 256;
+    const bool second = (int)blockIdx.x >= per_draw;
+    const int b = ((int)blockIdx.x - (second ? per_draw : 0)) * 256 + threadIdx.x;
     if (b >= p.B) return;
-    const unsigned long long off = p.offset_ptr ? *p.offset_ptr : p.offset;
+    const unsigned long long off = p.offset_ptr ? *p.offset_ptr : (second ? p.offset2 : p.offset);
+    const unsigned long long seed = second ? p.seed2 : p.seed;
     uint32_t w0[4], w1[4];
-    philox4x32_10((uint32_t)b, 0u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32) ^ 0xA0F1E2D3u, w0);
-    philox4x32_10((uint32_t)b, 1u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)p.seed, (uint32_t)(p.seed >> 32) ^ 0xA0F1E2D3u, w1);
+    philox4x32_10((uint32_t)b, 0u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0xA0F1E2D3u, w0);
+    philox4x32_10((uint32_t)b, 1u, (uint32_t)off, (uint32_t)(off >> 32), (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0xA0F1E2D3u, w1);
     float m[3][4];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void affine_sample_kernel(const AffineSamplePa
 #pragma unroll
             for (int j = 0; j < 3; ++j) m[i][j] = i == j ? 1.0f : 0.0f;
     }
-    float* dst = p.mat + (long long)b * 12;
+    float* dst = (second ? p.mat2 : p.mat) + (long long)b * 12;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -249,9 +254,26 @@ extern "C" int pcrl_color_jitter_u8(const uint8_t* rgb_in, uint8_t* rgb_out, int
     return PCRL_OK;
 }
 
+static int affine_sample_launch(float* mat, float* mat2, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                                const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset, uint64_t seed2,
+                                uint64_t offset2, const uint64_t* offset_ptr, void* stream);
+
 extern "C" int pcrl_affine_sample_f32(float* mat, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
                                       const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset,
                                       const uint64_t* offset_ptr, void* stream) {
+    return affine_sample_launch(mat, nullptr, B, rot_axis, rot_range, scale_range, translation_range, shift_height, seed, offset, 0, 0, offset_ptr, stream);
+}
+
+extern "C" int pcrl_affine_sample_pair_f32(float* mat, float* mat2, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                                           const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset, uint64_t seed2,
+                                           uint64_t offset2, const uint64_t* offset_ptr, void* stream) {
+    if (!mat2) return fail(PCRL_E_ARG, "affine sample pair: mat2 is NULL");
+    return affine_sample_launch(mat, mat2, B, rot_axis, rot_range, scale_range, translation_range, shift_height, seed, offset, seed2, offset2, offset_ptr, stream);
+}
+
+static int affine_sample_launch(float* mat, float* mat2, int32_t B, int32_t rot_axis, const float* rot_range, const float* scale_range,
+                                const float* translation_range, int32_t shift_height, uint64_t seed, uint64_t offset, uint64_t seed2,
+                                uint64_t offset2, const uint64_t* offset_ptr, void* stream) {
     if (!mat || B < 1 || rot_axis < 0 || rot_axis > 2) return fail(PCRL_E_ARG, "affine sample: bad arguments");
     AffineSampleParams p{};
     p.mat = mat; p.B = B; p.rot_axis = rot_axis; p.shift_height = shift_height;
@@ -260,7 +282,8 @@ extern "C" int pcrl_affine_sample_f32(float* mat, int32_t B, int32_t rot_axis, c
     if (scale_range) { p.scale_lo = scale_range[0]; p.scale_hi = scale_range[1]; }
     if (translation_range) for (int i = 0; i < 3; ++i) p.trans[i] = translation_range[i];
     p.seed = seed; p.offset = offset; p.offset_ptr = reinterpret_cast<const unsigned long long*>(offset_ptr);
-    hipLaunchKernelGGL(affine_sample_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    p.mat2 = mat2; p.seed2 = seed2; p.offset2 = offset2;
+    hipLaunchKernelGGL(affine_sample_kernel, dim3((B + 255) / 256 * (mat2 ? 2 : 1)), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("affine_sample_kernel");
     return PCRL_OK;
 }

@@ -669,17 +669,26 @@ def segmax_bwd(grad_out, idx, N):
     return dx
 
 
-def affine_sample(out, rot_axis, rot_range, scale_range, translation_range, shift_height, seed, offset=0, offset_tensor=None):
+def affine_sample(out, rot_axis, rot_range, scale_range, translation_range, shift_height, seed, offset=0, offset_tensor=None, second=None):
     """GlobalRotScaleTrans's [B,3,4] matrices drawn by one launch (pcrl_affine_sample_f32) into `out` (float32, contiguous, cuda).
-    Ranges are None or sequences of 2 / 2 / 3 floats; offset_tensor: device int64 [1] read at run time (hipGraph replays)."""
+    Ranges are None or sequences of 2 / 2 / 3 floats; offset_tensor: device int64 [1] read at run time (hipGraph replays).
+    second = (out2, seed2, offset2): a second, independent draw of the same transform in the same launch (pcrl_affine_sample_pair_f32)."""
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape[1:]) == (3, 4)
     arr = lambda v, n: None if v is None else (ctypes.c_float * n)(*[float(x) for x in v])
+    u64 = lambda v: ctypes.c_uint64(int(v) & (2 ** 64 - 1))
     if offset_tensor is not None:
         assert offset_tensor.dtype == torch.int64 and offset_tensor.is_cuda
+    optr = _ptr(offset_tensor) if offset_tensor is not None else None
     with _span("affine_sample"):
-        check(lib().pcrl_affine_sample_f32(_ptr(out), out.shape[0], int(rot_axis), arr(rot_range, 2), arr(scale_range, 2), arr(translation_range, 3),
-                                           int(bool(shift_height)), ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), ctypes.c_uint64(int(offset)),
-                                           _ptr(offset_tensor) if offset_tensor is not None else None, _stream()))
+        if second is None:
+            check(lib().pcrl_affine_sample_f32(_ptr(out), out.shape[0], int(rot_axis), arr(rot_range, 2), arr(scale_range, 2), arr(translation_range, 3),
+                                               int(bool(shift_height)), u64(seed), u64(offset), optr, _stream()))
+        else:
+            out2, seed2, offset2 = second
+            assert out2.is_cuda and out2.dtype == torch.float32 and out2.is_contiguous() and out2.shape == out.shape
+            check(lib().pcrl_affine_sample_pair_f32(_ptr(out), _ptr(out2), out.shape[0], int(rot_axis), arr(rot_range, 2), arr(scale_range, 2),
+                                                    arr(translation_range, 3), int(bool(shift_height)), u64(seed), u64(offset), u64(seed2), u64(offset2),
+                                                    optr, _stream()))
     return out
 
 

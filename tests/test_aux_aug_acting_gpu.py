@@ -836,6 +836,13 @@ def test_affine_sample_kernel_draws_the_reference_s_matrix_family(cuda):
     assert np.all(v[-1, :, 3] == 0) and np.any(draw(shift_height=True)[-1, :, 3].cpu().numpy() != 0)       # delta_xyz[-1] = 0
     ident = draw(rot_range=None, translation_range=None)                      # the scale has nothing to act on, as in the reference
     assert torch.equal(ident[:, :, :3], torch.eye(3, device=cuda).expand(B, 3, 3)) and torch.all(ident[:, :, 3] == 0)
+    # two draws in one launch (pcrl_affine_sample_pair_f32) = the two single launches
+    second = torch.full((B, 3, 4), float("nan"), device=cuda)
+    first = draw(second=(second, 10, 3))
+    assert torch.equal(first, m) and torch.equal(second, draw(seed=10, offset=3))
+    second.fill_(float("nan"))
+    draw(offset_tensor=off, second=(second, 10, 77))                          # a device-side offset slot serves both draws
+    assert torch.equal(second, draw(seed=10, offset=1))
 
 
 def test_drq_jitter_plus_scale_step_matches_the_restatement_and_draws_fresh_matrices(cuda):
@@ -903,4 +910,17 @@ def test_drq_jitter_plus_scale_step_matches_the_restatement_and_draws_fresh_matr
     for a, b in zip(seen[3:-1], seen[4:]):
         assert not torch.equal(a, b)                                                     # replayed launches drew again
     assert not torch.equal(seen[-1][0], seen[-1][1])                                     # the two calls of a step differ
+    # the first call's launch draws for both calls of the step (PCRL_AFFINE_PAIR=0: a launch per call): same matrices, same steps
+    def replayed_losses(pair):
+        torch.manual_seed(0)
+        ag = build_agent(cfg).to(cuda)
+        ag.obs_aug[0].pair_draws = pair
+        mem2 = DeviceReplay(64, device=cuda, seed=3)
+        mem2.push_batch(make_batch_np(64, N, A, seed=40))
+        ag.enable_graphs(warmup=1)
+        out = [ag.update_parameters(mem2, u) for u in range(1, 9)]
+        torch.cuda.synchronize()
+        return out, [m.clone() for m in ag.obs_aug[0]._mats.values()]
+    (la, ma), (lb, mb) = replayed_losses(True), replayed_losses(False)
+    assert la == lb and len(ma) == len(mb) == 2 and all(torch.equal(x, y) for x, y in zip(ma, mb))
     assert np.isfinite(losses).all() and len(set(np.round(losses, 7))) == len(losses)
