@@ -41,7 +41,7 @@ struct GemmParams {
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
     int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
-    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS
+    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS; 2: a 32x32 tile per WAVE
     int a_rc, b_rc;          // cfg 1: operand is contiguous along its row index (m resp. n) instead of along k
     int wg_n, wg_nm;         // n tiles, n tiles * m tiles
     float inv_wg_n, inv_wg_nm, inv_wg_m;
@@ -201,6 +201,115 @@ __device__ __forceinline__ void gemm_tile32_splitk(const GemmParams& p, const in
             if (c_off[e] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row[e]] = v;
         } else {
             buf_store_f1(rs_c, c_off[e], 0, v);
+        }
+    }
+}
+
+
+// cfg 2: EIGHT 32x32 output tiles per workgroup, one per wave with the whole K loop -- no split-K, no LDS, no barrier.  For problems with
+// thousands of tiles and a short contraction, i.e. the heads' weight gradients (1 024 x 1 025 outputs, K = batch): split eight ways a wave of
+// cfg 0 had 16 MFMAs (K = 256) between its prologue and the LDS reduce, and the launch ran at 40-48 TFLOP/s.  The workgroup's waves form a
+// 2 (m) x 4 (n) block of tiles: an A row block is shared by four waves, a B column block by two (L1).
+__device__ __forceinline__ void gemm_tile32_wave(const GemmParams& p, const int wg) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    // every field is needed within the next microsecond: one clause of scalar loads instead of dependent waits
+    asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.C), "s"(p.bias), "s"(p.mask), "s"(p.C_ones), "s"(p.a_bs), "s"(p.b_bs), "s"(p.c_bs),
+                 "s"(p.bias_bs), "s"(p.mask_bs), "s"(p.c_ones_bs));
+    asm volatile("" ::"s"(p.a_sm4), "s"(p.a_sk4), "s"(p.b_sn4), "s"(p.b_sk4), "s"(p.ldc4), "s"(p.ld_mask4), "s"(p.M), "s"(p.N), "s"(p.K),
+                 "s"(p.relu), "s"(p.ones_col), "s"(p.accumulate), "s"(p.a_k4), "s"(p.b_k4), "s"(p.wg_n), "s"(p.wg_nm), "s"(p.inv_wg_n),
+                 "s"(p.inv_wg_nm), "s"(p.wg_begin));
+    // tile decode without integer division (exact for < 2^20 workgroups; checked on the host)
+    const int local = wg - p.wg_begin;
+    const int bz = __builtin_amdgcn_readfirstlane((int)(((float)local + 0.5f) * p.inv_wg_nm));
+    const int rem = local - bz * p.wg_nm;
+    const int my = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * p.inv_wg_n));
+    const int nx = rem - my * p.wg_n;
+    const int m0 = (2 * my + (wave >> 2)) * 32, n0 = (4 * nx + (wave & 3)) * 32;
+    if (m0 >= p.M || n0 >= p.N) return;              // (the whole wave: this path has no barrier)
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(uniform_ptr(p.A + bz * p.a_bs), kGemmRecords);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(uniform_ptr(p.B + bz * p.b_bs), kGemmRecords);
+    const int n = n0 + i;
+    int n_read = min(n, p.N - 1);
+    if (n_read == p.ones_col) n_read = 0;                       // that column is never read from memory
+    const unsigned a_off = (unsigned)min(m0 + i, p.M - 1) * p.a_sm4 + 16u * h * p.a_sk4;
+    const unsigned b_off = (unsigned)n_read * p.b_sn4 + 16u * h * p.b_sk4;
+    const bool a4 = p.a_k4 != 0, b4 = p.b_k4 != 0, ones = p.ones_col >= 0, n_ones = n == p.ones_col;
+    const int n_sc = (p.K + 31) >> 5;
+    const int sc_begin = 0, sc_end = n_sc, full_end = p.K >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    auto load = [&](int sc, f32x4 (&a)[4], f32x4 (&b)[4]) {
+        gemm_load_full(rs_a, a_off, p.a_sk4, a4, sc, a);
+        gemm_load_full(rs_b, b_off, p.b_sk4, b4, sc, b);
+        if (ones) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[t][j] = n_ones ? 1.0f : b[t][j];
+        }
+    };
+    int sc = sc_begin;
+    if (sc < full_end) load(sc, a0, b0);
+    if (sc + 1 < full_end) load(sc + 1, a1, b1);
+    while (sc < full_end) {             // two 32-k chunks in flight
+        gemm_mfma16(a0, b0, acc);
+        if (sc + 2 < full_end) load(sc + 2, a0, b0);
+        if (++sc >= full_end) break;
+        gemm_mfma16(a1, b1, acc);
+        if (sc + 2 < full_end) load(sc + 2, a1, b1);
+        ++sc;
+    }
+    if (sc < sc_end) {                  // the ragged last chunk (K % 32 != 0), owned by one k-slice
+        const int kbase = 32 * sc + 16 * h;
+        gemm_load_tail(rs_a, a_off, p.a_sk4, kbase, p.K, a0);
+        gemm_load_tail(rs_b, b_off, p.b_sk4, kbase, p.K, b0);
+        if (ones) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b0[t][j] = n_ones ? (kbase + 4 * t + j < p.K ? 1.0f : 0.0f) : b0[t][j];
+        }
+        gemm_mfma16(a0, b0, acc);
+    }
+    // Epilogue: the lane owns column n0 + (lane & 31) of its sixteen accumulator rows.
+    const int col = n0 + (lane & 31);
+    const bool col_ok = col < p.N;
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(uniform_ptr(p.C + bz * p.c_bs), kGemmRecords);
+    const float bv = p.bias ? (p.bias + bz * p.bias_bs)[min(col, p.N - 1)] : 0.0f;
+    float mv[16], old[16];
+    unsigned c_off[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        c_off[r] = (row < p.M && col_ok) ? (unsigned)row * p.ldc4 + 4u * col : kGemmOob;
+        mv[r] = 1.0f; old[r] = 0.0f;
+    }
+    if (p.mask) {
+        const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(uniform_ptr(p.mask + bz * p.mask_bs), kGemmRecords);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            mv[r] = buf_load_f1(rs_m, c_off[r] == kGemmOob ? kGemmOob : (unsigned)row * p.ld_mask4 + 4u * col, 0);
+        }
+    }
+    if (p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = buf_load_f1(rs_c, c_off[r], 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[r] + bv;
+        if (p.relu) v = v > 0.0f ? v : 0.0f;
+        v = mv[r] > 0.0f ? v : 0.0f;
+        v = old[r] + v;
+        if (p.C_ones && col == p.ones_col) {
+            if (c_off[r] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row] = v;
+        } else {
+            buf_store_f1(rs_c, c_off[r], 0, v);
         }
     }
 }
@@ -468,6 +577,7 @@ __global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const Gemm
         if (j < g.n && wg >= g.wg_begin[j]) gi = j;
     const GemmParams p = g.p[gi];
     if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
+    else if (p.cfg == 2) gemm_tile32_wave(p, wg);
     else gemm_tile32_splitk(p, wg, gemm_smem);
 }
 
@@ -596,6 +706,9 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
 
 using namespace pcrl;
 
+static long long wave_tile_min_tiles() { static const long long v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MIN"); return e ? atoll(e) : 1536ll; }(); return v; }
+static int wave_tile_max_k() { static const int v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MAX_K"); return e ? atoi(e) : 1024; }(); return v; }
+
 static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool want_tile64, bool force_tile64) {
     if (!d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 1) return fail(PCRL_E_ARG, "bad GEMM shape");
@@ -636,9 +749,14 @@ static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool
     const bool pays = force_tile64 || (a_kc && b_kc && d->K >= 512) || (a_kc && b_rc && d->K >= 512 && own_tiles64 >= 384);
     p.cfg = (want_tile64 && big && pays && (a_kc || a_rc) && (b_kc || b_rc)) ? 1 : 0;
     p.a_rc = !a_kc; p.b_rc = !b_kc;
-    const int t = p.cfg ? 64 : 32;
-    p.wg_n = (p.N + t - 1) / t;
-    const int wg_m = (p.M + t - 1) / t;
+    // a tile per wave: enough tiles to give every SIMD of the chip one and a half of them, and a contraction short enough that splitting it
+    // eight ways leaves a wave nothing to do (tools/bench_gemm.py: dW1 of two heads at 256 rows 22.3 -> see DESIGN.md section 4.3)
+    const long long tiles32 = (long long)((d->M + 31) / 32) * ((d->N + 31) / 32) * d->batch;
+    if (p.cfg == 0 && tiles32 >= wave_tile_min_tiles() && d->K <= wave_tile_max_k()) p.cfg = 2;
+    const int t = p.cfg == 1 ? 64 : 32;
+    const int tn = p.cfg == 2 ? 128 : t, tm = p.cfg == 2 ? 64 : t;       // a workgroup's block of the output
+    p.wg_n = (p.N + tn - 1) / tn;
+    const int wg_m = (p.M + tm - 1) / tm;
     p.wg_nm = p.wg_n * wg_m;
     p.inv_wg_n = 1.0f / (float)(p.wg_n > 0 ? p.wg_n : 1);
     p.inv_wg_nm = 1.0f / (float)(p.wg_nm > 0 ? p.wg_nm : 1);

@@ -61,6 +61,40 @@ def test_linear_backward_and_batched(cuda, gemm_path, M, K, N):
     np.testing.assert_allclose(DWB[:, :, K].cpu().numpy(), ref_db.numpy(), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(1000, 1100, 200, "epilogue"), (1024, 1025, 256, "ones"), (1500, 1030, 33, "accumulate")])
+def test_tile_per_wave_path_with_every_epilogue(cuda, M, N, K, kind):
+    """Problems with >= 1 536 tiles of 32 x 32 and K <= 1 024 run a tile per WAVE (dense.hip cfg 2: the heads' weight gradients): ragged
+    M / N / K (waves whose tile lies outside leave, the last k chunk is partial), bias + ReLU + mask, the ones column with its separate
+    destination, accumulation into C -- against float64."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(M + N + K)
+    H = 2
+    a = g.randn(H, K, M).astype(np.float32)              # A row-contiguous (stride 1 along m): the weight gradient's dY^T
+    b = g.randn(H, K, N).astype(np.float32)              # B row-contiguous
+    A_, B_ = T(a, cuda), T(b, cuda)
+    ref = np.einsum("hkm,hkn->hmn", a.astype(np.float64), b.astype(np.float64))
+    if kind == "epilogue":
+        bias, mask = g.randn(H, N).astype(np.float32), (g.rand(H, M, N) < 0.6).astype(np.float32)
+        C = torch.full((H, M, N), float("nan"), device=cuda)
+        hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, bias=T(bias, cuda), mask=T(mask, cuda), ld_mask=N, relu=True, batch=H,
+                 batch_strides=(K * M, K * N, M * N, N, M * N))
+        want = np.maximum(ref + bias[:, None, :], 0) * mask
+        np.testing.assert_allclose(C.cpu().numpy(), want, atol=2e-4, rtol=1e-5)
+    elif kind == "ones":
+        # column N - 1 of B is never read: it stands for a column of ones (bias gradient) and lands in its own vector
+        C = torch.full((H, M, N), float("nan"), device=cuda)
+        ones = torch.full((H, M), float("nan"), device=cuda)
+        hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, ones_col=N - 1, batch=H, batch_strides=(K * M, K * N, M * N, 0, 0), c_ones=ones, c_ones_batch_stride=M)
+        np.testing.assert_allclose(C[:, :, :N - 1].cpu().numpy(), ref[:, :, :N - 1], atol=2e-4, rtol=1e-5)
+        np.testing.assert_allclose(ones.cpu().numpy(), a.astype(np.float64).sum(1), atol=2e-4, rtol=1e-5)
+        assert torch.isnan(C[:, :, N - 1]).all()
+    else:
+        c0 = g.randn(H, M, N).astype(np.float32)
+        C = T(c0, cuda)
+        hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, accumulate=True, batch=H, batch_strides=(K * M, K * N, M * N, 0, 0))
+        np.testing.assert_allclose(C.cpu().numpy(), c0 + ref, atol=2e-4, rtol=1e-5)
+
+
 def test_layernorm_rows(cuda):
     from pointcloud_rl_amd import hip
     g = np.random.RandomState(1)
