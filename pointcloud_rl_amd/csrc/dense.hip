@@ -41,7 +41,7 @@ struct GemmParams {
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
     int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
-    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS; 2: a 32x32 tile per WAVE
+    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS; 2: a 32x32 tile per WAVE; 3: 64x32 per wave
     int a_rc, b_rc;          // cfg 1: operand is contiguous along its row index (m resp. n) instead of along k
     int wg_n, wg_nm;         // n tiles, n tiles * m tiles
     float inv_wg_n, inv_wg_nm, inv_wg_m;
@@ -315,6 +315,123 @@ __device__ __forceinline__ void gemm_tile32_wave(const GemmParams& p, const int 
 }
 
 
+// cfg 3: cfg 2 with TWO row blocks per wave when the A operand is contiguous along its rows (the weight gradient's dY^T): lane i loads rows
+// 2 i and 2 i + 1 of a k-step with ONE 8-byte load, and the two values feed two MFMAs (one per accumulator; an accumulator's MFMA rows are the
+// even resp. odd rows of the wave's 64 x 32 tile) against the same B value -- three load instructions per four MFMAs instead of eight for two
+// row-contiguous operands, which is what bounds cfg 0 / cfg 2 on these problems.  k runs in half chunks of 16 (lane half h takes 8 h .. 8 h + 7),
+// three of them in flight.  The workgroup's waves form a 2 (m) x 4 (n) block: 128 x 128 outputs.
+__device__ __forceinline__ void gemm_tile64x32_wave(const GemmParams& p, const int wg) {
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 31, h = lane >> 5;
+    asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.C), "s"(p.bias), "s"(p.mask), "s"(p.C_ones), "s"(p.a_bs), "s"(p.b_bs), "s"(p.c_bs),
+                 "s"(p.bias_bs), "s"(p.mask_bs), "s"(p.c_ones_bs));
+    asm volatile("" ::"s"(p.a_sm4), "s"(p.a_sk4), "s"(p.b_sn4), "s"(p.b_sk4), "s"(p.ldc4), "s"(p.ld_mask4), "s"(p.M), "s"(p.N), "s"(p.K),
+                 "s"(p.relu), "s"(p.ones_col), "s"(p.accumulate), "s"(p.a_k4), "s"(p.b_k4), "s"(p.wg_n), "s"(p.wg_nm), "s"(p.inv_wg_n),
+                 "s"(p.inv_wg_nm), "s"(p.wg_begin));
+    const int local = wg - p.wg_begin;
+    const int bz = __builtin_amdgcn_readfirstlane((int)(((float)local + 0.5f) * p.inv_wg_nm));
+    const int rem = local - bz * p.wg_nm;
+    const int my = __builtin_amdgcn_readfirstlane((int)(((float)rem + 0.5f) * p.inv_wg_n));
+    const int nx = rem - my * p.wg_n;
+    const int m0 = (2 * my + (wave >> 2)) * 64, n0 = (4 * nx + (wave & 3)) * 32;
+    if (m0 >= p.M || n0 >= p.N) return;              // (the whole wave: this path has no barrier)
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(uniform_ptr(p.A + bz * p.a_bs), kGemmRecords);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(uniform_ptr(p.B + bz * p.b_bs), kGemmRecords);
+    const int n = n0 + i;
+    int n_read = min(n, p.N - 1);
+    if (n_read == p.ones_col) n_read = 0;                       // that column is never read from memory
+    // rows 2 i, 2 i + 1 of the tile (M is even on this path; a pair hanging over the end is clamped and never stored)
+    const unsigned a_off = 4u * (unsigned)min(m0 + 2 * i, p.M - 2) + 8u * h * p.a_sk4;
+    const unsigned b_off = (unsigned)n_read * p.b_sn4 + 8u * h * p.b_sk4;
+    const bool b4 = p.b_k4 != 0, ones = p.ones_col >= 0, n_ones = n == p.ones_col;
+    const int n_hc = (p.K + 15) >> 4, full_end = p.K >> 4;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    f32x2 a[3][8];
+    float b[3][8];
+    auto load = [&](int hc, f32x2 (&av)[8], float (&bv)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = buf_load_f2(rs_a, a_off, (unsigned)(16 * hc + u) * p.a_sk4);
+        if (b4) {
+            const f32x4 lo = buf_load_f4(rs_b, b_off, 64u * (unsigned)hc), hi = buf_load_f4(rs_b, b_off + 16u, 64u * (unsigned)hc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { bv[u] = lo[u]; bv[4 + u] = hi[u]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = buf_load_f1(rs_b, b_off, (unsigned)(16 * hc + u) * p.b_sk4);
+        }
+        if (ones) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = n_ones ? 1.0f : bv[u];
+        }
+    };
+    auto mfma8 = [&](const f32x2 (&av)[8], const float (&bv)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u], acc1, 0, 0, 0);
+        }
+    };
+    if (0 < full_end) load(0, a[0], b[0]);
+    if (1 < full_end) load(1, a[1], b[1]);
+    if (2 < full_end) load(2, a[2], b[2]);
+    int hc = 0;
+    while (hc < full_end) {             // three half chunks in flight
+        mfma8(a[0], b[0]);
+        if (hc + 3 < full_end) load(hc + 3, a[0], b[0]);
+        if (++hc >= full_end) break;
+        mfma8(a[1], b[1]);
+        if (hc + 3 < full_end) load(hc + 3, a[1], b[1]);
+        if (++hc >= full_end) break;
+        mfma8(a[2], b[2]);
+        if (hc + 3 < full_end) load(hc + 3, a[2], b[2]);
+        ++hc;
+    }
+    if (hc < n_hc) {                    // the ragged last half chunk (K % 16 != 0): k >= K reads as zero
+        const int kbase = 16 * hc + 8 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = kbase + u < p.K;
+            a[0][u] = buf_load_f2(rs_a, in ? a_off + (unsigned)(16 * hc + u) * p.a_sk4 : kGemmOob, 0);
+            b[0][u] = buf_load_f1(rs_b, in ? b_off + (unsigned)(16 * hc + u) * p.b_sk4 : kGemmOob, 0);
+            if (ones) b[0][u] = n_ones ? (in ? 1.0f : 0.0f) : b[0][u];
+        }
+        mfma8(a[0], b[0]);
+    }
+    // Epilogue: the lane owns column n0 + (lane & 31); accumulator e holds tile rows 2 rho + e, rho = the MFMA row of register r.
+    const int col = n0 + (lane & 31);
+    const bool col_ok = col < p.N;
+    const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(uniform_ptr(p.C + bz * p.c_bs), kGemmRecords);
+    const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(uniform_ptr((p.mask ? p.mask : p.C) + bz * p.mask_bs), kGemmRecords);
+    const float bv = p.bias ? (p.bias + bz * p.bias_bs)[min(col, p.N - 1)] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float mv[16], old[16];
+        unsigned c_off[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + e;
+            c_off[r] = (row < p.M && col_ok) ? (unsigned)row * p.ldc4 + 4u * col : kGemmOob;
+            mv[r] = p.mask ? buf_load_f1(rs_m, c_off[r] == kGemmOob ? kGemmOob : (unsigned)row * p.ld_mask4 + 4u * col, 0) : 1.0f;
+            old[r] = p.accumulate ? buf_load_f1(rs_c, c_off[r], 0) : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + e;
+            float v = (e ? acc1[r] : acc0[r]) + bv;
+            if (p.relu) v = v > 0.0f ? v : 0.0f;
+            v = mv[r] > 0.0f ? v : 0.0f;
+            v = old[r] + v;
+            if (p.C_ones && col == p.ones_col) {
+                if (c_off[r] != kGemmOob) (p.C_ones + bz * p.c_ones_bs)[row] = v;
+            } else {
+                buf_store_f1(rs_c, c_off[r], 0, v);
+            }
+        }
+    }
+}
+
 // cfg 1: one 64x64 output tile per workgroup, for the layers where all three dimensions are large (the 1024 x 1024 layers
 // of the heads and their gradients).  Both operands are staged through LDS in 64-k chunks (two stages: the global loads of
 // chunk c + 1 are in flight while chunk c is multiplied), so every operand element is fetched from L2 once per workgroup
@@ -578,6 +695,7 @@ __global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const Gemm
     const GemmParams p = g.p[gi];
     if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
     else if (p.cfg == 2) gemm_tile32_wave(p, wg);
+    else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
     else gemm_tile32_splitk(p, wg, gemm_smem);
 }
 
@@ -707,6 +825,7 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
 using namespace pcrl;
 
 static long long wave_tile_min_tiles() { static const long long v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MIN"); return e ? atoll(e) : 1536ll; }(); return v; }
+static bool wave_tile_pairs() { static const bool v = [] { const char* e = getenv("PCRL_GEMM_WAVE_PAIRS"); return !e || atoi(e) != 0; }(); return v; }
 static int wave_tile_max_k() { static const int v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MAX_K"); return e ? atoi(e) : 1024; }(); return v; }
 
 static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool want_tile64, bool force_tile64) {
@@ -752,9 +871,14 @@ static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool
     // a tile per wave: enough tiles to give every SIMD of the chip one and a half of them, and a contraction short enough that splitting it
     // eight ways leaves a wave nothing to do (tools/bench_gemm.py: dW1 of two heads at 256 rows 22.3 -> see DESIGN.md section 4.3)
     const long long tiles32 = (long long)((d->M + 31) / 32) * ((d->N + 31) / 32) * d->batch;
-    if (p.cfg == 0 && tiles32 >= wave_tile_min_tiles() && d->K <= wave_tile_max_k()) p.cfg = 2;
+    if (p.cfg == 0 && tiles32 >= wave_tile_min_tiles() && d->K <= wave_tile_max_k()) {
+        // two row blocks per wave from 8-byte loads where A is contiguous along its rows and pairs of rows never straddle anything
+        const bool pairs = wave_tile_pairs() && d->a_stride_m == 1 && d->M % 2 == 0 && d->M >= 2 && reinterpret_cast<uintptr_t>(p.A) % 8 == 0 &&
+                           d->a_stride_k % 2 == 0 && p.a_bs % 2 == 0;
+        p.cfg = pairs ? 3 : 2;
+    }
     const int t = p.cfg == 1 ? 64 : 32;
-    const int tn = p.cfg == 2 ? 128 : t, tm = p.cfg == 2 ? 64 : t;       // a workgroup's block of the output
+    const int tn = p.cfg >= 2 ? 128 : t, tm = p.cfg == 3 ? 128 : p.cfg == 2 ? 64 : t;       // a workgroup's block of the output
     p.wg_n = (p.N + tn - 1) / tn;
     const int wg_m = (p.M + tm - 1) / tm;
     p.wg_nm = p.wg_n * wg_m;

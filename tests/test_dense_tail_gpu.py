@@ -61,9 +61,11 @@ def test_linear_backward_and_batched(cuda, gemm_path, M, K, N):
     np.testing.assert_allclose(DWB[:, :, K].cpu().numpy(), ref_db.numpy(), atol=2e-4, rtol=1e-5)
 
 
-@pytest.mark.parametrize("M,N,K,kind", [(1000, 1100, 200, "epilogue"), (1024, 1025, 256, "ones"), (1500, 1030, 33, "accumulate")])
+@pytest.mark.parametrize("M,N,K,kind", [(1000, 1100, 200, "epilogue"), (1024, 1025, 256, "ones"), (1500, 1030, 33, "accumulate"),
+                                        (1001, 1100, 200, "epilogue"), (1023, 1025, 250, "ones"), (1501, 1030, 40, "accumulate")])
 def test_tile_per_wave_path_with_every_epilogue(cuda, M, N, K, kind):
-    """Problems with >= 1 536 tiles of 32 x 32 and K <= 1 024 run a tile per WAVE (dense.hip cfg 2: the heads' weight gradients): ragged
+    """Problems with >= 1 536 tiles of 32 x 32 and K <= 1 024 run a tile per WAVE (dense.hip cfg 2; cfg 3 -- two row blocks per wave from
+    8-byte loads -- when A is contiguous along an EVEN number of rows: the heads' weight gradients): ragged
     M / N / K (waves whose tile lies outside leave, the last k chunk is partial), bias + ReLU + mask, the ones column with its separate
     destination, accumulation into C -- against float64."""
     from pointcloud_rl_amd import hip
