@@ -210,6 +210,7 @@ class FusedStep:
         # 12.0 us, its step 0.9873 -> 0.9772 ms, tools/r4_ab15.sh).  The backward tail replaces FOUR launches (~28 us): 16 384.
         self.policy_tail_max_split = int(_env_max) if _env_max else int(__import__("os").environ.get("PCRL_TAIL_FWD_MAX_SPLIT", "24576"))
         self.policy_tail_bwd_max_split = int(_env_max) if _env_max else 16384
+        self.tail_split_rows = int(__import__("os").environ.get("PCRL_TAIL_SPLIT_MAX", "512"))     # the same variable csrc/headtail.hip reads
         self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
         self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
         self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
@@ -219,7 +220,7 @@ class FusedStep:
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
-        split = self.H == 1024 and M <= 512        # the row-split kernels' domain (headtail.hip: PCRL_TAIL_SPLIT_MAX)
+        split = self.H == 1024 and M <= self.tail_split_rows        # the row-split kernels' domain (headtail.hip: PCRL_TAIL_SPLIT_MAX)
         return M * 2 * self.A <= ((self.policy_tail_bwd_max_split if bwd else self.policy_tail_max_split) if split else self.policy_tail_max)
 
     def _buf(self, name, *shape, dtype=torch.float32):
