@@ -210,6 +210,46 @@ def test_rccl_single_rank_exchange_equals_plain_step(cuda, graphs, capture):
             assert ra[k] == rb[k] or (np.isnan(ra[k]) and np.isnan(rb[k])), k
 
 
+def _probe_worker(rank, port, break_replay, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PCRL_EXCHANGE_SINGLE_RANK="1")
+    os.environ.pop("PCRL_CAPTURE_EXCHANGE", None)
+    import warnings
+    import torch.distributed as dist
+    from pointcloud_rl_amd.utils import dist as du
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    if break_replay:                       # a stack whose replayed graph fails: the probe must say so and select the segmented schedule
+        def boom(self):
+            raise RuntimeError("HIP error: simulated failure of a replayed graph holding a collective")
+        torch.cuda.CUDAGraph.replay = boom
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        verdict = du.capture_exchange()
+    again = du.capture_exchange()
+    x = torch.ones(8, device="cuda")
+    dist.all_reduce(x)                      # the process group is still usable
+    torch.cuda.synchronize()
+    torch.save(dict(verdict=verdict, again=again, env=os.environ.get("PCRL_CAPTURE_EXCHANGE"), warned=[str(w.message) for w in caught],
+                    x=x.cpu()), os.path.join(out, "probe.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_replay", [False, True], ids=["works", "replay-fails"])
+def test_captured_allreduce_probe_selects_the_schedule(cuda, break_replay):
+    """utils/dist.py::capture_exchange asks ONCE whether an RCCL all-reduce inside a replayed hipGraph works (one small captured
+    all-reduce, replayed and checked, the verdict agreed between the ranks): yes -> the exchanging step is captured whole; a replay
+    that fails -> a warning, PCRL_CAPTURE_EXCHANGE=0 for the rest of the process (eager all-reduces between per-segment graphs), and
+    the process group stays usable -- instead of a rank that ends with exit code 75 at its first replayed step."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as out:
+        mp.spawn(_probe_worker, args=(_free_port(), break_replay, out), nprocs=1, join=True)
+        r = torch.load(os.path.join(out, "probe.pt"))
+    assert r["verdict"] == r["again"] == (not break_replay)
+    assert r["env"] == ("0" if break_replay else None)
+    assert any("does not work on this stack" in w for w in r["warned"]) == break_replay
+    assert torch.equal(r["x"], torch.ones(8))
+
+
 def test_bench_single_rank_exchange_over_rccl(cuda):
     """bench.py's data-parallel leg (process group, to_ddp, segmented graphs, comm / no-comm timing) over RCCL with one rank."""
     import json
