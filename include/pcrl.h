@@ -330,12 +330,20 @@ int pcrl_gemm_f32(const pcrl_gemm_desc* d, void* stream);
 /* Up to 4 INDEPENDENT problems in one launch (no problem may read what another writes): dW and dx of
  * one layer, or the online and target Q heads of one layer.  Same per-problem semantics as above. */
 int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
-/* Tuning knob (tests, benchmarks): a launch runs its long-K forward-shaped problems (M, N >= 48, K >= 512, both operands
- * k-contiguous and 16-byte readable) as LDS-staged 64x64 tiles when together they make at least `min_tiles` workgroups,
- * otherwise as 32x32 split-K tiles; min_tiles <= 1 forces the staged tiles for every problem they can compute (K >= 64,
- * any operand orientation).  The results of the two paths agree to fp32 summation order.  Returns the previous value
- * (default 192, or the environment variable PCRL_GEMM_TILE64_MIN); a negative argument only queries. */
+/* How a launch picks the tile path of each problem (csrc/dense.hip, csrc/dense_wtile.h); the results of all paths agree to fp32
+ * summation order.  By default: forward-shaped (A, B k-contiguous) and data-gradient-shaped (A k-contiguous, B contiguous along n)
+ * problems with K >= 128, K % 4 == 0 run as wave-private staged tiles of 16 x 16 ... 32 x 64 outputs -- the finest shape that still
+ * gives the chip at most one workgroup per CU --, weight-gradient-shaped ones (both operands contiguous along their row index, M and
+ * the real column count multiples of 4 and >= 64) as LDS panels of 64 x 64 / 64 x 128 outputs, the largest forward-shaped problems as
+ * LDS-staged 64 x 64 tiles when the launch has at least `min_tiles` of them (default 192), everything else as 32 x 32 split-K tiles.
+ * Knob for tests and benchmarks: min_tiles <= 1 forces the 64 x 64 staged tiles for every problem they can compute (M, N >= 48,
+ * K >= 64, any operand orientation); min_tiles >= 2^30 selects the paths of rounds 1-4 only (32 x 32 split-K tiles, a tile per wave
+ * for the weight gradients).  Returns the previous value; a negative argument only queries. */
 int pcrl_gemm_set_tile64_min(int32_t min_tiles);
+/* What pcrl_gemm_group_f32 would launch for these problems, without launching: out[3 i .. 3 i + 2] = {path, tile shape, workgroups}
+ * of problem i (path: 0 32 x 32 split-K, 1 64 x 64 staged, 2 / 3 a tile per wave, 4 wave-private staged tiles, 5 weight-gradient
+ * panels; -1 for an empty problem).  Tests assert with it that a shape reaches the path they mean to cover. */
+int pcrl_gemm_group_plan_f32(const pcrl_gemm_desc* descs, int32_t n, int32_t* out);
 
 /* Row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1] = nn.LayerNorm(out), pointnet.py:110).
  * The result is written to n_dst <= 4 destinations (dst[i] with leading dimension ld_dst[i]): the

@@ -123,7 +123,7 @@ class RandomJitterPoints(_PointAug):
         """shared_counter: device int64 [1] tensor that changes exactly once per update step before the step's encoder launches
         (None: every call advances its own counter, as outside update steps)."""
         assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1)
-        self._shared, self._slot, self._predrawn = shared_counter, 0, None
+        self._shared, self._slot = shared_counter, 0
 
     def __repr__(self):
         return f"{type(self).__name__}(jitter_range={self.jitter_range},"
@@ -337,7 +337,7 @@ class GlobalRotScaleTrans(_PointAug):
         """shared_counter: device int64 [1] tensor the step advances once before its encoder launches (DeviceReplay.state[:1]);
         None: every call draws with torch's generator, as the reference does."""
         assert shared_counter is None or (shared_counter.dtype == torch.int64 and shared_counter.numel() == 1)
-        self._shared, self._slot = shared_counter, 0
+        self._shared, self._slot, self._predrawn = shared_counter, 0, None     # a pair drawn ahead never outlives its step
 
     def __repr__(self):
         return (f"{type(self).__name__}(rot_range={self.rot_range}, scale_ratio_range={self.scale_ratio_range}, "

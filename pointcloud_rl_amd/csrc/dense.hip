@@ -41,7 +41,9 @@ struct GemmParams {
     int ones_col;            // B[k][ones_col] == 1 for every k (bias gradient); -1: none
     int accumulate;          // C += result
     int a_k4, b_k4;          // operand is k-contiguous and 16-byte aligned
-    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS; 2: a 32x32 tile per WAVE; 3: 64x32 per wave
+    int cfg;                 // 0: 32x32 tile per workgroup, K split over the 8 waves; 1: 64x64 tile staged through LDS; 2: a 32x32 tile per WAVE; 3: 64x32 per wave;
+                             // 4: wave-private staged tiles (dense_wtile.h: gemm_wtile); 5: weight-gradient panels (gemm_wgrad_panel)
+    int shape;               // cfg 4 / 5: which tile shape (kWTile* / kWPanel* below)
     int a_rc, b_rc;          // cfg 1: operand is contiguous along its row index (m resp. n) instead of along k
     int wg_n, wg_nm;         // n tiles, n tiles * m tiles
     float inv_wg_n, inv_wg_nm, inv_wg_m;
@@ -87,6 +89,10 @@ __device__ __forceinline__ T* uniform_ptr(T* ptr) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
+
+}  // namespace pcrl
+#include "dense_wtile.h"
+namespace pcrl {
 
 __device__ __forceinline__ void gemm_mfma16(const f32x4 (&a)[4], const f32x4 (&b)[4], f32x16& acc) {
 #pragma unroll
@@ -685,6 +691,13 @@ __device__ __forceinline__ void gemm_tile64(const GemmParams& p, const int wg, f
     }
 }
 
+// cfg 4 tile shapes: E x (BM, BN) blocks; a row-contiguous B (data gradient) takes the transposed 2-block shape and has no 32 x 64 one
+__host__ __device__ constexpr int wtile_shapes(int brc) { return brc ? 3 : 4; }
+__host__ __device__ constexpr int wtile_tm(int shape, int brc) { return shape == 0 ? 16 : shape == 1 ? (brc ? 32 : 16) : 32; }
+__host__ __device__ constexpr int wtile_tn(int shape, int brc) { return shape == 0 ? 16 : shape == 1 ? (brc ? 16 : 32) : shape == 2 ? 32 : 64; }
+// cfg 5 panel shapes: 0 = 64 x 128 (no split-K), 1 = 64 x 64 (two k halves)
+__host__ __device__ constexpr int wpanel_tn(int shape) { return shape == 0 ? 128 : 64; }
+
 __global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     const int wg = blockIdx.x;
@@ -693,10 +706,36 @@ __global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const Gemm
     for (int j = 1; j < kGemmGroup; ++j)
         if (j < g.n && wg >= g.wg_begin[j]) gi = j;
     const GemmParams p = g.p[gi];
-    if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
+    if (p.cfg == 4) {
+        if (!p.b_rc) {
+            if (p.shape == 0) gemm_wtile<16, 1, 1, 32, false, 2>(p, wg, gemm_smem);
+            else if (p.shape == 1) gemm_wtile<16, 1, 2, 32, false, 2>(p, wg, gemm_smem);
+            else if (p.shape == 2) gemm_wtile<32, 1, 1, 16, false, 2>(p, wg, gemm_smem);
+            else gemm_wtile<32, 1, 2, 16, false, 1>(p, wg, gemm_smem);
+        } else {
+            if (p.shape == 0) gemm_wtile<16, 1, 1, 32, true, 2>(p, wg, gemm_smem);
+            else if (p.shape == 1) gemm_wtile<16, 2, 1, 32, true, 2>(p, wg, gemm_smem);
+            else gemm_wtile<32, 1, 1, 16, true, 2>(p, wg, gemm_smem);      // (a 32 x 64 tile of this kind spills at 128 registers and measured no faster)
+        }
+    } else if (p.cfg == 5) {
+        if (p.shape == 0) gemm_wgrad_panel<2, 4, 32>(p, wg, gemm_smem);
+        else gemm_wgrad_panel<2, 2, 64>(p, wg, gemm_smem);
+    } else if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
     else if (p.cfg == 2) gemm_tile32_wave(p, wg);
     else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
     else gemm_tile32_splitk(p, wg, gemm_smem);
+}
+
+static size_t gemm_lds_bytes(const GemmParams& p) {
+    if (p.cfg == 4) {
+        if (!p.b_rc) return p.shape == 0 ? WTile<16, 1, 1, 32, false>::lds_bytes() : p.shape == 1 ? WTile<16, 1, 2, 32, false>::lds_bytes()
+                          : p.shape == 2 ? WTile<32, 1, 1, 16, false>::lds_bytes() : WTile<32, 1, 2, 16, false>::lds_bytes();
+        return p.shape == 0 ? WTile<16, 1, 1, 32, true>::lds_bytes() : p.shape == 1 ? WTile<16, 2, 1, 32, true>::lds_bytes()
+                            : WTile<32, 1, 1, 16, true>::lds_bytes();
+    }
+    if (p.cfg == 5) return p.shape == 0 ? WPanel<2, 4, 32>::lds_bytes() : WPanel<2, 2, 64>::lds_bytes();
+    if (p.cfg == 1) return kGemmLdsBytes;
+    return p.cfg == 0 ? kGemmLdsBytes32 : 0;
 }
 
 // Row-wise LayerNorm over a short feature vector (PointNet.final_mlp[1]: nn.LayerNorm(out), eps 1e-5,
@@ -824,11 +863,34 @@ __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float
 
 using namespace pcrl;
 
-static long long wave_tile_min_tiles() { static const long long v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MIN"); return e ? atoll(e) : 1536ll; }(); return v; }
-static bool wave_tile_pairs() { static const bool v = [] { const char* e = getenv("PCRL_GEMM_WAVE_PAIRS"); return !e || atoi(e) != 0; }(); return v; }
-static int wave_tile_max_k() { static const int v = [] { const char* e = getenv("PCRL_GEMM_WAVE_TILES_MAX_K"); return e ? atoi(e) : 1024; }(); return v; }
+// a tile per wave (cfg 2 / 3, the legacy weight-gradient path): from this many 32 x 32 tiles, up to this K
+constexpr long long kWaveTileMinTiles = 1536;
+constexpr int kWaveTileMaxK = 1024;
 
-static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool want_tile64, bool force_tile64) {
+// How a launch picks its tile paths (pcrl_gemm_set_tile64_min):
+//   auto (default)   the wave-private staged tiles / weight-gradient panels of dense_wtile.h wherever an operand layout allows them, the
+//                    LDS-staged 64 x 64 tiles for the largest problems, the 32 x 32 split-K tiles for the rest (short K, odd strides);
+//   min_tiles <= 1   the 64 x 64 tiles forced for every problem they can compute (tests: every orientation);
+//   min_tiles >= 2^30  the paths of rounds 1-4 only: 32 x 32 split-K tiles and a tile per wave (tests keep them covered: they serve every
+//                    shape the newer paths decline).
+static std::atomic<int> g_tile64_min{192};
+static int tile64_min_tiles() { return g_tile64_min.load(std::memory_order_relaxed); }
+static bool legacy_only() { return tile64_min_tiles() >= (1 << 30); }
+
+extern "C" int pcrl_gemm_set_tile64_min(int32_t min_tiles) {
+    const int prev = tile64_min_tiles();
+    if (min_tiles >= 0) g_tile64_min.store(min_tiles, std::memory_order_relaxed);
+    return prev;
+}
+
+struct GemmPlan {
+    bool kind_f, kind_x, kind_w;     // forward-shaped / data-gradient-shaped / weight-gradient-shaped for the dense_wtile.h paths
+    bool t64_ok;                     // computable by the 64 x 64 staged tiles
+    bool t64_pays;                   // ... and the rounds-2/3 measurements say they pay (given enough tiles in the launch)
+    bool a_kc, b_kc;
+};
+
+static int gemm_fill_common(const pcrl_gemm_desc* d, GemmParams& p, GemmPlan& pl) {
     if (!d->A || !d->B || !d->C) return fail(PCRL_E_ARG, "NULL argument");
     if (d->M < 0 || d->N < 0 || d->K < 0 || d->batch < 1) return fail(PCRL_E_ARG, "bad GEMM shape");
     p = GemmParams{};
@@ -855,71 +917,62 @@ static int gemm_fill(const pcrl_gemm_desc* d, GemmParams& p, int& wg_total, bool
     p.a_k4 = d->a_stride_k == 1 && aligned(p.A, d->a_stride_m, p.a_bs);
     p.b_k4 = d->b_stride_k == 1 && aligned(p.B, d->b_stride_n, p.b_bs);
     // 64x64 LDS-staged tiles: all three dimensions large, both operands readable in 16-byte pieces in one of the two orientations
-    const bool a_kc = p.a_k4 && d->a_stride_m >= d->K, a_rc = d->a_stride_m == 1 && aligned(p.A, d->a_stride_k, p.a_bs);
-    const bool b_kc = p.b_k4 && d->b_stride_n >= d->K, b_rc = d->b_stride_n == 1 && aligned(p.B, d->b_stride_k, p.b_bs);
-    // Measured (tools/bench_gemm.py, MI355X): the staged tiles win where K is long and both operands are k-contiguous (the
-    // forward layers: 4 heads x 256x1024x1024 in 24.7 us against 32.7 us); the gradient GEMMs -- short K (dW: K = batch) or
-    // a row-contiguous operand read from LDS four bytes at a time (dX) -- are faster as 32x32 split-K tiles at four
-    // workgroups per CU -- unless the caller forces the path (force_tile64: tests exercise every orientation).
+    pl.a_kc = p.a_k4 && d->a_stride_m >= d->K;
+    pl.b_kc = p.b_k4 && d->b_stride_n >= d->K;
+    const bool a_rc = d->a_stride_m == 1 && aligned(p.A, d->a_stride_k, p.a_bs);
+    const bool b_rc = d->b_stride_n == 1 && aligned(p.B, d->b_stride_k, p.b_bs);
     const bool big = d->M >= 48 && d->N >= 48 && d->K >= 64;
-    // ... and the data gradient (dY k-contiguous, W row-contiguous) once the batch gives it several hundred tiles of its own
-    // (two heads of 1 024 rows: 43.6 us staged against 56.2 us; 512 rows tie; 256 rows lose 25.6 to 15.2)
+    pl.t64_ok = big && (pl.a_kc || a_rc) && (pl.b_kc || b_rc);
+    // Measured (tools/bench_gemm.py, rounds 2-3): the staged 64 x 64 tiles win where K is long and both operands are k-contiguous, and for the
+    // data gradient (dY k-contiguous, W row-contiguous) once the batch gives it several hundred tiles of its own.
     const long long own_tiles64 = (long long)((d->M + 63) / 64) * ((d->N + 63) / 64) * d->batch;
-    const bool pays = force_tile64 || (a_kc && b_kc && d->K >= 512) || (a_kc && b_rc && d->K >= 512 && own_tiles64 >= 384);
-    p.cfg = (want_tile64 && big && pays && (a_kc || a_rc) && (b_kc || b_rc)) ? 1 : 0;
-    p.a_rc = !a_kc; p.b_rc = !b_kc;
-    // a tile per wave: enough tiles to give every SIMD of the chip one and a half of them, and a contraction short enough that splitting it
-    // eight ways leaves a wave nothing to do (tools/bench_gemm.py: dW1 of two heads at 256 rows 22.3 -> see DESIGN.md section 4.3)
-    const long long tiles32 = (long long)((d->M + 31) / 32) * ((d->N + 31) / 32) * d->batch;
-    if (p.cfg == 0 && tiles32 >= wave_tile_min_tiles() && d->K <= wave_tile_max_k()) {
-        // two row blocks per wave from 8-byte loads where A is contiguous along its rows and pairs of rows never straddle anything
-        const bool pairs = wave_tile_pairs() && d->a_stride_m == 1 && d->M % 2 == 0 && d->M >= 2 && reinterpret_cast<uintptr_t>(p.A) % 8 == 0 &&
-                           d->a_stride_k % 2 == 0 && p.a_bs % 2 == 0;
-        p.cfg = pairs ? 3 : 2;
-    }
-    const int t = p.cfg == 1 ? 64 : 32;
-    const int tn = p.cfg >= 2 ? 128 : t, tm = p.cfg == 3 ? 128 : p.cfg == 2 ? 64 : t;       // a workgroup's block of the output
-    p.wg_n = (p.N + tn - 1) / tn;
+    pl.t64_pays = (pl.a_kc && pl.b_kc && d->K >= 512) || (pl.a_kc && b_rc && d->K >= 512 && own_tiles64 >= 384);
+    p.a_rc = !pl.a_kc; p.b_rc = !pl.b_kc;
+    // dense_wtile.h: A staged in 16-byte pieces along k (K % 4 == 0: a piece lies inside K or outside), a contraction long enough to give
+    // the eight k slices something to do, no column of ones
+    const bool a_stage = pl.a_kc && d->K % 4 == 0 && d->K >= 128 && d->ones_col < 0 && d->M > 0 && d->N > 0;
+    pl.kind_f = a_stage && pl.b_kc;
+    pl.kind_x = a_stage && !pl.b_kc && d->b_stride_n == 1;
+    // ... weight gradient: both operands contiguous along their row index and readable in 16-byte pieces of four rows, the ones column last
+    const int n_real = d->ones_col >= 0 ? d->ones_col : d->N;
+    pl.kind_w = a_rc && b_rc && d->M % 4 == 0 && n_real % 4 == 0 && d->M >= 64 && n_real >= 64 && d->K >= 1 &&
+                (d->ones_col < 0 || d->ones_col == d->N - 1);
+    return PCRL_OK;
+}
+
+static void gemm_set_tiles(GemmParams& p, int tm, int tn, int n_cols, int batch, int& wg_total) {
+    p.wg_n = (n_cols + tn - 1) / tn;
     const int wg_m = (p.M + tm - 1) / tm;
     p.wg_nm = p.wg_n * wg_m;
     p.inv_wg_n = 1.0f / (float)(p.wg_n > 0 ? p.wg_n : 1);
     p.inv_wg_nm = 1.0f / (float)(p.wg_nm > 0 ? p.wg_nm : 1);
     p.inv_wg_m = 1.0f / (float)(wg_m > 0 ? wg_m : 1);
     p.wg_begin = wg_total;
-    p.tiles = p.wg_nm * d->batch;
+    p.tiles = p.wg_nm * batch;
     wg_total += p.tiles;
-    return PCRL_OK;
 }
 
-// Problems of a launch that could run as 64x64 tiles do so when together they give the chip enough workgroups: a 64x64
-// tile moves half the L2 bytes per FLOP of four 32x32 split-K tiles but is a quarter of the parallelism.
-static std::atomic<int> g_tile64_min{-1};
-static int tile64_min_tiles() {
-    int v = g_tile64_min.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("PCRL_GEMM_TILE64_MIN");
-        v = e ? atoi(e) : 192;
-        g_tile64_min.store(v, std::memory_order_relaxed);
+// The legacy choice between cfg 0 / 2 / 3 for a problem that is not a 64 x 64 one
+static void gemm_pick_legacy(const pcrl_gemm_desc* d, GemmParams& p, int& tm, int& tn) {
+    p.cfg = 0;
+    const long long tiles32 = (long long)((d->M + 31) / 32) * ((d->N + 31) / 32) * d->batch;
+    if (tiles32 >= kWaveTileMinTiles && d->K <= kWaveTileMaxK) {
+        // two row blocks per wave from 8-byte loads where A is contiguous along its rows and pairs of rows never straddle anything
+        const bool pairs = d->a_stride_m == 1 && d->M % 2 == 0 && d->M >= 2 && reinterpret_cast<uintptr_t>(p.A) % 8 == 0 &&
+                           d->a_stride_k % 2 == 0 && p.a_bs % 2 == 0;
+        p.cfg = pairs ? 3 : 2;
     }
-    return v;
+    tn = p.cfg >= 2 ? 128 : 32;
+    tm = p.cfg == 3 ? 128 : p.cfg == 2 ? 64 : 32;               // a workgroup's block of the output
 }
 
-extern "C" int pcrl_gemm_set_tile64_min(int32_t min_tiles) {
-    const int prev = tile64_min_tiles();
-    if (min_tiles >= 0) g_tile64_min.store(min_tiles, std::memory_order_relaxed);
-    return prev;
-}
-
-extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream) {
+// Tile paths, workgroup ranges and the LDS size of one launch; src[i] = the caller's index of the launch's i-th problem.
+static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_t& lds, int& wg_total, int (&src)[kGemmGroup]) {
     if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
-    GemmGroup g{};
-    int wg_total = 0;
     // Workgroups are dispatched in index order: a problem with a long K loop and few tiles (the data gradient of a small batch:
     // K = 1 024, <= 256 tiles) goes first, so that its few long workgroups start at once and the many short ones of its
-    // partner (the weight gradient, K = batch) fill in around them.  Measured (tools/bench_gemm.py, MI355X), dW1 | dh1 of
-    // two heads as [dW, dX] -> [dX, dW]: 32 rows 19.1 -> 14.3 us, 64 rows 20.0 -> 17.7, 128 rows 26.4 -> 22.0; one head of
-    // 256 rows 22.2 -> 19.8; from 512 tiles of the long problem up the order is neutral to -4 % and stays as given.
-    // The problems of a launch are independent, so the order changes no result.
+    // partner (the weight gradient, K = batch) fill in around them (round 3, tools/bench_gemm.py).  The problems of a launch are
+    // independent, so the order changes no result.
     int order[kGemmGroup], n_first = 0;
     bool first[kGemmGroup];
     for (int i = 0; i < n; ++i) {
@@ -930,28 +983,90 @@ extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void*
     }
     for (int i = 0, k = n_first; i < n; ++i)
         if (!first[i]) order[k++] = i;
-    for (int pass = 0; pass < 2; ++pass) {          // pass 0: everything eligible as 64x64 tiles; pass 1 (too few of them): 32x32
-        g = GemmGroup{};
-        wg_total = 0;
-        int tiles64 = 0;
-        for (int oi = 0; oi < n; ++oi) {
-            const int i = order[oi];
-            const int rc = gemm_fill(&descs[i], g.p[g.n], wg_total, pass == 0, tile64_min_tiles() <= 1);
-            if (rc != PCRL_OK) return rc;
-            g.wg_begin[g.n] = g.p[g.n].wg_begin;
-            if (g.p[g.n].cfg == 1) tiles64 += g.p[g.n].wg_nm * descs[i].batch;
-            if (descs[i].M > 0 && descs[i].N > 0) ++g.n;        // empty problems contribute no workgroups
-        }
-        if (pass == 1 || tiles64 == 0 || tiles64 >= tile64_min_tiles()) break;
+
+    g = GemmGroup{};
+    GemmPlan plan[kGemmGroup];
+    const pcrl_gemm_desc* dd[kGemmGroup];
+    for (int oi = 0; oi < n; ++oi) {
+        const pcrl_gemm_desc* d = &descs[order[oi]];
+        if (int rc = gemm_fill_common(d, g.p[g.n], plan[g.n])) return rc;
+        dd[g.n] = d; src[g.n] = order[oi];
+        if (d->M > 0 && d->N > 0) ++g.n;        // empty problems contribute no workgroups
     }
-    if (g.n == 0 || wg_total == 0) return PCRL_OK;
+    wg_total = 0; lds = 0;
+    if (g.n == 0) return PCRL_OK;
+    const bool legacy = legacy_only(), force64 = tile64_min_tiles() <= 1;
+    const int cus = num_cus();
+    // 64 x 64 staged tiles: everything eligible (forced), or what pays -- if the launch then has enough of them to fill the chip
+    bool use64[kGemmGroup];
+    int tiles64 = 0;
+    for (int i = 0; i < g.n; ++i) {
+        use64[i] = !legacy && plan[i].t64_ok && (force64 || plan[i].t64_pays);
+        if (use64[i]) tiles64 += ((dd[i]->M + 63) / 64) * ((dd[i]->N + 63) / 64) * dd[i]->batch;
+    }
+    if (!force64 && tiles64 < tile64_min_tiles())
+        for (int i = 0; i < g.n; ++i) use64[i] = false;
+    for (int i = 0; i < g.n; ++i) {
+        const pcrl_gemm_desc* d = dd[i];
+        GemmParams& p = g.p[i];
+        int tm = 32, tn = 32, n_cols = d->N;
+        const bool wt = !legacy && !force64 && (plan[i].kind_f || plan[i].kind_x);
+        if (wt) {
+            // the finest tile shape that still gives the chip at most one workgroup per CU (measured, tools/probes/gemm_staged.hip: a launch
+            // is fastest with the largest number of workgroups <= #CUs); beyond the coarsest shape, the 64 x 64 staged tiles where they pay
+            const int brc = plan[i].kind_x ? 1 : 0;
+            const int n_shapes = wtile_shapes(brc);
+            int shape = n_shapes - 1;
+            long long wgs_coarsest = 0;
+            for (int sh = 0; sh < n_shapes; ++sh) {
+                const long long wgs = (long long)((d->M + wtile_tm(sh, brc) - 1) / wtile_tm(sh, brc)) * ((d->N + wtile_tn(sh, brc) - 1) / wtile_tn(sh, brc)) * d->batch;
+                wgs_coarsest = wgs;
+                if (wgs <= cus) { shape = sh; break; }
+            }
+            if (shape == n_shapes - 1 && wgs_coarsest > cus && use64[i]) {
+                p.cfg = 1; tm = tn = 64;
+            } else {
+                p.cfg = 4; p.shape = shape; p.b_rc = brc; tm = wtile_tm(shape, brc); tn = wtile_tn(shape, brc);
+            }
+        } else if (!legacy && !force64 && plan[i].kind_w) {
+            const int n_real = d->ones_col >= 0 ? d->ones_col : d->N;
+            const long long wgs64 = (long long)((d->M + 63) / 64) * ((n_real + 63) / 64) * d->batch;
+            p.cfg = 5; p.shape = wgs64 <= cus ? 1 : 0;
+            tm = 64; tn = wpanel_tn(p.shape); n_cols = n_real;
+        } else if (use64[i]) {
+            p.cfg = 1; tm = tn = 64;
+        } else {
+            gemm_pick_legacy(d, p, tm, tn);
+        }
+        gemm_set_tiles(p, tm, tn, n_cols, d->batch, wg_total);
+        g.wg_begin[i] = p.wg_begin;
+        const size_t need = gemm_lds_bytes(p);
+        lds = need > lds ? need : lds;
+    }
     if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), kGemmLdsBytes)) return rc;
-    bool any64 = false;
-    for (int i = 0; i < g.n; ++i) any64 = any64 || g.p[i].cfg == 1;
-    const size_t lds = any64 ? kGemmLdsBytes : kGemmLdsBytes32;      // a launch of 32x32 tiles only keeps several workgroups per CU
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream) {
+    GemmGroup g;
+    size_t lds;
+    int wg_total, src[kGemmGroup];
+    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src)) return rc;
+    if (g.n == 0 || wg_total == 0) return PCRL_OK;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), 160 * 1024)) return rc;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
     PCRL_CHECK_LAUNCH("gemm_f32_kernel");
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_gemm_group_plan_f32(const pcrl_gemm_desc* descs, int32_t n, int32_t* out) {
+    if (!out) return fail(PCRL_E_ARG, "NULL argument");
+    GemmGroup g;
+    size_t lds;
+    int wg_total, src[kGemmGroup];
+    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src)) return rc;
+    for (int i = 0; i < n; ++i) { out[3 * i] = -1; out[3 * i + 1] = 0; out[3 * i + 2] = 0; }
+    for (int i = 0; i < g.n; ++i) { out[3 * src[i]] = g.p[i].cfg; out[3 * src[i] + 1] = g.p[i].shape; out[3 * src[i] + 2] = g.p[i].tiles; }
     return PCRL_OK;
 }
 

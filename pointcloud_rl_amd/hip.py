@@ -381,6 +381,15 @@ def gemm_group(descs):
         check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
 
 
+def gemm_plan(descs):
+    """[(path, tile shape, workgroups)] pcrl_gemm_group_f32 would use for these problems (include/pcrl.h: pcrl_gemm_group_plan_f32)."""
+    descs = [d for d in descs if d is not None]
+    arr = (GemmDesc * len(descs))(*descs)
+    out = (ctypes.c_int32 * (3 * len(descs)))()
+    check(lib().pcrl_gemm_group_plan_f32(arr, len(descs), out))
+    return [tuple(out[3 * i:3 * i + 3]) for i in range(len(descs))]
+
+
 def gemm_set_tile64_min(min_tiles):
     """Tuning knob of pcrl_gemm_group_f32 (include/pcrl.h): minimum number of 64x64 tiles in a launch for the LDS-staged
     path; returns the previous value (negative argument: query only)."""

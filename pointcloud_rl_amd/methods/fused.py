@@ -285,7 +285,7 @@ class FusedStep:
         # Measured on MI355X (tools/r4_ab6.sh, same box, initial training state): a rank's 32-cloud share of K1 (A = 6) 0.3318 -> 0.3275 ms,
         # K1 itself 0.8440 -> 0.8459 (neutral: one launch and two graph nodes fewer, the tail 2.3 us longer), K3's 128-cloud share
         # (A = 22: 44 KB of action columns per row) 0.6753 -> 0.6807 -- so only for small action spaces.
-        return (self.tails and self.fold_q0 and self.H == 1024 and M <= 512 and self.A <= self.fold_max_a and self._policy_tail_fits(M)
+        return (self.tails and self.fold_q0 and self.H == 1024 and M <= self.tail_split_rows and self.A <= self.fold_max_a and self._policy_tail_fits(M)
                 and group in (1, 2, 4))
 
     def _actor_forward(self, XA, M, tag, act_dst, ld_act, save, extra_l0=(), fold=None):

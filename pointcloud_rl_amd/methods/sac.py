@@ -683,6 +683,8 @@ class SAC(BaseAgent):
             return dict(calls=[t.calls for t in jitters], slots=[getattr(t, "_slot", 0) for t in jitters])
         for t, c, sl in zip(jitters, restore["calls"], restore["slots"]):
             t.calls, t._slot = c, sl
+            if hasattr(t, "_predrawn"):
+                t._predrawn = None          # matrices drawn ahead inside the aborted capture belong to a graph that is thrown away
         if self._fused is not None:
             self._fused._forked = False
             self._fused._entry_cols = None

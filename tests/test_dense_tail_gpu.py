@@ -15,8 +15,9 @@ def T(a, dev):
 
 @pytest.fixture(params=["auto", "tile64", "tile32"])
 def gemm_path(request):
-    """Run a GEMM test on the default tile selection, with the LDS-staged 64x64 tiles forced wherever a problem is
-    eligible, and with them disabled (32x32 split-K everywhere)."""
+    """Run a GEMM test on the default tile selection (round 5: wave-private staged tiles / weight-gradient panels wherever the operand
+    layout allows), with the LDS-staged 64x64 tiles forced wherever a problem is eligible, and on the paths of rounds 1-4 only
+    (32x32 split-K tiles, a tile per wave)."""
     from pointcloud_rl_amd import hip
     prev = hip.gemm_set_tile64_min({"auto": -1, "tile64": 1, "tile32": 1 << 30}[request.param])
     yield request.param
@@ -61,32 +62,53 @@ def test_linear_backward_and_batched(cuda, gemm_path, M, K, N):
     np.testing.assert_allclose(DWB[:, :, K].cpu().numpy(), ref_db.numpy(), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("path", ["auto", "legacy"])
 @pytest.mark.parametrize("M,N,K,kind", [(1000, 1100, 200, "epilogue"), (1024, 1025, 256, "ones"), (1500, 1030, 33, "accumulate"),
-                                        (1001, 1100, 200, "epilogue"), (1023, 1025, 250, "ones"), (1501, 1030, 40, "accumulate")])
-def test_tile_per_wave_path_with_every_epilogue(cuda, M, N, K, kind):
-    """Problems with >= 1 536 tiles of 32 x 32 and K <= 1 024 run a tile per WAVE (dense.hip cfg 2; cfg 3 -- two row blocks per wave from
-    8-byte loads -- when A is contiguous along an EVEN number of rows: the heads' weight gradients): ragged
-    M / N / K (waves whose tile lies outside leave, the last k chunk is partial), bias + ReLU + mask, the ones column with its separate
-    destination, accumulation into C -- against float64."""
+                                        (1001, 1100, 200, "epilogue"), (1023, 1025, 250, "ones"), (1501, 1030, 40, "accumulate"),
+                                        (1024, 1025, 32, "ones"), (64, 129, 100, "ones"), (2048, 1024, 512, "accumulate")])
+def test_weight_gradient_paths_with_every_epilogue(cuda, path, M, N, K, kind):
+    """Weight-gradient-shaped problems (both operands contiguous along their row index, K = batch).  Default: LDS panels of 64 x 64 /
+    64 x 128 outputs (dense_wtile.h: gemm_wgrad_panel) when M and the real column count are multiples of 4; otherwise, and with the
+    rounds-1-4 paths selected, a tile per WAVE from 1 536 tiles of 32 x 32 (dense.hip cfg 2; cfg 3 -- two row blocks per wave from
+    8-byte loads -- when A is contiguous along an EVEN number of rows).  Ragged M / N / K, bias + ReLU + mask, the ones column with
+    its separate destination, accumulation into C -- against float64."""
+    from pointcloud_rl_amd import hip
+    prev = hip.gemm_set_tile64_min(-1 if path == "auto" else 1 << 30)
+    try:
+        _weight_gradient_case(cuda, path, M, N, K, kind)
+    finally:
+        hip.gemm_set_tile64_min(prev)
+
+
+def _weight_gradient_case(cuda, path, M, N, K, kind):
     from pointcloud_rl_amd import hip
     g = np.random.RandomState(M + N + K)
     H = 2
     a = g.randn(H, K, M).astype(np.float32)              # A row-contiguous (stride 1 along m): the weight gradient's dY^T
     b = g.randn(H, K, N).astype(np.float32)              # B row-contiguous
     A_, B_ = T(a, cuda), T(b, cuda)
-    ref = np.einsum("hkm,hkn->hmn", a.astype(np.float64), b.astype(np.float64))
+    ref = np.matmul(a.astype(np.float64).transpose(0, 2, 1), b.astype(np.float64))
     if kind == "epilogue":
         bias, mask = g.randn(H, N).astype(np.float32), (g.rand(H, M, N) < 0.6).astype(np.float32)
         C = torch.full((H, M, N), float("nan"), device=cuda)
+        plan = hip.gemm_plan([hip.gemm_desc(A_, B_, C, M, N, K, (1, M), (N, 1), N, batch=H, batch_strides=(K * M, K * N, M * N, N, M * N))])
+        assert plan[0][0] == (5 if path == "auto" and M % 4 == 0 and N % 4 == 0 else 3 if M % 2 == 0 else 2), plan
         hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, bias=T(bias, cuda), mask=T(mask, cuda), ld_mask=N, relu=True, batch=H,
                  batch_strides=(K * M, K * N, M * N, N, M * N))
         want = np.maximum(ref + bias[:, None, :], 0) * mask
         np.testing.assert_allclose(C.cpu().numpy(), want, atol=2e-4, rtol=1e-5)
     elif kind == "ones":
-        # column N - 1 of B is never read: it stands for a column of ones (bias gradient) and lands in its own vector
+        # column N - 1 of B does not exist: it stands for a column of ones (bias gradient) and lands in its own vector.  B holds the N - 1
+        # real columns (as the heads' activations do: the panels need 16-byte aligned rows)
+        b1 = np.ascontiguousarray(b[:, :, :N - 1])
+        B1 = T(b1, cuda)
         C = torch.full((H, M, N), float("nan"), device=cuda)
         ones = torch.full((H, M), float("nan"), device=cuda)
-        hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, ones_col=N - 1, batch=H, batch_strides=(K * M, K * N, M * N, 0, 0), c_ones=ones, c_ones_batch_stride=M)
+        d = hip.gemm_desc(A_, B1, C, M, N, K, (1, M), (N - 1, 1), N, ones_col=N - 1, batch=H, batch_strides=(K * M, K * (N - 1), M * N, 0, 0),
+                          c_ones=ones, c_ones_batch_stride=M)
+        if path == "auto":
+            assert (hip.gemm_plan([d])[0][0] == 5) == (M % 4 == 0 and (N - 1) % 4 == 0), hip.gemm_plan([d])
+        hip.gemm_group([d])
         np.testing.assert_allclose(C[:, :, :N - 1].cpu().numpy(), ref[:, :, :N - 1], atol=2e-4, rtol=1e-5)
         np.testing.assert_allclose(ones.cpu().numpy(), a.astype(np.float64).sum(1), atol=2e-4, rtol=1e-5)
         assert torch.isnan(C[:, :, N - 1]).all()
@@ -95,6 +117,70 @@ def test_tile_per_wave_path_with_every_epilogue(cuda, M, N, K, kind):
         C = T(c0, cuda)
         hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, accumulate=True, batch=H, batch_strides=(K * M, K * N, M * N, 0, 0))
         np.testing.assert_allclose(C.cpu().numpy(), c0 + ref, atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["forward", "data-gradient"])
+@pytest.mark.parametrize("M,N,K,H,want_shape", [(32, 1024, 1024, 1, 0), (32, 1024, 1024, 4, 1), (64, 1024, 1024, 4, 2), (128, 1024, 1024, 1, 1),
+                                                (256, 1024, 1024, 1, 2), (256, 1024, 1024, 2, 3), (37, 50, 1000, 2, 0), (5, 3, 128, 1, 0),
+                                                (300, 1030, 196, 1, None), (256, 50, 1024, 2, 0), (100, 520, 260, 3, None), (128, 1024, 1024, 4, 3)])
+def test_wave_private_staged_tiles(cuda, kind, M, N, K, H, want_shape):
+    """dense_wtile.h::gemm_wtile: every tile shape (16 x 16 ... 32 x 64 outputs, v_mfma_f32_16x16x4_f32 and 32x32x2 blocks), forward-shaped
+    (A, B k-contiguous) and data-gradient-shaped (B contiguous along n), ragged M / N / K (K % 4 == 0), heads batched; bias + ReLU resp.
+    the ReLU mask of the layer input, and accumulation -- against float64.  The launch plan must say the shape is reached."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(M + N + K + H)
+    a = g.randn(H, M, K).astype(np.float32)
+    A_ = T(a, cuda)
+    if kind == "forward":
+        w, b = (g.randn(H, N, K) / np.sqrt(K)).astype(np.float32), g.randn(H, N).astype(np.float32)
+        W_, B_ = T(w, cuda), T(b, cuda)
+        C = torch.full((H, M, N), float("nan"), device=cuda)
+        d = hip.gemm_desc(A_, W_, C, M, N, K, (K, 1), (1, K), N, bias=B_, relu=True, batch=H, batch_strides=(M * K, N * K, M * N, N, 0))
+        want = np.maximum(np.matmul(a.astype(np.float64), w.astype(np.float64).transpose(0, 2, 1)) + b[:, None, :], 0)
+    else:
+        w = (g.randn(H, K, N) / np.sqrt(K)).astype(np.float32)
+        mask = np.maximum(g.randn(H, M, N), 0).astype(np.float32)
+        c0 = g.randn(H, M, N).astype(np.float32)
+        W_, MK, C = T(w, cuda), T(mask, cuda), T(c0, cuda)
+        d = hip.gemm_desc(A_, W_, C, M, N, K, (K, 1), (N, 1), N, mask=MK, ld_mask=N, accumulate=True, batch=H, batch_strides=(M * K, K * N, M * N, 0, M * N))
+        want = c0 + np.matmul(a.astype(np.float64), w.astype(np.float64)) * (mask > 0)
+    path, shape, wgs = hip.gemm_plan([d])[0]
+    assert path == 4, (path, shape, wgs)
+    if want_shape is not None:
+        assert shape == min(want_shape, 2 if kind == "data-gradient" else 3), (shape, wgs)
+    hip.gemm_group([d])
+    np.testing.assert_allclose(C.cpu().numpy(), want, atol=3e-5 * np.sqrt(K / 128), rtol=1e-5)
+
+
+def test_grouped_launch_mixes_the_round5_paths(cuda):
+    """dW | db (panels) + dx (wave tiles, row-contiguous B) + a forward layer (wave tiles) + a short-K problem (32 x 32 split-K) in ONE
+    launch == the same problems launched one by one, bit for bit (a problem's tile path does not depend on its neighbours)."""
+    from pointcloud_rl_amd import hip
+    g = np.random.RandomState(11)
+    M, K, N = 128, 1024, 1024
+    dy, x, w = g.randn(2, M, N).astype(np.float32), g.randn(2, M, K).astype(np.float32), (g.randn(2, N, K) / 32).astype(np.float32)
+    x2, w2 = g.randn(70, 56).astype(np.float32), g.randn(33, 56).astype(np.float32)
+    DY, X, W, X2, W2 = T(dy, cuda), T(x, cuda), T(w, cuda), T(x2, cuda), T(w2, cuda)
+
+    def descs(dwb, db, dx, y2, y3):
+        return [hip.gemm_desc(DY, X, dwb, N, K + 1, M, (1, N), (K, 1), K, ones_col=K, c_ones=db, c_ones_batch_stride=N, batch=2, batch_strides=(M * N, M * K, N * K, 0, 0)),
+                hip.gemm_desc(DY, W, dx, M, K, N, (N, 1), (K, 1), K, batch=2, batch_strides=(M * N, N * K, M * K, 0, 0)),
+                hip.gemm_desc(X2, W2, y2, 70, 33, 56, (56, 1), (1, 56), 33, relu=True),
+                hip.gemm_desc(X, W, y3, M, N, K, (K, 1), (1, K), N, batch=2, batch_strides=(M * K, N * K, M * N, 0, 0))]
+    shapes = [(2, N, K), (2, N), (2, M, K), (70, 33), (2, M, N)]
+    outs_a = [torch.zeros(*sh, device=cuda) for sh in shapes]
+    outs_b = [torch.zeros(*sh, device=cuda) for sh in shapes]
+    assert [pl[0] for pl in hip.gemm_plan(descs(*outs_a))] == [5, 4, 0, 4]
+    hip.gemm_group(descs(*outs_a))
+    for d in descs(*outs_b):
+        hip.gemm_group([d])
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    f64 = np.float64
+    np.testing.assert_allclose(outs_a[0].cpu().numpy(), np.matmul(dy.astype(f64).transpose(0, 2, 1), x.astype(f64)), atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[1].cpu().numpy(), dy.astype(f64).sum(1), atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[2].cpu().numpy(), np.matmul(dy.astype(f64), w.astype(f64)), atol=3e-4, rtol=1e-5)
+    np.testing.assert_allclose(outs_a[4].cpu().numpy(), np.matmul(x.astype(f64), w.astype(f64).transpose(0, 2, 1)), atol=3e-4, rtol=1e-5)
 
 
 def test_layernorm_rows(cuda):
