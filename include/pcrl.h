@@ -78,7 +78,10 @@ typedef struct pcrl_cloud_desc {
  *            every cloud and every key (RandomDownSample.process_single: one shared random permutation prefix,
  *            pcd_aug.py:231-257 + array_ops.py:659-680); N becomes n_index and the returned argmax counts
  *            positions of the subsampled cloud, as it does in the reference where the tensors are sliced.
- *            Jitter noise / Philox counters are indexed by the subsampled position. */
+ *            Jitter noise / Philox counters are indexed by the subsampled position.
+ *            n_index_ptr (optional, device): the number of positions that exist is read from there at run time, 1 <= *n_index_ptr <=
+ *            n_index -- RandomDownSample(fixed_ratio=False) keeps a different number of points every call (pcd_aug.py:244-246);
+ *            a launch replayed from a hipGraph follows the value.  Shapes, strides and counters stay those of n_index. */
 /*  COLOR     : ColorJitterPoints (pcd_aug.py:269-303): torchvision's ColorJitter on the uint8 rgb key viewed as a
  *            [B,3,1,N] image batch -- brightness / contrast / saturation / hue applied in the drawn order with ONE set of
  *            factors for the whole batch, uint8 truncation after every step, the contrast step blending with the cloud's
@@ -99,6 +102,7 @@ typedef struct pcrl_aug_desc {
     float color_factor[4];        /* brightness, contrast, saturation factors (blend ratios) and the hue shift */
     float color_one_minus[4];     /* (float)(1.0 - (double)factor) for the three blends, as torch forms it; [3] unused */
     const float* color_mean;      /* device [stored clouds]: grayscale mean entering the contrast step (NULL when contrast is skipped) */
+    const int32_t* n_index_ptr;   /* device, optional: PCRL_AUG_SUBSAMPLE with a point count decided on the device (see above) */
 } pcrl_aug_desc;
 
 /* Weights of the shared per-point MLP in the reference's own state_dict layout

@@ -247,6 +247,7 @@ class RefAgent:
         self.route = None        # tests only: argmax routing of the gradient-carrying encoder pass (pointnet_forward(route=))
         self.keep = None         # tests only: dict receiving that pass's pooled tensor / observation
         self.critic_grad_hook = None   # tests only: called with self after the critic's backward, before its optimizer step
+        self.post_critic_hook = None   # tests only: called with self right after the critic's optimizer step (before the actor phase)
 
     # -- modules ---------------------------------------------------------------------------
     def actor(self, obs, eps, detach_visual=False, masks=None):
@@ -350,6 +351,8 @@ class RefAgent:
             self.critic_grad_hook(self)
         self.last_grads = {"critic": {k: P[k].grad.detach().clone() for k in self.critic_names if P[k].grad is not None}}
         self.critic_optim.step()
+        if self.post_critic_hook is not None:
+            self.post_critic_hook(self)
         critic_grad = self.grad_norm([P[k] for k in self.critic_names])
         self.critic_optim.zero_grad()   # shared_backbone (sac.py:147-148)
         ret = {

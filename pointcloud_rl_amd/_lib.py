@@ -32,7 +32,8 @@ class AugDesc(ctypes.Structure):
                 ("jitter_lo", ctypes.c_float), ("jitter_hi", ctypes.c_float),
                 ("seed", ctypes.c_uint64), ("offset", ctypes.c_uint64), ("affine", ctypes.c_void_p),
                 ("offset_ptr", ctypes.c_void_p), ("point_index", ctypes.c_void_p), ("n_index", ctypes.c_int32), ("color_order", ctypes.c_int32),
-                ("color_factor", ctypes.c_float * 4), ("color_one_minus", ctypes.c_float * 4), ("color_mean", ctypes.c_void_p)]
+                ("color_factor", ctypes.c_float * 4), ("color_one_minus", ctypes.c_float * 4), ("color_mean", ctypes.c_void_p),
+                ("n_index_ptr", ctypes.c_void_p)]
 
 
 class EncoderWeights(ctypes.Structure):

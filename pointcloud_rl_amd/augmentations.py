@@ -133,17 +133,22 @@ class RandomJitterPoints(_PointAug):
 class RandomDownSample:
     """Keep a random subset of the points, the same subset for every cloud of the batch and every key
     (pcd_aug.py:231-268: `batch_perm(data[:1, 0, :], 1, max_num_points)[0]` = the first k entries of
-    `rand(N).argsort()`, drawn once per call and applied to all `req_keys`).  With drop_ratio and
-    fixed_ratio=False the number of dropped points is itself random per call (`np.random.randint(int(N * ratio))`),
-    exactly as in the reference -- the cloud size then changes from step to step, which a captured hipGraph cannot
-    follow: use fixed_ratio=True (or max_num_points) together with `agent.enable_graphs()`.
-    Nothing is gathered: the index travels with the observation and the encoder reads point index[p] for position p."""
+    `rand(N).argsort()`, drawn once per call and applied to all `req_keys`).  Nothing is gathered: the index travels
+    with the observation and the encoder reads point index[p] for position p.
+    With drop_ratio and fixed_ratio=False -- what both shipped `pn_dropout.py` configs use -- the NUMBER of dropped points is itself
+    random per call (pcd_aug.py:244-246: `np.random.randint(int(N * ratio))`).  On the GPU that count is drawn on the device
+    (uniform on the same range, torch's CUDA generator) and handed to the kernels by pointer next to the full permutation
+    (`point_count`, include/pcrl.h n_index_ptr): tensor shapes do not change from call to call, so a captured hipGraph follows the
+    count like every other draw.  On CPU tensors (parity tests against the reference class) the count comes from numpy's global
+    generator exactly as in the reference and the index is sliced."""
 
     def __init__(self, main_key="inputs/xyz", req_keys=["input/xyz"], max_num_points=None, drop_ratio=None, fixed_ratio=True):
         assert (drop_ratio is not None) ^ (max_num_points is not None)
         self.main_key, self.req_keys = main_key, list(req_keys)
         self.max_num_points, self.drop_ratio, self.fixed_ratio = max_num_points, drop_ratio, fixed_ratio
         self.index_override = []       # parity tests queue explicit index tensors here
+        self.count_override = []       # ... and explicit kept-point counts (random-count mode)
+        self.last_count = None
 
     def __call__(self, data):
         assert self.main_key in data, f"{self.main_key}, {list(data.keys())}"
@@ -154,12 +159,29 @@ class RandomDownSample:
                                       "the fused encoder reads every per-point key through the same index")
         x = data[self.main_key]
         N = x.shape[-1]
+        out = _as_augmented(data)
+        random_count = self.drop_ratio is not None and not self.fixed_ratio
+        if random_count and x.is_cuda:
+            hi = int(N * self.drop_ratio)                 # n_drop is uniform on [0, hi)
+            if hi < 1:
+                return out
+            if self.index_override:
+                index = self.index_override.pop(0).to(device=x.device, dtype=torch.int32).contiguous()
+                assert index.numel() == N, "random-count mode takes the whole permutation"
+            else:
+                index = torch.rand(N, device=x.device).argsort().to(torch.int32)
+            if self.count_override:
+                count = torch.full((1,), int(self.count_override.pop(0)), dtype=torch.int32, device=x.device)
+            else:
+                count = (N - torch.randint(0, hi, (1,), device=x.device, dtype=torch.int64)).to(torch.int32)
+            out.aug["point_index"], out.aug["point_count"] = index, count
+            self.last_count = count          # (a replayed graph rewrites this tensor in place: tests read the count a step used)
+            return out
         if self.drop_ratio is not None:
             n_drop = int(N * self.drop_ratio) if self.fixed_ratio else int(np.random.randint(int(N * self.drop_ratio)))
             k = N - n_drop
         else:
             k = min(self.max_num_points, N)
-        out = _as_augmented(data)
         if self.index_override:
             index = self.index_override.pop(0).to(device=x.device, dtype=torch.int32).contiguous()
         elif k >= N:

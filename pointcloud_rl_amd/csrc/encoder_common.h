@@ -27,6 +27,7 @@ struct CloudParams {
     unsigned long long seed, offset;
     const unsigned long long* offset_ptr;
     const int* point_index;   // SUBSAMPLE: stored point of position n (N is then the subsampled count)
+    const int* n_ptr;         // SUBSAMPLE, optional: how many of the N positions exist, read at run time (1 <= *n_ptr <= N)
     int color_order;          // COLOR: four step ids, 4 bits each
     float color_fac[4], color_omf[4];
     const float* color_mean;  // [stored clouds]

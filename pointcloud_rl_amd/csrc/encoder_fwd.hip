@@ -228,10 +228,15 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
     const f32x4* s_w1v = reinterpret_cast<const f32x4*>(s_w1);
 
+    // SUBSAMPLE with a count decided on the device (CloudParams::n_ptr): positions [n_pts, N) do not exist in this call -- their tiles are
+    // skipped, and the lanes of the last live tile past n_pts hold copies of point n_pts - 1, exactly like the lanes past N of a ragged cloud
+    const int n_pts = p.cl.n_ptr ? __builtin_amdgcn_readfirstlane(max(1, min(*p.cl.n_ptr, p.cl.N))) : p.cl.N;
+    const int tiles_live = (n_pts + 31) >> 5;
+
     for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
         const int b = work / p.S, seg = work - b * p.S;
         const int t_begin = seg * p.tiles_per_seg;
-        const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
+        const int t_end = min(min(t_begin + p.tiles_per_seg, p.tiles_total), tiles_live);
         __syncthreads();   // previous read-out of s_keys (and the prologue) is complete
         // {value +0.0, point 0}: what a channel that is zero everywhere (ReLU-dead) must report, so zero maxima never
         // have to be written by anybody
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
 
         for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
             const int pidx = tile * 32 + l31;
-            const bool valid = pidx < p.cl.N;
-            const int pc = valid ? pidx : p.cl.N - 1;
+            const bool valid = pidx < n_pts;
+            const int pc = valid ? pidx : n_pts - 1;
 
             PCRL_FSTAMP(0);
             // ---- preprocess (+ augmentation) ---------------------------------------------
@@ -461,16 +466,21 @@ __global__ __launch_bounds__(512, 1) void encoder_fwd_wide_kernel(const FwdParam
     const f32x4* s_gb2 = reinterpret_cast<const f32x4*>(s_ln2);
     const unsigned* s_key_hi = reinterpret_cast<const unsigned*>(s_keys) + 1;
 
+    // SUBSAMPLE with a count decided on the device (CloudParams::n_ptr): positions [n_pts, N) do not exist in this call -- their tiles are
+    // skipped, and the lanes of the last live tile past n_pts hold copies of point n_pts - 1, exactly like the lanes past N of a ragged cloud
+    const int n_pts = p.cl.n_ptr ? __builtin_amdgcn_readfirstlane(max(1, min(*p.cl.n_ptr, p.cl.N))) : p.cl.N;
+    const int tiles_live = (n_pts + 31) >> 5;
+
     for (int work = blockIdx.x; work < p.cl.B * p.S; work += gridDim.x) {
         const int b = work / p.S, seg = work - b * p.S;
         const int t_begin = seg * p.tiles_per_seg;
-        const int t_end = min(t_begin + p.tiles_per_seg, p.tiles_total);
+        const int t_end = min(min(t_begin + p.tiles_per_seg, p.tiles_total), tiles_live);
         __syncthreads();
         for (int i = tid; i < C3; i += nthreads) s_keys[i] = 0x00000000FFFFFFFFull;      // {value +0.0, point 0}
         __syncthreads();
         for (int tile = t_begin + wave; tile < t_end; tile += nwaves) {
             const int pidx = tile * 32 + l31;
-            const int pc = pidx < p.cl.N ? pidx : p.cl.N - 1;
+            const int pc = pidx < n_pts ? pidx : n_pts - 1;
             const f32x16 x = load_point<T0>(p.cl, s_desc, b, pc);
             const unsigned half_mask = half ? 0xFFFFFFFFu : 0u;
             f32x16 a0[MB1];
@@ -662,11 +672,13 @@ int fill_cloud_params(const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug, i
     if (aug && aug->flags) {
         if ((aug->flags & (PCRL_AUG_JITTER | PCRL_AUG_AFFINE)) && (clouds->seg[0].channels != 3 || clouds->seg[0].dtype != PCRL_DT_F32))
             return fail(PCRL_E_ARG, "augmentation needs segment 0 = xyz (3 x f32)");
+        if (aug->n_index_ptr && !(aug->flags & PCRL_AUG_SUBSAMPLE)) return fail(PCRL_E_ARG, "n_index_ptr without SUBSAMPLE");
         if (aug->flags & PCRL_AUG_SUBSAMPLE) {
             if (!aug->point_index || aug->n_index < 1 || aug->n_index > clouds->N)
                 return fail(PCRL_E_ARG, "SUBSAMPLE needs point_index and 1 <= n_index <= N (got %d of %d)", aug->n_index, clouds->N);
             p.point_index = aug->point_index;
             p.N = aug->n_index;
+            p.n_ptr = aug->n_index_ptr;
         }
         if ((aug->flags & PCRL_AUG_AFFINE) && !aug->affine) return fail(PCRL_E_ARG, "AFFINE without matrix");
         if (aug->flags & PCRL_AUG_COLOR) {

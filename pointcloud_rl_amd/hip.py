@@ -161,8 +161,10 @@ def encoder_pack_flush_pending():
 
 
 def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine=None, row_mul=1, row_add=0, offset_tensor=None,
-                  point_index=None, color=None):
-    """color: dict(order=[4 step ids in application order], factors=[brightness, contrast, saturation, hue] (None: skip),
+                  point_index=None, color=None, point_count=None):
+    """point_count: device int32 [1] tensor -- how many of point_index's positions exist this call (RandomDownSample with a random
+    count; read by the kernels at run time, see include/pcrl.h n_index_ptr).
+    color: dict(order=[4 step ids in application order], factors=[brightness, contrast, saturation, hue] (None: skip),
     mean=float32 device tensor [stored clouds] or None) -- ColorJitterPoints, see include/pcrl.h PCRL_AUG_COLOR."""
     flags = 0
     aug = AugDesc()
@@ -183,6 +185,9 @@ def make_aug_desc(jitter_noise=None, jitter_range=None, seed=0, offset=0, affine
         assert point_index.dtype == torch.int32 and point_index.is_cuda and point_index.is_contiguous() and point_index.ndim == 1
         flags |= _lib.AUG_SUBSAMPLE
         aug.point_index, aug.n_index = point_index.data_ptr(), point_index.numel()
+        if point_count is not None:
+            assert point_count.dtype == torch.int32 and point_count.is_cuda and point_count.numel() == 1
+            aug.n_index_ptr = point_count.data_ptr()
     if color is not None:
         flags |= _lib.AUG_COLOR
         order = 0

@@ -210,6 +210,7 @@ class FusedStep:
         # 12.0 us, its step 0.9873 -> 0.9772 ms, tools/r4_ab15.sh).  The backward tail replaces FOUR launches (~28 us): 16 384.
         self.policy_tail_max_split = int(_env_max) if _env_max else int(__import__("os").environ.get("PCRL_TAIL_FWD_MAX_SPLIT", "24576"))
         self.policy_tail_bwd_max_split = int(_env_max) if _env_max else 16384
+        self.phase_hook = None     # tests only: called between the critic's optimizer pass and the actor phase of an eager step
         self.tail_split_rows = int(__import__("os").environ.get("PCRL_TAIL_SPLIT_MAX", "512"))     # the same variable csrc/headtail.hip reads
         self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
         self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
@@ -488,6 +489,11 @@ class FusedStep:
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
 
         # ---- actor + temperature (sac.py:161-205) --------------------------------------------------------
+        if do_actor and self.phase_hook is not None:
+            # tests only (tests/test_fullsize_parity_gpu.py): lets the caller put another implementation's post-critic-step parameters
+            # in place, so that the actor phase is compared from ONE state; eager steps only -- a captured graph would freeze what it does
+            assert not torch.cuda.is_current_stream_capturing()
+            self.phase_hook()
         if do_actor:
             a_obs = obs if actor_obs is None else actor_obs
             vis_a, state_a = split(a_obs)

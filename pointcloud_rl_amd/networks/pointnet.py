@@ -49,6 +49,9 @@ def materialize(obs):
         jit = hip.color_jitter_u8(rgb, color)
         out["rgb"] = torch.repeat_interleave(jit, repeat, dim=0) if repeat > 1 else jit
     index = aug.pop("point_index", None)
+    count = aug.pop("point_count", None)
+    if index is not None and count is not None:
+        index = index[:int(count.item())]       # (host read: this path is for consumers outside the hot loop)
     if index is not None:          # RandomDownSample: the same points of every key
         out = {k: (v[..., index.long()] if torch.is_tensor(v) and v.ndim == 3 else v) for k, v in out.items()}
     if aug:

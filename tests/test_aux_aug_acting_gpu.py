@@ -263,9 +263,13 @@ def test_random_downsample_is_an_index_on_the_point_load(cuda):
     g = torch.randn_like(p1)
     assert torch.equal(hip.encoder_bwd(d1, ew, packed, i1, g, aug=a1), hip.encoder_bwd(d2, ew, packed, i2, g))
     # random drop count (fixed_ratio=False) and max_num_points variants
+    var = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=False)(dobs).aug
+    assert var["point_index"].numel() == N and N - int(N * 0.3) < int(var["point_count"]) <= N       # the count travels by pointer
     np.random.seed(0)
-    k_var = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=False)(dobs).aug["point_index"].numel()
-    assert N - int(N * 0.3) < k_var <= N
+    k_cpu = RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], drop_ratio=0.3, fixed_ratio=False)(
+        {k: v.cpu() for k, v in dobs.items()}).aug["point_index"].numel()
+    np.random.seed(0)
+    assert k_cpu == N - np.random.randint(int(N * 0.3))               # on CPU tensors: the reference's own numpy draw, index sliced
     assert RandomDownSample(main_key="xyz", req_keys=["xyz", "rgb", "seg"], max_num_points=100)(dobs).aug["point_index"].numel() == 100
     with pytest.raises(NotImplementedError):
         RandomDownSample(main_key="xyz", req_keys=["xyz"], max_num_points=100)(dobs)       # rgb / seg would keep all points
@@ -289,6 +293,81 @@ def test_drq_step_with_random_downsample(cuda):
     assert agent._graphs and agent._fused is not None
     losses = [r["drq/critic_loss"] for r in rets[4:]]
     assert len(set(np.round(losses, 7))) == len(losses)        # every replay draws a new subset
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("B,N,count", [(6, 300, 211), (6, 300, 300), (2, 1200, 841), (2, 1200, 1), (3, 64, 33), (300, 96, 70)])
+def test_random_count_downsample_equals_the_sliced_cloud(cuda, dtype, B, N, count):
+    """RandomDownSample(fixed_ratio=False) on the GPU: the full permutation + a device-resident count (include/pcrl.h n_index_ptr)
+    encodes exactly like the cloud sliced to the first `count` positions -- pooled values, argmax and every gradient bit for bit;
+    few clouds (split over workgroups: segments past the count stay empty) and many, counts that are not tile multiples."""
+    from pointcloud_rl_amd import hip
+    obs = make_obs(B, N, seed=B + N, seg=1)
+    dobs = {k: torch.from_numpy(v).to(cuda) for k, v in obs.items()}
+    w = make_encoder_weights(7, 64, 128, 256, seed=4)
+    wt = {k: torch.from_numpy(v).to(cuda) for k, v in w.items()}
+    ew, _ = hip.make_encoder_weights(wt["w0"], wt["b0"], wt["w1"], wt["g1"], wt["be1"], wt["w2"], wt["g2"], wt["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(7, 64, 128, 256) // 4, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+    perm = torch.from_numpy(np.random.RandomState(count).permutation(N).astype(np.int32)).to(cuda)
+    cnt = torch.full((1,), count, dtype=torch.int32, device=cuda)
+    d1, _k = hip.make_cloud_desc(dobs)
+    a_var = hip.make_aug_desc(point_index=perm, point_count=cnt, jitter_range=(-0.01, 0.01), seed=3, offset=5)
+    p1, i1 = hip.encoder_fwd(d1, ew, packed, aug=a_var, bf16=dtype == "bf16")
+    a_cut = hip.make_aug_desc(point_index=perm[:count].contiguous(), jitter_range=(-0.01, 0.01), seed=3, offset=5)
+    if count == N:                 # same Philox counters only when the logical N agrees; otherwise compare without jitter
+        p2, i2 = hip.encoder_fwd(d1, ew, packed, aug=a_cut, bf16=dtype == "bf16")
+        assert torch.equal(p1, p2) and torch.equal(i1, i2)
+    a_var = hip.make_aug_desc(point_index=perm, point_count=cnt)
+    a_cut = hip.make_aug_desc(point_index=perm[:count].contiguous())
+    p1, i1 = hip.encoder_fwd(d1, ew, packed, aug=a_var, bf16=dtype == "bf16")
+    p2, i2 = hip.encoder_fwd(d1, ew, packed, aug=a_cut, bf16=dtype == "bf16")
+    assert torch.equal(p1, p2) and torch.equal(i1, i2) and int(i1.max()) < count
+    g = torch.randn_like(p1)
+    assert torch.equal(hip.encoder_bwd(d1, ew, packed, i1, g, aug=a_var, pooled=p1, bf16=dtype == "bf16"),
+                       hip.encoder_bwd(d1, ew, packed, i2, g, aug=a_cut, pooled=p2, bf16=dtype == "bf16"))
+    # the count is read at run time: the same descriptor, a new value
+    cnt.fill_(max(1, count // 2))
+    p3, i3 = hip.encoder_fwd(d1, ew, packed, aug=a_var, bf16=dtype == "bf16")
+    p4, i4 = hip.encoder_fwd(d1, ew, packed, aug=hip.make_aug_desc(point_index=perm[:max(1, count // 2)].contiguous()), bf16=dtype == "bf16")
+    assert torch.equal(p3, p4) and torch.equal(i3, i4)
+    with pytest.raises(RuntimeError):
+        hip.encoder_fwd(d1, ew, packed, aug=_aug_with_count_only(hip, cnt))
+
+
+def _aug_with_count_only(hip, cnt):
+    aug = hip.make_aug_desc(jitter_range=(-0.01, 0.01), seed=1)
+    aug.n_index_ptr = cnt.data_ptr()
+    return aug
+
+
+def test_drq_reference_pn_dropout_config_follows_the_count_under_graph_replay(cuda):
+    """configs/mfrl/drq/{dm_control,maniskill}/pn_dropout.py ship RandomDownSample(drop_ratio=0.3, fixed_ratio=False): the number of kept
+    points changes every call (pcd_aug.py:244-246).  The obs_aug dict is the reference's, verbatim; the step is captured and replayed,
+    and the replays must see different counts, all in (N - int(0.3 N), N]."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    N = 128
+    obs_aug = dict(type="RandomDownSample", main_key="xyz", req_keys=["xyz", "rgb", "pos_encoding"], drop_ratio=0.3, fixed_ratio=False)
+    cfg = configs.drq_dmc(6, 6, 8, head_hidden=64, obs_aug=obs_aug)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, 6)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    agent.enable_graphs(warmup=1)
+    mem = SyntheticReplay(8, N, 6, seed=2, device=cuda)
+    aug = agent.obs_aug.transforms[0]
+    rets, counts = [], []
+    for u in range(1, 15):
+        rets.append(agent.update_parameters(mem, u))
+        counts.append(int(aug.last_count))
+    assert agent._graphs and agent._fused is not None and getattr(agent, "_use_graphs", False)
+    assert all(np.isfinite(list(r.values())).all() for r in rets)
+    replayed = counts[4:]                                       # both (actor / critic-only) graphs are captured by then
+    assert len(set(replayed)) >= 3, counts
+    assert all(N - int(0.3 * N) < c <= N for c in counts), counts
+    losses = [r["drq/critic_loss"] for r in rets[4:]]
+    assert len(set(np.round(losses, 7))) == len(losses)
 
 
 def test_device_replay_without_replacement_walks_the_reference_epoch_order(cuda):

@@ -340,3 +340,104 @@ def test_full_size_update_matches_cpu_restatement(cuda, name):
         assert worst[k] <= tol, (name, k, worst[k], tol)
     assert worst["unconfirmed_events"] == 0 or not confirm
     assert worst["event_max_preact"] <= EVENT_TAU
+
+
+# Round 5: the ACTOR phase un-steered.  In the test above the free run's actor phase starts from ITS critic's Adam
+# step, the HIP step's from its own -- two parameter states that differ by lr-sized amounts wherever an encoder event was not moved --, so
+# the free actor-phase gradients could only be bounded at 5e-2.  Here both implementations run the actor phase from ONE state: the
+# restatement runs free (own decisions, own argmax, nothing injected or moved), its parameters right after its critic optimizer step are
+# captured, and the HIP step puts exactly those in place between its critic pass and its actor phase (FusedStep.phase_hook).  What remains
+# is summation order on identical inputs: actor-phase metrics and every actor / temperature gradient element are held to the 1e-5 class.
+# A head ReLU unit of the actor phase whose pre-activation is within rounding of zero still decides by summation order; such units are
+# counted by a SECOND, steered pass of the restatement's actor phase (it must find every disagreement on |z| <= flip_max_preact) and only
+# a case with such a flip falls back to the located-event bound.
+ACTOR_FREE_TOL = dict(actor_metric_rel=3e-5, actor_grad_rel_to_max=1e-4, alpha_grad_rel=1e-4)
+ACTOR_CASES = [n for n in CASES if "f32split" not in n]
+
+
+@pytest.mark.parametrize("name", ACTOR_CASES)
+def test_actor_phase_from_the_restatements_post_critic_state(cuda, name):
+    from oracle import torch_ref
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    case = CASES[name]
+    B, N, A, S = case["B"], case["N"], case["A"], case["S"]
+    agent = _build(case, cuda)
+    params = {n: p.detach().clone() for n, p in agent.named_parameters()}
+    ref = torch_ref.RefAgent(params, kind=case["kind"], gamma=agent.gamma, reward_scale=agent.reward_scale, alpha=0.1,
+                             target_entropy=agent.target_entropy, update_coeff=agent.update_coeff["default"],
+                             num_aug=getattr(agent, "num_aug", 2), mirror_redundancy=False)
+    agent = agent.to(cuda)
+    assert agent.use_fused_step
+    g = torch.Generator().manual_seed(7)
+    num_aug = getattr(agent, "num_aug", 1) if case["kind"] == "drq" else 1
+    u = 2                                                          # an actor step (actor_update_interval 2), from the initial state
+    batch_np = make_batch_np(B, N, A, seed=21, agent=S, **case["obs_kw"])
+    cpu_batch = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v))
+                 for k, v in batch_np.items()}
+    eps = [torch.randn(B * num_aug, A, generator=g), torch.randn(B, A, generator=g)]
+    jit = [torch.empty(B * num_aug, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)] if case["kind"] == "drq" else None
+    # 1. the restatement, free; its post-critic-step parameters are captured
+    snap = {}
+    ref.post_critic_hook = lambda r: snap.update({n: p.detach().clone() for n, p in r.P.items()})
+    free = copy.deepcopy(ref)
+    free.post_critic_hook = ref.post_critic_hook
+    want = free.update_parameters(cpu_batch, u, [e.clone() for e in eps], None if jit is None else [j.clone() for j in jit])
+    assert snap and "actor" in free.last_grads
+    # 2. the HIP step; between its critic pass and its actor phase the restatement's state goes in
+    agent.actor.head.noise_override = [e.to(cuda) for e in eps]
+    if jit is not None:
+        agent.obs_aug[0].noise_override = [j.to(cuda) for j in jit]
+    got = {}
+
+    def put_state():
+        with torch.no_grad():
+            for n, p in agent.named_parameters():
+                if not n.startswith("target_critic."):
+                    p.copy_(snap[n].to(p.device))
+        agent.encoder.invalidate_packed()
+    if agent._flat is None:
+        agent._prepare()                                           # flat buffers + the fused step object (normally built by the first update)
+    assert agent._fused is not None, "the fused HIP step must be the one under test"
+    agent._fused.phase_hook = put_state
+    try:
+        res = agent.update_parameters(Memory(batch_np), u)
+    finally:
+        agent._fused.phase_hook = None
+    got = res
+    pre = agent.metric_prefix
+    worst = dict(actor_metric_rel=0.0, actor_grad_rel_to_max=0.0, alpha_grad_rel=0.0, actor_flips=0, actor_flip_max_preact=0.0)
+    detail = {}
+    for k in (f"{pre}/actor_loss", f"{pre}/alpha_loss", f"{pre}/entropy", f"{pre}/actor_grad"):
+        err = abs(got[k] - want[k]) / max(1.0, abs(want[k]))
+        detail[f"metric/{k}"] = err
+        worst["actor_metric_rel"] = max(worst["actor_metric_rel"], err)
+    mine = _flat_grads(agent, "actor")
+    for n, gm in mine.items():
+        gr = free.last_grads["actor"][_ref_name("actor", n)].numpy()
+        err = float(np.abs(gm - gr).max()) / max(float(np.abs(gr).max()), 1e-12)
+        detail[f"grad/actor/{n}"] = err
+        worst["actor_grad_rel_to_max"] = max(worst["actor_grad_rel_to_max"], err)
+    ga = float(agent._flat["alpha"].grad.detach().cpu().reshape(-1)[0]) if "alpha" in agent._flat else float(agent.log_alpha.grad)
+    gr = float(free.last_grads["alpha"]["log_alpha"])
+    worst["alpha_grad_rel"] = abs(ga - gr) / max(abs(gr), 1e-12)
+    # 3. units of the actor phase that decide by summation order: the restatement's actor phase once more from the captured state, with the
+    # HIP step's decisions injected -- every disagreement is reported with its pre-activation
+    masks = agent._fused.relu_decisions(B * num_aug, B)
+    masks = {k: [[m.cpu() for m in head] for head in v] if k != "pi" else [m.cpu() for m in v] for k, v in masks.items()}
+    steer = copy.deepcopy(ref)
+    steer.post_critic_hook = None
+    steer.update_parameters(cpu_batch, u, [e.clone() for e in eps], None if jit is None else [j.clone() for j in jit],
+                            relu_masks={k: v for k, v in masks.items() if k in ("pi", "q_pi")})
+    for n_bad, z_bad in steer.flips:
+        worst["actor_flips"] += n_bad
+        worst["actor_flip_max_preact"] = max(worst["actor_flip_max_preact"], z_bad)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"parity_actor_phase_{name}.json"), "w") as f:
+        json.dump(dict(case=name, worst=worst, detail=detail), f, indent=1)
+    print(name, worst)
+    assert worst["actor_flip_max_preact"] <= TOL["flip_max_preact"]
+    assert worst["actor_metric_rel"] <= ACTOR_FREE_TOL["actor_metric_rel"], (name, worst, sorted(detail.items(), key=lambda kv: -kv[1])[:5])
+    assert worst["alpha_grad_rel"] <= ACTOR_FREE_TOL["alpha_grad_rel"], (name, worst)
+    bound = ACTOR_FREE_TOL["actor_grad_rel_to_max"] if worst["actor_flips"] == 0 else FREE_TOL["free_head_grad_rel_to_max"]
+    assert worst["actor_grad_rel_to_max"] <= bound, (name, worst, sorted(detail.items(), key=lambda kv: -kv[1])[:5])

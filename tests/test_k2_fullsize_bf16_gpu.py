@@ -129,3 +129,109 @@ def test_k2_backward_full_size_properties(cuda):
             assert err < 8e-2, f"{name}: {err:.3e} of the largest entry against autograd through the bf16 emulation"
         else:
             assert err < 3e-2, f"{name}: {err:.3e} of the largest entry against autograd through the bf16 emulation"
+
+
+def test_k2_step_as_benched_against_the_fp32_restatement(cuda):
+    """What bench.py times as `config3_k2`, asserted as a STEP at its full size: DrQ, 256 samples x 2 augmentations = 512 clouds of
+    N = 1200, C = 7, nets [128, 128, 256], bf16 conv1 / conv2, obs_aug = [GlobalRotScaleTrans(rotation + per-axis scale),
+    RandomJitterPoints], ManiSkill heads (S = 68, A = 22) -- against the CPU restatement of the reference's fp32 DrQ step on the SAME
+    256 transitions with the matrices, the jitter noise and the policy noise injected on both sides.  Bounds: those of
+    test_update_step_gpu.py::test_drq_mixed_precision_step_against_the_reference_fixture (losses / Q statistics 1e-2 relative, floor 1;
+    gradient norms 6 %) -- what bf16 operands in two of three encoder layers do to an fp32 step."""
+    import bench
+    from oracle import torch_ref
+    from pointcloud_rl_amd.augmentations import GlobalRotScaleTrans, RandomJitterPoints
+    from pointcloud_rl_amd.synthetic import make_batch_np
+    wl = bench.WORKLOADS["k2"]
+    Bs, Np, A, S = wl["B"], wl["N"], wl["A"], wl["S"]
+    assert (Bs, Np, wl["aug"]) == (256, 1200, "rot_scale+jitter")
+    agent, C = bench.build_agent(wl, Bs, torch.device("cpu"))
+    assert C == 7 and agent.encoder.compute_dtype == "bf16"
+    assert [type(t) for t in agent.obs_aug.transforms] == [GlobalRotScaleTrans, RandomJitterPoints]
+    params = {n: p.detach().clone() for n, p in agent.named_parameters()}
+    ref = torch_ref.RefAgent(params, kind="drq", gamma=agent.gamma, reward_scale=agent.reward_scale, alpha=0.1, target_entropy=agent.target_entropy,
+                             update_coeff=agent.update_coeff["default"], num_aug=agent.num_aug, mirror_redundancy=False)
+    agent = agent.to(cuda)
+    rst = agent.obs_aug[0]
+    g = torch.Generator().manual_seed(12)
+
+    class Mem:
+        def __init__(self, b):
+            self.b = b
+
+        def sample(self, n):
+            return self
+
+        def to_torch(self, device=None, non_blocking=False):
+            from pointcloud_rl_amd.utils.torch_utils import to_torch
+            return to_torch(self.b, device=device)
+    worst, worst_g = 0.0, 0.0
+    for u in (1, 2):
+        batch_np = make_batch_np(Bs, Np, A, seed=50 + u, agent=S, **wl["obs_kw"])
+        cpu_batch = {k: ({kk: torch.from_numpy(vv) for kk, vv in v.items()} if isinstance(v, dict) else torch.from_numpy(v)) for k, v in batch_np.items()}
+        eps = [torch.randn(2 * Bs, A, generator=g)] + ([torch.randn(Bs, A, generator=g)] if u % 2 == 0 else [])
+        jit = [torch.empty(2 * Bs, 3, Np).uniform_(-0.01, 0.01, generator=g) for _ in range(2)]
+        aff = [rst.sample_matrix(2 * Bs, "cpu") for _ in range(2)]
+        agent.actor.head.noise_override = [e.to(cuda) for e in eps]
+        rst.matrix_override = [m.to(cuda) for m in aff]
+        agent.obs_aug[1].noise_override = [j.to(cuda) for j in jit]
+        got = agent.update_parameters(Mem(batch_np), u)
+        assert agent._fused is not None, "the fused HIP step is what the bench times"
+        want = ref.update_parameters(cpu_batch, u, eps, jit, affine_list=aff)
+        assert got.keys() == want.keys()
+        for k, v in want.items():
+            if k.endswith("_grad"):
+                worst_g = max(worst_g, abs(got[k] - v) / max(abs(v), 1e-6))
+            else:
+                worst = max(worst, abs(got[k] - v) / max(1.0, abs(v)))
+    print(f"K2 step as benched vs the fp32 restatement: worst metric {worst:.2e}, worst gradient norm {worst_g:.2e}")
+    assert worst <= 1e-2 and worst_g <= 0.06, (worst, worst_g)
+
+
+@pytest.mark.parametrize("tag,Bc,Nc,C,c1", [("config4 one GPU", 1024, 1200, 7, 128), ("config5 one GPU", 512, 8192, 6, 64)])
+def test_one_gpu_launch_geometries_the_bench_times_are_batch_order_invariant(cuda, tag, Bc, Nc, C, c1):
+    """bench.py's `config4_k3` (1 024 clouds of 1 200 points, C = 7) and `config5_k4` (512 x 8 192, C = 6) time launch geometries that the
+    parity tests cover at one rank's share (128 / 64 clouds); at the full one-GPU geometry the fp32 forward and backward are checked
+    through what does not depend on the size: a cloud's pooled values and argmax are bitwise the same wherever it sits in the batch
+    (reversed order: another workgroup, another position in the persistent loop), a slice launched alone gives the same bits, and
+    the backward is bitwise reproducible and equals, restricted to a slice's clouds, the slice's own backward summed in cloud order
+    only up to the fixed-order reduce (compared to 1e-5 of each tensor's largest entry)."""
+    from pointcloud_rl_amd import hip
+    obs_np = make_obs(Bc, Nc, seed=5, seg=C - 6)
+    obs = {k: torch.from_numpy(v).to(cuda) for k, v in obs_np.items()}
+    w_np = make_encoder_weights(C, c1, 128, 256, seed=9)
+    w = {k: torch.from_numpy(v).to(cuda) for k, v in w_np.items()}
+    ew, keep = hip.make_encoder_weights(w["w0"], w["b0"], w["w1"], w["g1"], w["be1"], w["w2"], w["g2"], w["be2"], 1e-6)
+    packed = torch.empty(hip.encoder_packed_bytes(ew.c_in, ew.c1, ew.c2, ew.c3) // 4, dtype=torch.float32, device=cuda)
+    hip.encoder_pack_weights(ew, packed)
+
+    def fwd(o):
+        desc, k = hip.make_cloud_desc(o)
+        pooled, argmax = hip.encoder_fwd(desc, ew, packed)
+        return pooled, argmax, desc, k
+    pooled, argmax, desc, k0 = fwd(obs)
+    assert pooled.shape == (Bc, 256) and bool(torch.isfinite(pooled).all()) and int(argmax.max()) < Nc
+    rev = {k: v.flip(0).contiguous() for k, v in obs.items()}
+    p_rev, a_rev, d_rev, k1 = fwd(rev)
+    assert torch.equal(p_rev.flip(0), pooled) and torch.equal(a_rev.flip(0), argmax)
+    sel = slice(Bc // 2 - 3, Bc // 2 + 5)
+    sl = {k: v[sel].contiguous() for k, v in obs.items()}
+    p_sl, a_sl, d_sl, k2 = fwd(sl)
+    assert torch.equal(p_sl, pooled[sel]) and torch.equal(a_sl, argmax[sel])
+    gp = torch.randn(Bc, 256, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
+    run = lambda: hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled).clone()
+    ga, gb = run(), run()
+    assert torch.equal(ga, gb) and bool(torch.isfinite(ga).all())
+    # gradient of the reversed batch with the reversed upstream gradient: the same sum over clouds in another order
+    g_rev = hip.encoder_bwd(d_rev, ew, packed, a_rev, gp.flip(0).contiguous(), pooled=p_rev)
+    for name, v in hip.encoder_grad_views(ga, ew).items():
+        r = hip.encoder_grad_views(g_rev, ew)[name]
+        assert float((v - r).abs().max()) <= 1e-5 * float(v.abs().max()), (tag, name)
+    # a slice's own backward == the full launch's with every other cloud's upstream gradient zeroed
+    gp0 = torch.zeros_like(gp)
+    gp0[sel] = gp[sel]
+    g_full0 = hip.encoder_bwd(desc, ew, packed, argmax, gp0, pooled=pooled).clone()
+    g_slice = hip.encoder_bwd(d_sl, ew, packed, a_sl, gp[sel].contiguous(), pooled=p_sl)
+    for name, v in hip.encoder_grad_views(g_slice, ew).items():
+        r = hip.encoder_grad_views(g_full0, ew)[name]
+        assert float((v - r).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1e-12), (tag, name)

@@ -415,3 +415,38 @@ def test_round4_launch_cuts_equal_the_launches_they_replace(cuda, monkeypatch, k
     for (n, p), (_, q) in zip(base.named_parameters(), new.named_parameters()):
         err = (p - q).abs()
         assert (err <= 2e-6).float().mean() >= 0.999 and err.max() <= 2.1e-3, (n, float(err.max()))
+
+
+def test_update_on_the_batch_the_reference_replay_container_produced(cuda):
+    """tests/golden/ref_seam_batch_drq_maniskill.npz (tools/gen_golden_seam.py) is what the reference's ReplayMemory -> GDict.to_torch ->
+    `agent._fetcher` handed to the step in the build container (configs/mfrl/drq/maniskill/pn_jitter.py: xyz f32, rgb u8, seg bool,
+    agent f32, episode_dones next to dones).  The same structure drives update_parameters here -- eagerly and replayed from a hipGraph --
+    and a DeviceReplay fed with the same transitions returns a batch of the same keys, dtypes and shapes."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.replay import DeviceReplay
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_seam_batch_drq_maniskill.npz"))
+    batch = {}
+    for k in z.files:
+        node, parts = batch, k.split("/")
+        for part in parts[:-1]:
+            node = node.setdefault(part, {})
+        node[parts[-1]] = z[k]
+    B, N, A, S = 8, 96, 8, 10
+    cfg = configs.drq_maniskill(7, A, S, B)
+    cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+    torch.manual_seed(0)
+    agent = build_agent(cfg).to(cuda)
+    rets = [agent.update_parameters(Memory(batch), u) for u in (1, 2)]
+    assert agent._fused is not None and all(np.isfinite(list(r.values())).all() for r in rets)
+    agent.enable_graphs(warmup=1)
+    rets += [agent.update_parameters(Memory(batch), u) for u in range(3, 9)]
+    assert agent._graphs and all(np.isfinite(list(r.values())).all() for r in rets)
+    mem = DeviceReplay(16, device=cuda, seed=1)
+    mem.push_batch(batch)
+    got = mem.sample(B).to_torch(device=cuda)
+    for k in ("obs", "next_obs", "actions", "rewards", "dones", "episode_dones"):
+        want = batch[k]
+        for kk, vv in (want.items() if isinstance(want, dict) else [(None, want)]):
+            t = got[k][kk] if kk is not None else got[k]
+            assert str(t.dtype) == f"torch.{vv.dtype}" and tuple(t.shape) == vv.shape, (k, kk, t.dtype, vv.dtype)
