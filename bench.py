@@ -93,6 +93,11 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=100)
     ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
+    ap.add_argument("--dry-run-ranks", type=int, default=0, help="rehearsal of the multi-GPU run on a ONE-GPU box: the launcher starts this many ranks "
+                    "exactly as `--gpus N` does (rendezvous on 127.0.0.1, to_ddp's broadcast, the sharded replay rings, the data-parallel step "
+                    "schedule, the comm / no-comm timing, the extra workloads behind their watchdog, rank 0's line last on stdout), but the ranks "
+                    "share cuda:0 for compute and exchange over gloo (host threads) instead of RCCL; the line is tagged `dry_run` and is not a "
+                    "measurement")
     return ap.parse_args()
 
 
@@ -243,6 +248,16 @@ def exchange_mode(agent, dist_on):
     if not graphs:
         return "eager step, asynchronous all-reduces"
     return "captured in the step's hipGraph" if all(len(segs) == 1 for segs, _, _ in graphs.values()) else "eager all-reduces between per-segment hipGraphs"
+
+
+def exchange_probe(dist_on):
+    """Verdict of the one-time probe that decides whether the all-reduces may live inside the step's hipGraph (utils/dist.py:
+    capture_exchange): "works", "failed: <why>" (the run then used eager all-reduces between per-segment graphs), "not run" (a backend
+    whose collectives cannot be captured, e.g. gloo; or PCRL_CAPTURE_EXCHANGE=0), "skipped"."""
+    if not dist_on:
+        return None
+    from pointcloud_rl_amd.utils.dist import probe_verdict
+    return probe_verdict()
 
 
 def usable_cpus():
@@ -403,6 +418,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.dry_run_ranks:
+        args.gpus, args.backend, args.share_gpu = args.dry_run_ranks, "gloo", True
     wl = dict(WORKLOADS[args.workload])
     if not args.replay_capacity:
         args.replay_capacity = wl.get("capacity", 2048)
@@ -558,6 +575,7 @@ def main():
                        "parallelism": f"dp{world}", "batch_per_gpu": b_rank,
                        "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist_on else None,
                        "rccl_ranks": torch.distributed.get_world_size() if dist_on else 1, "exchange": exch_mode,
+                       "exchange_probe": exchange_probe(dist_on),
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": roof,
             "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
@@ -565,6 +583,9 @@ def main():
         if nocomm_ms is not None:
             out["ms_per_step_nocomm"] = nocomm_ms
             out["comm_ms_per_step"] = elapsed / args.steps * 1e3 - nocomm_ms
+        if args.dry_run_ranks:
+            out["dry_run"] = (f"{world} ranks sharing cuda:0 over gloo (host-side all-reduces): a rehearsal of launcher, rendezvous, to_ddp, the "
+                              "data-parallel schedule and the extras -- not a measurement")
         if dist_on and world == 1:
             out["debug"] = f"single-rank exchange over backend {args.backend}: data-parallel schedule with a one-rank process group"
         if not dist_on and not args.no_cpu_baseline:

@@ -165,10 +165,21 @@ class HipAdam(torch.optim.Optimizer):
 
 
 def _is_capture_error(err):
-    """True for the errors HIP / RCCL / torch raise when an operation is not allowed while a stream is being captured
-    (hipErrorStreamCaptureUnsupported / Invalidated / ..., "operation not permitted when stream is capturing")."""
+    """True for what HIP / RCCL / torch raise when the EXCHANGING step cannot be captured whole: an operation refused while a stream is
+    being captured (hipErrorStreamCapture*, "operation not permitted when stream is capturing", "... is capturing"), or a collective
+    that failed inside the capture (ProcessGroupNCCL's "NCCL error ... unhandled cuda / system error", RCCL's own messages).  Only the
+    capture of a step WITH its all-reduces asks this (SAC._run_step), so a collective's failure there is fallback-eligible; out of
+    memory, assertions and argument errors of this library ("pcrl") are not."""
+    if isinstance(err, (AssertionError, NotImplementedError)):
+        return False
     text = str(err).lower()
-    return "captur" in text and "out of memory" not in text
+    if "out of memory" in text or "pcrl_e_" in text:
+        return False
+    capture = any(k in text for k in ("streamcapture", "stream capture", "is capturing", "capturing stream", "while capturing", "during capture",
+                                      "stream is capturing", "captures_underway", "capture_begin", "capture_end"))
+    collective = any(k in text for k in ("nccl error", "rccl error", "ncclinternalerror", "ncclunhandledcudaerror", "ncclsystemerror",
+                                         "unhandled cuda error", "unhandled hip error", "unhandled system error"))
+    return capture or collective
 
 
 def _plain_adam(optim):

@@ -40,27 +40,45 @@ def capture_exchange():
 
 
 _PROBE = None
+_PROBE_NOTE = "not run"
+
+
+def probe_verdict():
+    """What the one-time probe of `capture_exchange` found, for logs / bench.py's line: "not run", "works", "failed: <why>", "skipped"."""
+    return _PROBE_NOTE
 
 
 def _captured_allreduce_works():
     """Asked once per process: ONE small all-reduce captured into a hipGraph, replayed twice and checked against the expected sum, the
-    verdict agreed between the ranks (eager MIN all-reduce).  A stack whose RCCL refuses stream capture or breaks under graph replay is
-    found here -- identically on every rank and before anything of the step is captured -- and the run uses the segmented schedule
-    (eager all-reduces between per-segment graphs) instead of ending with exit code 75 at its first replayed step.  A replay that
-    HANGS cannot be recovered from in-process: it raises after PCRL_EXCHANGE_PROBE_TIMEOUT_S (30) and the rank ends as before.
-    PCRL_EXCHANGE_PROBE=0 skips the probe (captured exchange assumed to work)."""
-    global _PROBE
+    verdict agreed between the ranks.  A stack whose RCCL refuses stream capture or breaks under graph replay is found here --
+    identically on every rank and before anything of the step is captured -- and the run uses the segmented schedule (eager
+    all-reduces between per-segment graphs) instead of ending with exit code 75 at its first replayed step.
+
+    Two agreements, both eager MIN all-reduces that EVERY rank reaches on every path (a rank whose capture raised is no longer
+    capturing): (1) did the capture succeed everywhere -- only then does any rank replay its graph, so a replayed 1 024-float SUM is
+    never paired with a peer's eager collective; (2) did the replays give the expected sum everywhere.  A replay that HANGS cannot be
+    recovered from in-process: it raises after PCRL_EXCHANGE_PROBE_TIMEOUT_S (30) and the rank ends non-zero at once (its peers'
+    collectives then fail or time out; bench.py's launcher stops them when it sees the first rank die and starts fresh children for
+    its one retry).  PCRL_EXCHANGE_PROBE=0 skips the probe (captured exchange assumed to work)."""
+    global _PROBE, _PROBE_NOTE
     if _PROBE is not None:
         return _PROBE
     if os.environ.get("PCRL_EXCHANGE_PROBE", "1") == "0":
-        _PROBE = True
+        _PROBE, _PROBE_NOTE = True, "skipped"
         return True
     import time
     import warnings
     import torch
-    ok, why = True, ""
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def agree(flag):
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        quiesce_before_capture()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+    ok, why, graph = True, "", None
+    buf = torch.ones(1024, device=dev)
     try:
-        buf = torch.ones(1024, device=torch.device("cuda", torch.cuda.current_device()))
         dist.all_reduce(buf)                          # eager: the communicator's lazy initialisation must not be captured
         quiesce_before_capture()
         graph = torch.cuda.CUDAGraph()
@@ -68,35 +86,45 @@ def _captured_allreduce_works():
             warnings.filterwarnings("ignore", message="The CUDA Graph is empty")      # (a one-rank all-reduce launches nothing)
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 dist.all_reduce(buf, async_op=True).wait()
-        want = float(dist.get_world_size())
-        for _ in range(2):
-            buf.fill_(1.0)
-            graph.replay()
-        done = torch.cuda.Event()
-        done.record()
-        t0, limit = time.monotonic(), float(os.environ.get("PCRL_EXCHANGE_PROBE_TIMEOUT_S", "30"))
-        while not done.query():
-            if time.monotonic() - t0 > limit:
-                raise TimeoutError(f"a replayed hipGraph holding one RCCL all-reduce did not finish within {limit:.0f} s")
-            time.sleep(0.001)
-        if not bool((buf == want).all()):
-            ok, why = False, f"a replayed all-reduce of ones gave {float(buf[0])} on {int(want)} ranks"
-        del graph
-    except TimeoutError as err:
-        raise RuntimeError(f"captured exchange probe: {err} (hipGraph / RCCL: the stream is wedged)") from err
     except RuntimeError as err:
-        ok, why = False, str(err).splitlines()[0]
+        ok, why = False, "capture: " + str(err).splitlines()[0]
         try:
             torch.cuda.synchronize()
         except RuntimeError:
             pass
-    verdict = torch.tensor([1.0 if ok else 0.0], device=torch.device("cuda", torch.cuda.current_device()))
-    quiesce_before_capture()
-    dist.all_reduce(verdict, op=dist.ReduceOp.MIN)   # every rank takes the same schedule
-    _PROBE = bool(verdict.item() > 0.5)
+    everyone_captured = agree(ok)
+    if everyone_captured:
+        try:
+            want = float(dist.get_world_size())
+            for _ in range(2):
+                buf.fill_(1.0)
+                graph.replay()
+            done = torch.cuda.Event()
+            done.record()
+            t0, limit = time.monotonic(), float(os.environ.get("PCRL_EXCHANGE_PROBE_TIMEOUT_S", "30"))
+            while not done.query():
+                if time.monotonic() - t0 > limit:
+                    raise TimeoutError(f"a replayed hipGraph holding one RCCL all-reduce did not finish within {limit:.0f} s")
+                time.sleep(0.001)
+            if not bool((buf == want).all()):
+                ok, why = False, f"a replayed all-reduce of ones gave {float(buf[0])} on {int(want)} ranks"
+        except TimeoutError as err:
+            _PROBE_NOTE = f"failed: {err}"
+            raise RuntimeError(f"captured exchange probe: {err} (hipGraph / RCCL: the stream is wedged)") from err
+        except RuntimeError as err:
+            ok, why = False, "replay: " + str(err).splitlines()[0]
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError:
+                pass
+    elif ok:
+        why = "another rank could not capture the all-reduce"
+    del graph
+    _PROBE = agree(ok and everyone_captured)          # every rank takes the same schedule
+    _PROBE_NOTE = "works" if _PROBE else "failed: " + (why or "another rank's replay failed")
     if not _PROBE:
-        warnings.warn("RCCL all-reduce inside a replayed hipGraph does not work on this stack"
-                      + (f" ({why})" if why else " (another rank's probe failed)") + ": eager all-reduces between per-segment graphs instead")
+        warnings.warn("RCCL all-reduce inside a replayed hipGraph does not work on this stack (" + (why or "another rank's probe failed")
+                      + "): eager all-reduces between per-segment graphs instead")
         os.environ["PCRL_CAPTURE_EXCHANGE"] = "0"
     quiesce_before_capture()
     return _PROBE

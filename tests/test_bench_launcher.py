@@ -89,3 +89,21 @@ def test_which_errors_count_as_a_failure_of_the_captured_exchange(monkeypatch):
     monkeypatch.delenv("PCRL_CAPTURE_EXCHANGE")
     monkeypatch.setenv("WORLD_SIZE", "1")
     assert not any(bench.exchange_in_graph_failure(e) for e in yes)
+
+
+def test_only_capture_and_collective_failures_select_the_segmented_schedule():
+    """methods/sac.py::_is_capture_error decides whether a failed capture of the EXCHANGING step falls back to per-segment graphs: stream-
+    capture refusals and collective failures inside the capture do; out of memory, assertions, this library's argument errors and
+    unrelated messages that merely mention a capture do not."""
+    from pointcloud_rl_amd.methods.sac import _is_capture_error
+    yes = ["HIP error: operation not permitted when stream is capturing", "hipErrorStreamCaptureUnsupported: operation not permitted",
+           "CUDA error: operation failed due to a previous error during capture", "NCCL error in: ProcessGroupNCCL.cpp:1970, unhandled cuda error",
+           "ncclSystemError: System call (e.g. socket, malloc) or external library call failed", "RCCL error: invalid usage",
+           "hipErrorStreamCaptureInvalidated"]
+    no = ["HIP out of memory while capturing stream", "pcrl_gemm_group_f32: PCRL_E_ARG 1 <= n <= 4 problems (capture)", "invalid argument",
+          "the screen capture tool failed", "shape mismatch"]
+    for text in yes:
+        assert _is_capture_error(RuntimeError(text)), text
+    for text in no:
+        assert not _is_capture_error(RuntimeError(text)), text
+    assert not _is_capture_error(AssertionError("stream is capturing"))

@@ -218,7 +218,11 @@ def _probe_worker(rank, port, break_replay, out):
     from pointcloud_rl_amd.utils import dist as du
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1)
-    if break_replay:                       # a stack whose replayed graph fails: the probe must say so and select the segmented schedule
+    if break_replay == "capture":          # a stack that refuses collectives under stream capture: no rank may go on to replay
+        def refuse(self, *a, **k):
+            raise RuntimeError("HIP error: simulated operation not permitted when stream is capturing")
+        torch.cuda.CUDAGraph.capture_begin = refuse
+    elif break_replay:                     # a stack whose replayed graph fails: the probe must say so and select the segmented schedule
         def boom(self):
             raise RuntimeError("HIP error: simulated failure of a replayed graph holding a collective")
         torch.cuda.CUDAGraph.replay = boom
@@ -230,11 +234,11 @@ def _probe_worker(rank, port, break_replay, out):
     dist.all_reduce(x)                      # the process group is still usable
     torch.cuda.synchronize()
     torch.save(dict(verdict=verdict, again=again, env=os.environ.get("PCRL_CAPTURE_EXCHANGE"), warned=[str(w.message) for w in caught],
-                    x=x.cpu()), os.path.join(out, "probe.pt"))
+                    x=x.cpu(), note=du.probe_verdict()), os.path.join(out, "probe.pt"))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("break_replay", [False, True], ids=["works", "replay-fails"])
+@pytest.mark.parametrize("break_replay", [False, True, "capture"], ids=["works", "replay-fails", "capture-fails"])
 def test_captured_allreduce_probe_selects_the_schedule(cuda, break_replay):
     """utils/dist.py::capture_exchange asks ONCE whether an RCCL all-reduce inside a replayed hipGraph works (one small captured
     all-reduce, replayed and checked, the verdict agreed between the ranks): yes -> the exchanging step is captured whole; a replay
@@ -246,7 +250,8 @@ def test_captured_allreduce_probe_selects_the_schedule(cuda, break_replay):
         r = torch.load(os.path.join(out, "probe.pt"))
     assert r["verdict"] == r["again"] == (not break_replay)
     assert r["env"] == ("0" if break_replay else None)
-    assert any("does not work on this stack" in w for w in r["warned"]) == break_replay
+    assert any("does not work on this stack" in w for w in r["warned"]) == bool(break_replay)
+    assert r["note"] == "works" if not break_replay else r["note"].startswith("failed: " + ("capture" if break_replay == "capture" else "replay")), r["note"]
     assert torch.equal(r["x"], torch.ones(8))
 
 
@@ -377,3 +382,32 @@ def test_bench_two_rccl_ranks_print_the_contract_line():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["backend"].startswith("nccl")
     assert d["config"]["exchange"] == "captured in the step's hipGraph" or "launcher_note" in d, d["config"]["exchange"]
     assert d["value"] > 0 and d["config"]["batch_per_gpu"] == 128 and "comm_ms_per_step" in d
+
+
+def test_bench_dry_run_of_the_eight_rank_launch(cuda):
+    """`python bench.py --dry-run-ranks 8`: what the driver's 8-GPU run executes -- the launcher and its rendezvous, one process per
+    rank, to_ddp's broadcast, each rank's shard of the replay ring, the data-parallel step schedule with its comm / no-comm timing,
+    the three extra workloads behind their watchdog, rank 0's JSON line last on stdout -- rehearsed on this one-GPU box with the ranks
+    sharing cuda:0 and gloo in place of RCCL.  One line, rc 0, within five minutes; the line says what it is."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--dry-run-ranks", "8", "--steps", "20", "--warmup", "5", "--extra-steps", "10",
+           "--replay-capacity", "512"]
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420, env=env)
+    took = time.time() - t0
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{") and sum(l.startswith("{") for l in lines) == 1, lines[-3:]
+    d = json.loads(lines[-1])
+    assert took < 300, took
+    assert d["n_gpus"] == 8 and d["config"]["rccl_ranks"] == 8 and d["config"]["batch_per_gpu"] == 32 and d["config"]["parallelism"] == "dp8"
+    assert "dry_run" in d and d["config"]["backend"] == "gloo" and d["config"]["exchange_probe"] == "not run"
+    assert d["value"] > 0 and d["ms_per_step_nocomm"] > 0 and "comm_ms_per_step" in d
+    assert "extras_error" not in d, d.get("extras_error")
+    for key, b_rank in (("config4_k3", 128), ("config3_k2", 32), ("config5_k4", 64)):
+        assert d[key]["n_gpus"] == 8 and d[key]["batch_per_gpu"] == b_rank and d[key]["value"] > 0, key

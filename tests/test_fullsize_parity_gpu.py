@@ -441,3 +441,11 @@ def test_actor_phase_from_the_restatements_post_critic_state(cuda, name):
     assert worst["alpha_grad_rel"] <= ACTOR_FREE_TOL["alpha_grad_rel"], (name, worst)
     bound = ACTOR_FREE_TOL["actor_grad_rel_to_max"] if worst["actor_flips"] == 0 else FREE_TOL["free_head_grad_rel_to_max"]
     assert worst["actor_grad_rel_to_max"] <= bound, (name, worst, sorted(detail.items(), key=lambda kv: -kv[1])[:5])
+    if worst["actor_flips"]:
+        # a unit did decide by summation order: with the HIP step's decisions injected (nothing else) the same gradients are tight again
+        steered = 0.0
+        for n, gm in mine.items():
+            gr = steer.last_grads["actor"][_ref_name("actor", n)].numpy()
+            steered = max(steered, float(np.abs(gm - gr).max()) / max(float(np.abs(gr).max()), 1e-12))
+        print(name, "actor gradients with the located head decisions injected:", steered)
+        assert steered <= ACTOR_FREE_TOL["actor_grad_rel_to_max"], (name, steered)
