@@ -159,11 +159,52 @@ def encoder_roofline(agent, wl, C, b_rank, n_fwd, ms_fwd, steps_timed, workload,
         else:
             traffic_src = f"{os.path.relpath(cands[-1], ROOT)} is stale (measured on kernel sources {tj.get('kernel_source_sha')}, " \
                           f"now {kernel_source_sha()}): not reported"
-    return {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * spec[2])), "launches": n_fwd, "avg_launch_ms": ms_fwd,
-            "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
-            "algorithmic_flops_per_launch": flops_per_launch}
+    alg_bytes = int(clouds_per_launch * (wl["N"] * (12 + 3 + (C - 6)) + 8 * spec[2]))
+    out = {"kernel": "encoder_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+           "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+           "algorithmic_bytes_per_launch": alg_bytes, "launches": n_fwd, "avg_launch_ms": ms_fwd,
+           "timed_with": "HIP events on the launch stream" + (", eager pass after the graph-replayed timed region" if graphed else ", inside the timed region"),
+           "algorithmic_flops_per_launch": flops_per_launch}
+    if is_bf16:
+        # The bf16 kernel is NOT bound by the matrix pipe: measured (profiles/r04_bf16_fwd_ceiling.md, profiles/r03_fwd_stamps.md) a SIMD spends
+        # 4.1 k of its 16.5 k cycles per 32-point tile in MFMAs and 12.4 k in ~1 900 vector / LDS instructions on the accumulators it holds
+        # (LayerNorm-2 + the max-pool against the LDS keys: ~8.5 per conv2 output) -- with those two phases removed the same launch reaches
+        # 0.275 of the bf16 peak, the best redesign by instruction count ~0.22.  `frac` stays achieved / dense bf16 MFMA peak for comparison.
+        out.update(bound="valu", mfma_frac=achieved / peak,
+                   valu={"vector_or_lds_instructions_per_conv2_output": 8.5, "matrix_cycles_per_tile": 4100, "vector_cycles_per_tile": 12400,
+                         "frac_with_layernorm2_and_pool_removed": 0.275, "source": "profiles/r04_bf16_fwd_ceiling.md, profiles/r03_fwd_stamps.md"},
+                   bound_note="vector-instruction bound (fp32 LayerNorm / ReLU / pool on 256 accumulators per point), not MFMA-bound: "
+                              "the fraction of the dense bf16 MFMA peak is reported for comparison only")
+    if traffic and traffic > 2 * alg_bytes:
+        out["traffic_note"] = (f"counter traffic is {traffic / alg_bytes:.1f}x the algorithmic bytes: inside the step this launch's counters also see the "
+                               "write-back of lines its predecessors (Adam, re-pack, replay gather) left dirty in L2 and the feature head's weight reads; "
+                               "launched back to back the same kernel moves ~1.6x (DESIGN.md section 4.1).  At < 0.2 TB/s it is two orders of magnitude "
+                               "under the HBM roofline either way")
+    return out
+
+
+def feature_dim(agent):
+    fm = getattr(agent.encoder, "final_mlp", None)
+    return fm[0].out_features if fm is not None else agent.encoder.mlp_spec[-1]
+
+
+def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, head_hidden=1024, feat=None):
+    """Whole-step figure next to the dominant kernel's: SURVEY.md section 8(d)'s CANONICAL FLOPs per gradient step (encoder: next_obs fwd,
+    obs fwd + 2 x bwd, the actor's obs fwd every second step = 4.5 point-passes per point, DrQ's actor pass on augmentation #0 only; heads:
+    (2.5 F_a + 11 F_q) per sample) / ms_per_step / the dense MFMA peak of the encoder's arithmetic.  The implementation executes FEWER
+    FLOPs than canonical (the max-pool's gradient reaches <= c3 points per cloud), so this is a rate of useful work, not pipe utilisation."""
+    f_pt = 2.0 * (C * spec[0] + spec[0] * spec[1] + spec[1] * spec[2])
+    P = b_global * num_aug * wl["N"]
+    enc = (4.0 * P + 0.5 * b_global * wl["N"]) * f_pt
+    F = feat if feat is not None else 50
+    d_a = F + S
+    f_a = 2.0 * (d_a * head_hidden + head_hidden ** 2 + head_hidden * 2 * A)
+    f_q = 2.0 * ((d_a + A) * head_hidden + head_hidden ** 2 + head_hidden)
+    heads = (2.5 * f_a + 11 * f_q) * b_global * num_aug
+    peak = 2500.0 if is_bf16 else 157.3
+    tf = (enc + heads) / (ms_per_step * 1e-3) / 1e12
+    return {"canonical_gflop_per_step": (enc + heads) / 1e9, "encoder_gflop": enc / 1e9, "heads_gflop": heads / 1e9, "achieved": tf, "unit": "TFLOP/s",
+            "peak": peak, "frac": tf / peak, "note": "canonical (dense-backward) FLOPs of SURVEY.md 8(d) per measured step time; executed FLOPs are lower"}
 
 
 def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True, roofline=False,
@@ -210,6 +251,8 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
     out = {"value": steps / dt, "unit": "gradient steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "global_batch": wl["B"], "batch_per_gpu": b_rank, "points": wl["N"], "n_gpus": world, "scaling": "strong",
            "exchange": exchange_mode(agent, dist_on), "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32")}
+    out["step"] = step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], out["ms_per_step"],
+                                getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent))
     if roofline:
         # per-kernel spans from an eager pass over the same ring and weights (a replayed graph's launches cannot be bracketed by
         # host-recorded events); every rank runs it (the step's collectives are inside), rank 0's spans are reported
@@ -578,6 +621,8 @@ def main():
                        "exchange_probe": exchange_probe(dist_on),
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": roof,
+            "step": step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], elapsed / args.steps * 1e3,
+                                  getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent)),
             "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
         }
         if nocomm_ms is not None:
