@@ -296,7 +296,7 @@ class GlobalRotScaleTrans(_PointAug):
         self.calls = 0
         self._shared, self._slot, self._mats = None, 0, {}
         self._predrawn = None                  # (rows, slot) of matrices the previous call's launch has already drawn
-        self.pair_draws = os.environ.get("PCRL_AFFINE_PAIR", "1") == "1"
+        self.pair_draws = True
 
     def sample_matrix(self, batch_size, device):
         mat = torch.zeros([batch_size, 3, 4], device=device)

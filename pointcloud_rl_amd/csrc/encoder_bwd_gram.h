@@ -1191,12 +1191,6 @@ int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p
 #define PCRL_BWDG_AFTER(name)                                                                                     \
     do {                                                                                                           \
         PCRL_CHECK_LAUNCH(name);                                                                                   \
-        static const bool sync_each = getenv("PCRL_BWDG_SYNC") != nullptr;                                         \
-        if (sync_each) {                                                                                           \
-            hipError_t e_ = hipStreamSynchronize(stream);                                                          \
-            fprintf(stderr, "[bwdg] %s: %s\n", name, hipGetErrorString(e_));                                       \
-            if (e_ != hipSuccess) return fail(PCRL_E_LAUNCH, "%s: %s", name, hipGetErrorString(e_));               \
-        }                                                                                                          \
     } while (0)
 
 template <int T0, int C1, int C2, int C3>

@@ -1185,8 +1185,7 @@ static int launch_bwd(const BwdParams& p, int grid, hipStream_t stream) {
         PCRL_CHECK_LAUNCH("encoder_bwd_prep_kernel");
         const size_t lds = bwd_lds_bytes_tile(T0, C1, C2, C3);
         // at most C3 / 32 tiles per cloud: when even that many fit one per SIMD, take the four-wave build (no register spills)
-        static const int nw_forced = [] { const char* e = getenv("PCRL_BWD_TILE_WAVES"); return e ? atoi(e) : 0; }();
-        const bool four = !BF16 && !SPLIT && (nw_forced ? nw_forced == 4 : (long long)p.cl.B * (C3 / 32) <= 4ll * num_cus());
+        const bool four = !BF16 && !SPLIT && (long long)p.cl.B * (C3 / 32) <= 4ll * num_cus();
         if (four) {            // instantiated in its own translation unit (encoder_bwd_f32_nw4.hip) so that the two builds compile in parallel
             if (int rc = encoder_bwd_points_nw4_f32(T0, C1, C2, C3, p, lds, stream)) return rc;
         } else {
@@ -1342,14 +1341,13 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     if (p.cl.N > 32 * kBitmapMaxWords) return fail(PCRL_E_ARG, "encoder backward: N = %d > %d points per cloud", p.cl.N, 32 * kBitmapMaxWords);
     {
         // Gram form (encoder_bwd_gram.h): fp32 and split-precision arithmetic, every batch the tile list covers, when the forward's
-        // pooled values are given (the agents always pass them).  The bf16 mode and PCRL_BWD_ALGO=0 keep the round-2 kernels.
-        static const int algo = [] { const char* e = getenv("PCRL_BWD_ALGO"); return e ? atoi(e) : 1; }();
-        // bf16 mode (PCRL_BWD_BF16_GRAM, default 1): the same fp32 Gram-form backward at the bf16 forward's argmax / pooled values.  The
+        // pooled values are given (the agents always pass them).  A call WITHOUT pooled values keeps the round-2 kernels below (a dense
+        // search for the owned channels; every mode): tests/test_encoder_bwd_gpu.py is their main caller.
+        // bf16 mode: the same fp32 Gram-form backward at the bf16 forward's argmax / pooled values.  The
         // recompute of the two lower layers is then fp32 instead of the forward's bf16 contractions: the gradient of the fp32
         // function at the forward's routing, as close to the bf16 function's straight-through gradient as that one's own bf16
         // data-gradient GEMMs were (tests: the same 3e-2 bounds), and 12 % faster at K2's 512 x 1 200 clouds (380 -> 334 us).
-        static const int bf16_gram = [] { const char* e = getenv("PCRL_BWD_BF16_GRAM"); return e ? atoi(e) : 1; }();
-        if ((mode != 1 || bf16_gram != 0) && algo != 0 && p.cl.B <= kMaxTileModeClouds && w->w2 && pooled) {
+        if (p.cl.B <= kMaxTileModeClouds && w->w2 && pooled) {
             p.ops = reinterpret_cast<float*>(base + wg.ops); p.pw = reinterpret_cast<float*>(base + wg.pw);
             p.n_act = reinterpret_cast<int*>(base + wg.nact); p.act = reinterpret_cast<int*>(base + wg.act);
             p.slot = reinterpret_cast<unsigned char*>(base + wg.slot); p.own = reinterpret_cast<unsigned*>(base + wg.own);
@@ -1385,13 +1383,12 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     p.grads = grads;
     if (p.cl.N > 32 * kBitmapMaxWords) return fail(PCRL_E_ARG, "encoder backward: N = %d > %d points per cloud", p.cl.N, 32 * kBitmapMaxWords);
     {
-        static const int forced = [] { const char* e = getenv("PCRL_BWD_TILE_MODE"); return e ? atoi(e) : -1; }();   // -1: automatic
-        // measured (tools/bench_encoder.py, PCRL_BWD_TILE_MODE=0/1): dealing single tiles over all SIMDs also wins for large
+        // measured (tools/bench_encoder.py, round 2): dealing single tiles over all SIMDs also wins for large
         // batches of the c1 = 64 shapes (B 256: 212 -> 207 us, B 1024: 822 -> 739 us); with c1 = 128 the two schedules tie
         // (946 vs 960 us at B 1024, N 1200) and the one-workgroup-per-cloud kernel stays
         // (the bf16 build's tile kernel writes whole operand pieces: 512 x 1200 clouds with c1 = 128, 384 us by clouds, 366 us by tiles)
         const bool automatic = p.cl.B < num_cus() || w->c1 <= 64 || mode == 1;
-        p.tile_mode = (forced >= 0 ? forced != 0 : automatic) && p.cl.B <= kMaxTileModeClouds ? 1 : 0;
+        p.tile_mode = automatic && p.cl.B <= kMaxTileModeClouds ? 1 : 0;
     }
     p.parts = 1;
     while (p.parts < 8 && 2 * p.parts * p.cl.B <= num_cus()) p.parts *= 2;

@@ -874,7 +874,7 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     FwdParams p{};
     if (int rc = fill_cloud_params(clouds, aug, w->c_in, &p.cl)) return rc;
     if (p.cl.B == 0) return PCRL_OK;
-    static const int min_tiles_f32 = [] { const char* e = getenv("PCRL_FWD_MIN_TILES"); return e ? atoi(e) : 4; }();
+    constexpr int min_tiles_f32 = 4;          // one tile per SIMD (2 measured worse, 8 is the bf16 kernel's: DESIGN.md section 4.1)
     split_plan(p.cl.B, p.cl.N, &p.S, &p.tiles_total, &p.tiles_per_seg, mode == 1 ? 8 : min_tiles_f32);
     if (p.S > 1) {
         const size_t ws = (size_t)p.cl.B * p.S * w->c3 * sizeof(unsigned long long);
@@ -928,8 +928,7 @@ static int encoder_fwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     if (rc == PCRL_E_ARG) return fail(PCRL_E_ARG, "no fused kernel for C=%d (supported: 3..10 channels)", p.cl.C);
     if (rc) return rc;
     if (p.S > 1 && head) {
-        static const int merge_nt = [] { const char* e = getenv("PCRL_MERGE_NT"); return e ? atoi(e) : 1024; }();
-        if (p.head.weight && merge_nt == 1024) hipLaunchKernelGGL(encoder_merge_head_kernel<1024>, dim3(p.cl.B), dim3(1024), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
+        if (p.head.weight) hipLaunchKernelGGL(encoder_merge_head_kernel<1024>, dim3(p.cl.B), dim3(1024), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
         else hipLaunchKernelGGL(encoder_merge_head_kernel<256>, dim3(p.cl.B), dim3(256), 0, st, p.partial, p.S, w->c3, pooled, argmax, p.head);
         PCRL_CHECK_LAUNCH("encoder_merge_head_kernel");
     } else if (p.S > 1) {

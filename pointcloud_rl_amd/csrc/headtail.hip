@@ -20,6 +20,10 @@
 #include "common.h"
 
 namespace pcrl {
+// The row-split tail kernels (a row's hidden vector over the four waves of a workgroup) serve H = 1024 up to this many rows
+// (methods/fused.py: FusedStep.tail_split_rows is the same number).
+constexpr int kTailSplitMaxRows = 512;
+
 
 constexpr int kTailMaxChunks = 8;                  // H <= 2048
 constexpr float kTailHalfLog2Pi = 0.91893853320467274178f;
@@ -861,7 +865,7 @@ extern "C" int pcrl_q_tail_workspace_floats(int32_t M, int32_t H, size_t* part_f
 
 static int q_tail_launch(const QTailParams& p, hipStream_t st) {
     if (p.H % 256 || p.H < 256 || p.H > 256 * kTailMaxChunks) return fail(PCRL_E_ARG, "head tail: H must be a multiple of 256, <= %d (got %d)", 256 * kTailMaxChunks, p.H);
-    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    constexpr int split_max = kTailSplitMaxRows;
     if (p.H == 1024 && p.M <= split_max) {         // small batch: a row's hidden vector over four waves
         const int grid_s = (p.M + 3) / 4 + (p.cg_dst ? (2 * p.cg_ncols * p.H + 1023) / 1024 : 0);
         const size_t lds_s = p.mode == 0 ? sizeof(float) * 8 * (size_t)p.H : 0;
@@ -949,9 +953,9 @@ extern "C" int pcrl_policy_tail_bwd_f32(const float* dh1, int64_t dh1_head_strid
     p.fin_on = stat_part != nullptr;
     p.fin = ActorFinalizeParams{stat_part, (M + 3) / 4, M, log_alpha, target_entropy, alpha_grad, stats};
     hipStream_t st = (hipStream_t)stream;
-    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    constexpr int split_max = kTailSplitMaxRows;
     if (H == 1024 && M <= split_max && A <= 32) {
-        static const bool prefetch = [] { const char* e = getenv("PCRL_TAIL_PREFETCH"); return !e || atoi(e) != 0; }();
+        constexpr bool prefetch = true;          // every operand piece of a phase requested up front (A <= 24); the <0> loops serve wider heads
         const dim3 g(M + (p.fin_on ? 1 : 0));
         const int a8 = prefetch ? (A + 7) / 8 : 0;
         if (a8 == 1) hipLaunchKernelGGL(policy_tail_bwd_split_kernel<1>, g, dim3(256), 0, st, p);
@@ -1023,11 +1027,11 @@ static int policy_tail_fwd_impl(const float* h2, int32_t M, int32_t H, const flo
                        log_std_min, log_std_max, epsilon, feat, ld_feat, action, ld_action, action2, ld_action2, neg_logp, saved,
                        fold_pre, fold_pre_hs, fold_w0a, fold_w0a_hs, fold_h1, fold_h1_hs, fold_heads};
     hipStream_t st = (hipStream_t)stream;
-    static const int split_max = [] { const char* e = getenv("PCRL_TAIL_SPLIT_MAX"); return e ? atoi(e) : 512; }();
+    constexpr int split_max = kTailSplitMaxRows;
     if (fold_h1 && !(H == 1024 && M <= split_max && A <= 32))
         return fail(PCRL_E_ARG, "policy tail fold: built for H = 1024, M <= %d, A <= 32 (got H=%d M=%d A=%d)", split_max, H, M, A);
     if (H == 1024 && M <= split_max) {             // small batch: one row per workgroup, a quarter of the hidden vector per wave
-        static const bool prefetch = [] { const char* e = getenv("PCRL_TAIL_PREFETCH"); return !e || atoi(e) != 0; }();
+        constexpr bool prefetch = true;
         const int groups = (2 * A + 15) / 16;
         if (prefetch && groups == 1) hipLaunchKernelGGL(policy_tail_fwd_split_kernel<1>, dim3(M), dim3(256), 0, st, p);
         else if (prefetch && groups == 2) hipLaunchKernelGGL(policy_tail_fwd_split_kernel<2>, dim3(M), dim3(256), 0, st, p);

@@ -360,7 +360,7 @@ def _f(x):
     return ctypes.c_float(float(x))
 
 
-_SPAN_SHAPES = bool(os.environ.get("PCRL_SPAN_SHAPES"))
+_SPAN_SHAPES = False          # debugging: name GEMM spans by their shapes (set from a profiling script)
 
 
 def gemm_desc(A, B, C, M, N, K, a_strides, b_strides, ldc, bias=None, mask=None, ld_mask=0, relu=False, ones_col=-1, accumulate=False,

@@ -136,12 +136,12 @@ class DrQ(SAC):
         call of this step (calls differ by seed), instead of a counter increment + clone per call."""
         jitters = [t for t in (self.obs_aug.transforms if self.obs_aug is not None else []) if hasattr(t, "begin_step")]
         shared = memory.state[:1] if (jitters and getattr(memory, "graph_sampling", False) and torch.is_tensor(getattr(memory, "state", None))
-                                      and os.environ.get("PCRL_JITTER_SHARED_COUNTER", "1") == "1") else None
+                                      ) else None
         # A captured encoder launch holds the counter's ADDRESS.  The shared counter is used only where a captured step would also
         # hold the replay's sampling launch (no obs_processor, PCRL_GRAPH_SAMPLING on: SAC._run_step's rule; the same rule eagerly,
         # so that an eager and a graph-replayed run draw the same noise), and a graph captured with one replay's counter must not
         # be replayed against another replay (or none): a changed address drops the captured graphs.
-        if not (os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1" and self.obs_processor is None):
+        if not (self.graph_sampling and self.obs_processor is None):
             shared = None
         if getattr(self, "_use_graphs", False):
             ptr = None if shared is None else shared.data_ptr()

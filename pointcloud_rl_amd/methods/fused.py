@@ -172,8 +172,7 @@ class FusedStep:
         self.bufs = {}
         # head tails (csrc/headtail.hip): the last Linear of a head fused with the loss / squashed-Gaussian head that follows
         self.host_stats = None       # pinned mirror of the step's metrics (+ ready flag), allocated on first use
-        self.tails = (self.H % 256 == 0 and self.H <= 1024 and 2 * self.A <= 64 and self.q.dims[2][1] == 1
-                      and not bool(int(__import__("os").environ.get("PCRL_NO_TAILS", "0"))))
+        self.tails = (self.H % 256 == 0 and self.H <= 1024 and 2 * self.A <= 64 and self.q.dims[2][1] == 1)
         dev = fc.data.device
         self.stats_c = torch.zeros(4, device=dev)
         self.stats_a = torch.zeros(3, device=dev)
@@ -197,27 +196,27 @@ class FusedStep:
         # branch of the graph under the head GEMMs.  Measured on MI355X (profiles/r03_graph_branch.md): the two cross-stream edges
         # cost more than the 7.5 us launch they hide (K1 0.877 -> 0.902 ms per step, K3's 128-cloud share 0.701 -> 0.729), so the
         # default keeps the step one chain.
-        self._side = torch.cuda.Stream(device=dev) if __import__("os").environ.get("PCRL_BWD_FORK", "0") == "1" else None
+        self._side = None      # (the backward's prepare launch on a forked graph branch measured slower, profiles/r03_graph_branch.md; a test may set a stream)
         self._forked = False
         # rows x outputs up to which the policy's last layer runs inside the head kernels (csrc/headtail.hip) instead of as a GEMM + a
         # separate head launch: 4 096 for the wave-per-row kernels, 16 384 where the row-split kernels apply (H = 1024, <= 512 rows:
         # K3's 128-cloud share 0.669 -> 0.657 ms, K2's actor phase; K3's full batch stays on the GEMMs)
-        _env_max = __import__("os").environ.get("PCRL_POLICY_TAIL_MAX")
-        self.policy_tail_max = int(_env_max) if _env_max else 4096
+        self.policy_tail_max = 4096
         # forward tail: every row streams the 2A rows of the last layer against ~15.5 us for GEMM + head launch.  With one group of sixteen
         # outputs in flight the limit was 8 192 row-outputs (K2's actor phase, 11 264, took 25.6 us); with every piece requested at once
         # (policy_tail_fwd_split_kernel<G>, A <= 24) all of the row-split domain pays: 512 rows x 48 outputs (K2's 512-row critic phase
         # 12.0 us, its step 0.9873 -> 0.9772 ms, tools/r4_ab15.sh).  The backward tail replaces FOUR launches (~28 us): 16 384.
-        self.policy_tail_max_split = int(_env_max) if _env_max else int(__import__("os").environ.get("PCRL_TAIL_FWD_MAX_SPLIT", "24576"))
-        self.policy_tail_bwd_max_split = int(_env_max) if _env_max else 16384
+        self.policy_tail_max_split = 24576
+        self.policy_tail_bwd_max_split = 16384
         self.phase_hook = None     # tests only: called between the critic's optimizer pass and the actor phase of an eager step
-        self.tail_split_rows = int(__import__("os").environ.get("PCRL_TAIL_SPLIT_MAX", "512"))     # the same variable csrc/headtail.hip reads
-        self.fold_q0 = __import__("os").environ.get("PCRL_FOLD_Q0", "1") == "1"    # A/B switch of the first-layer fold (policy tail)
-        self.fold_max_a = int(__import__("os").environ.get("PCRL_FOLD_MAX_A", "8"))
-        self.attach_colsum = __import__("os").environ.get("PCRL_ATTACH_COLSUM", "1") == "1"
-        self.tail_bwd = __import__("os").environ.get("PCRL_TAIL_BWD", "1") == "1"     # A/B switch of policy_tail_bwd (csrc/headtail.hip)
-        # the critic phase's re-pack (+ the target heads' action-column image) as extra workgroups of the replay's sampling launch
-        self.entry_pack = __import__("os").environ.get("PCRL_ENTRY_PACK", "1") == "1"
+        # The switches below were the A/B arms of rounds 3-4 (measurements: DESIGN.md appendix); the kept arm is the default, the other one
+        # stays reachable as an attribute for the tests that check both give the same step (tests/test_update_step_gpu.py).
+        self.tail_split_rows = 512         # the row-split tail kernels' domain (csrc/headtail.hip kTailSplitMaxRows)
+        self.fold_q0 = True                # the Q heads' first layer finished inside the policy tail (A <= fold_max_a)
+        self.fold_max_a = 8
+        self.attach_colsum = True          # the step's leftover column sums ride on the encoder backward's reduce launch
+        self.tail_bwd = True               # pcrl_policy_tail_bwd_f32: four launches of the actor's backward in one
+        self.entry_pack = True             # the critic phase's re-pack rides on the replay's sampling launch
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):

@@ -229,6 +229,7 @@ class SAC(BaseAgent):
             self.alpha = self.log_alpha.exp().item()
         self.alpha_optim = build_optimizer(self.log_alpha, alpha_optim_cfg)
         self._flat = None
+        self.graph_sampling = True   # a device replay's sampling launch becomes the first node of the captured step (tests switch it off)
         self.use_fused_step = True   # autograd-free launch sequence (methods/fused.py) when the topology allows
         self.sync_alpha = True     # data-parallel: all-reduce log_alpha's gradient too (the reference does not)
 
@@ -576,7 +577,7 @@ class SAC(BaseAgent):
         first node of the captured step: replays call `fetch(launch=False)` (bookkeeping only)."""
         fetch = batch if callable(batch) else (lambda launch=True: batch)
         # a pre-processor produces fresh tensors outside the graph: its output cannot be the captured step's input in place
-        if not (callable(batch) and getattr(sampler, "graph_sampling", False) and os.environ.get("PCRL_GRAPH_SAMPLING", "1") == "1"
+        if not (callable(batch) and getattr(sampler, "graph_sampling", False) and self.graph_sampling
                 and self.obs_processor is None):
             sampler = None
         do_actor = updates % self.actor_update_interval == 0
@@ -831,8 +832,6 @@ class SAC(BaseAgent):
     # 128th call for the full hyper-parameter check) falls back to `_run_step`.
     def _refresh_fast(self):
         self._fast = None
-        if os.environ.get("PCRL_FAST_REPLAY", "1") != "1":
-            return
         if not (getattr(self, "_use_graphs", False) and self._fused is not None and self._target_flat is not None
                 and all(isinstance(o, HipAdam) for o in (self.critic_optim, self.actor_optim, self.alpha_optim))):
             return

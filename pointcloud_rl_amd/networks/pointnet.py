@@ -227,7 +227,7 @@ class PointNet(ExtendedModule):
         """The part of backward_raw that needs only the forward's outputs (hip.encoder_bwd_prepare); True when it was launched --
         backward_raw must then be called with prepared=True, behind it.  Exact fp32 arithmetic, Gram form only."""
         desc, keep, aug, aug_desc, ew, packed, pooled = ctx
-        if self.compute_dtype != "f32" or pooled is None or desc.B > 2048 or os.environ.get("PCRL_BWD_ALGO", "1") == "0":
+        if self.compute_dtype != "f32" or pooled is None or desc.B > 2048:
             return False
         hip.encoder_bwd_prepare(desc, ew, packed, argmax, pooled, self._workspace("bwd", desc.B), aug=aug_desc)
         return True

@@ -612,12 +612,11 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda, monkeypatc
     """With a DeviceReplay that draws its rows on the device, the sampling launch is the first node of the captured step and
     the metrics come back through the pinned mirror's flag (no copy node, no stream synchronisation): every returned metric and
     every parameter equal the eager run's bit for bit, and the replay counted every call.  The sampling launch also carries the critic
-    phase's re-pack (heads 1 024 wide, A <= 8: with the target heads' action-column image; PCRL_ENTRY_PACK=0: the separate launches)."""
+    phase's re-pack (heads 1 024 wide, A <= 8: with the target heads' action-column image; FusedStep.entry_pack = False: the separate launches)."""
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent
     from pointcloud_rl_amd.replay import DeviceReplay
     from pointcloud_rl_amd.synthetic import make_batch_np
-    monkeypatch.setenv("PCRL_ENTRY_PACK", entry_pack)
     B, N, steps = 8, 64, 12
 
     def run(graphs):
@@ -625,6 +624,8 @@ def test_sampling_inside_the_captured_step_equals_the_eager_run(cuda, monkeypatc
         cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
         torch.manual_seed(0)
         agent = build_agent(cfg).to(cuda)
+        agent._prepare()
+        agent._fused.entry_pack = entry_pack == "1"
         mem = DeviceReplay(64, device=cuda, seed=3)
         mem.push_batch(make_batch_np(48, N, A, seed=5))
         if graphs:
@@ -756,7 +757,7 @@ def test_drq_jitter_counter_follows_the_replay_that_feeds_the_step(cuda, monkeyp
     """DrQ's fused jitter reads its Philox offset from the replay's device draw counter (`DeviceReplay.state[0]`), an ADDRESS
     baked into the captured encoder launches.  Swapping the replay must drop the graphs captured with the old address (else the
     noise would repeat on every step: the old replay's counter no longer advances); without the sampling launch in the graph
-    (PCRL_GRAPH_SAMPLING=0) the shared counter is not used at all.  Both ways the graph-replayed run equals the eager run fed
+    (agent.graph_sampling = False) the shared counter is not used at all.  Both ways the graph-replayed run equals the eager run fed
     the same sequence bit for bit."""
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent
@@ -765,11 +766,12 @@ def test_drq_jitter_counter_follows_the_replay_that_feeds_the_step(cuda, monkeyp
     B, N, A = 8, 64, 4
     schedule = [0] * 6 + [1] * 6 + [0] * 4
 
-    def run(graphs):
+    def run(graphs, sampling):
         cfg = configs.drq_dmc(6, A, B, head_hidden=64, obs_aug=dict(configs.JITTER, seed=5))
         cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
         torch.manual_seed(0)
         agent = build_agent(cfg).to(cuda)
+        agent.graph_sampling = sampling == "1"
         rings = []
         for seed in (3, 4):
             mem = DeviceReplay(64, device=cuda, seed=seed)
@@ -784,9 +786,8 @@ def test_drq_jitter_counter_follows_the_replay_that_feeds_the_step(cuda, monkeyp
         return agent, rings, rets, ptrs
 
     for sampling in ("1", "0"):
-        monkeypatch.setenv("PCRL_GRAPH_SAMPLING", sampling)
-        eager, _, rets_e, _ = run(False)
-        graph, rings, rets_g, ptrs = run(True)
+        eager, _, rets_e, _ = run(False, sampling)
+        graph, rings, rets_g, ptrs = run(True, sampling)
         if sampling == "1":
             assert ptrs[5] == rings[0].state.data_ptr() and ptrs[11] == rings[1].state.data_ptr() and ptrs[-1] == rings[0].state.data_ptr()
         else:
@@ -989,7 +990,7 @@ def test_drq_jitter_plus_scale_step_matches_the_restatement_and_draws_fresh_matr
     for a, b in zip(seen[3:-1], seen[4:]):
         assert not torch.equal(a, b)                                                     # replayed launches drew again
     assert not torch.equal(seen[-1][0], seen[-1][1])                                     # the two calls of a step differ
-    # the first call's launch draws for both calls of the step (PCRL_AFFINE_PAIR=0: a launch per call): same matrices, same steps
+    # the first call's launch draws for both calls of the step (pair_draws = False: a launch per call): same matrices, same steps
     def replayed_losses(pair):
         torch.manual_seed(0)
         ag = build_agent(cfg).to(cuda)

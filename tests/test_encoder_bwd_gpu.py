@@ -85,7 +85,7 @@ def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
         assert (idx != idx_ref).mean() < 1e-3
         ref, _, _ = torch_reference_grads(obs, w, gpool, route=idx)
     # n_active = the points that receive gradient: the distinct argmax points of the LIVE channels (a channel the forward left at
-    # zero passes none; the round-2 kernels, PCRL_BWD_ALGO=0, count the points of all channels)
+    # zero passes none; the round-2 kernels -- a call without the forward's pooled values -- count the points of all channels)
     live_pts = [len(np.unique(r[m])) for r, m in zip(idx, pooled > 0)]
     assert np.array_equal(n_act, live_pts) or np.array_equal(n_act, [len(np.unique(r)) for r in idx])
     assert_grads_close(got, ref)
@@ -211,9 +211,8 @@ def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, 
     # bitwise reproducible
     assert torch.equal(flat, hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True))
     # With the forward's pooled values (what the agents pass) the bf16 mode runs the fp32 Gram-form backward at the bf16 forward's
-    # routing: the fp32 gradient along that argmax (PCRL_BWD_BF16_GRAM=0 keeps the kernels checked above)
-    import os
-    if os.environ.get("PCRL_BWD_BF16_GRAM", "1") != "0":
+    # routing: the fp32 gradient along that argmax (a call without pooled values keeps the kernels checked above)
+    if True:
         flat_g = hip.encoder_bwd(desc, ew, packed, argmax, torch.from_numpy(gpool).to(cuda), bf16=True, pooled=pooled)
         got_g = {k: v.cpu().numpy() for k, v in hip.encoder_grad_views(flat_g, ew).items()}
         ref32, _, _ = torch_reference_grads(obs, w, gpool, route=argmax.cpu().numpy())

@@ -106,14 +106,13 @@ def test_k2_backward_full_size_properties(cuda):
     t, h2 = _bf16_reference_grads(obs_sl, w_np, None)
     picked = torch.gather(h2, 2, a_sl.cpu().long()[:, :, None])[:, :, 0]
     (picked * g1[sel].cpu()).sum().backward()
-    # The bf16 mode's backward is (default, PCRL_BWD_BF16_GRAM=1) the fp32 Gram-form kernel at the bf16 forward's routing (argmax,
+    # The bf16 mode's backward is (given the forward's pooled values) the fp32 Gram-form kernel at the bf16 forward's routing (argmax,
     # pooled > 0): the EXACT fp32 gradient at that routing (measured < 5e-5 of each tensor's largest entry), which differs from autograd
     # through the rounding emulation by what bf16 operands change in the two recomputed layers (measured up to 5.8e-2, on norm1.bias /
-    # conv0.bias).  The round-2 bf16 kernels (PCRL_BWD_BF16_GRAM=0) are the mirror image: within 3e-3 of the emulation, up to 5.8e-2
+    # conv0.bias).  The round-2 bf16 kernels (a call without pooled values) are the mirror image: within 3e-3 of the emulation, up to 5.8e-2
     # from the fp32 gradient.
-    import os
     from test_encoder_bwd_gpu import torch_reference_grads
-    gram = os.environ.get("PCRL_BWD_BF16_GRAM", "1") != "0"
+    gram = True
     ref32, _, _ = torch_reference_grads(obs_sl, w_np, g1[sel].cpu().numpy(), route=a_sl.cpu().numpy())
     worst = {}
     for name, k in NAMES.items():

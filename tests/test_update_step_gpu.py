@@ -388,12 +388,12 @@ def test_round4_launch_cuts_equal_the_launches_they_replace(cuda, monkeypatch, k
     jit = [[torch.empty(rows, 3, N).uniform_(-0.01, 0.01, generator=g) for _ in range(2)] for _ in range(4)]
 
     def run(off):
-        for k in ("PCRL_TAIL_BWD", "PCRL_FOLD_Q0", "PCRL_ATTACH_COLSUM"):
-            monkeypatch.setenv(k, "0" if off else "1")
         cfg = configs.drq_dmc(6, A, B, head_hidden=1024) if kind == "drq" else configs.sac_dmc(6, A, B, head_hidden=1024)
         cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
         torch.manual_seed(0)
         agent = build_agent(cfg).to(cuda)
+        agent._prepare()
+        agent._fused.tail_bwd = agent._fused.fold_q0 = agent._fused.attach_colsum = not off
         mem = SyntheticReplay(B, N, A, seed=4, device=cuda)
         rets = []
         for u in range(1, 5):
