@@ -34,5 +34,24 @@ noise; two updates per case, each starting from the restatement's parameters.  T
 | case | metrics (rel) | head gradients (rel to max\\|g\\|) | encoder gradients BEFORE the events are moved (asserted <= 1e-3) | AFTER (asserted <= 2e-5) | located events of candidates | parameters with resolved gradient (abs, <= 1e-5) | other parameters (abs; bound 2.1 lr) | head ReLU decisions that differ (max \\|z\\|) | argmax entries that differ from ATen's (gap) | FREE: metrics | FREE: critic-phase head gradients | FREE: actor-phase gradients | FREE: encoder gradients | FREE: argmax entries that differ |
 |---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|
 """ + "\n".join(rows) + "\n\nLocated (and confirmed) events -- cloud, layer (0 conv0's ReLU / 1 LayerNorm-1's / 2 the pooled value's), channel, point, |pre-activation| in the restatement, shift of the encoder gradient in units of each tensor's largest entry:\n\n" + ("\n".join(events) if events else "(none)") + "\n"
+arows = []
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "parity_actor_phase_*.json"))):
+    d = json.load(open(f)); w = d["worst"]
+    arows.append(f"| `{d['case']}` | {w['actor_metric_rel']:.1e} | {w['actor_grad_rel_to_max']:.1e} | {w['alpha_grad_rel']:.1e} | {w['actor_flips']} ({w['actor_flip_max_preact']:.1e}) |")
+if arows:
+    out += """
+## The actor phase from ONE state (round 5, `test_actor_phase_from_the_restatements_post_critic_state`)
+
+The free run above starts its actor phase from ITS critic's Adam step, the HIP step from its own -- two states that differ by lr-sized amounts
+wherever an encoder event was not moved.  Here the restatement runs free (own decisions, own argmax), its parameters right after its critic
+optimizer step are captured, and the HIP step puts exactly those in place between its critic pass and its actor phase
+(`FusedStep.phase_hook`): what remains is summation order on identical inputs.  Asserted: actor-phase metrics <= 3e-5, every actor gradient
+element <= 1e-4 of its tensor's largest entry un-steered -- unless a head unit of the actor phase sits within rounding of zero (counted by a
+second pass of the restatement with the HIP step's decisions injected; every disagreement must be on |z| <= 2e-5): that case is bounded at
+5e-2 free and must be <= 1e-4 again with the located decisions injected.
+
+| case | actor-phase metrics (rel) | actor gradients, free (rel to max\\|g\\|) | temperature gradient (rel) | head units that decide by summation order (max \\|z\\|) |
+|---|---|---|---|---|
+""".replace("\\\\", "\\") + "\n".join(arows) + "\n"
 open(os.path.join(ROOT, "profiles", f"{rnd}_parity_errors.md"), "w").write(out)
 print(out)
