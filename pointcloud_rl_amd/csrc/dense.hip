@@ -698,14 +698,32 @@ __host__ __device__ constexpr int wtile_tn(int shape, int brc) { return shape ==
 // cfg 5 panel shapes: 0 = 64 x 128 (no split-K), 1 = 64 x 64 (two k halves)
 __host__ __device__ constexpr int wpanel_tn(int shape) { return shape == 0 ? 128 : 64; }
 
-__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const GemmGroup g) {
-    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-    const int wg = blockIdx.x;
+// Two kernels share the launch code.  `gemm_f32_kernel` holds the paths of rounds 1-4 (cfg 0-3) exactly as they were compiled then;
+// `gemm_f32_wt_kernel` holds every path (cfg 0-5) and runs the launches that contain a round-5 path.  ONE kernel for everything measured
+// 1-4 % slower on the 64 x 64 staged tiles (same source, another register allocation / code layout: K2's step +1.3 %), a kernel with ONLY
+// the round-5 paths measured 3.7 us slower on the grouped dW | dX launch (K1's step +4.5 us) -- tools/r5_ab2.sh, same box, three builds.
+__device__ __forceinline__ int gemm_find_problem(const GemmGroup& g, int wg) {
     int gi = 0;
 #pragma unroll
     for (int j = 1; j < kGemmGroup; ++j)
         if (j < g.n && wg >= g.wg_begin[j]) gi = j;
-    const GemmParams p = g.p[gi];
+    return gi;
+}
+
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    const int wg = blockIdx.x;
+    const GemmParams p = g.p[gemm_find_problem(g, wg)];
+    if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
+    else if (p.cfg == 2) gemm_tile32_wave(p, wg);
+    else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
+    else gemm_tile32_splitk(p, wg, gemm_smem);
+}
+
+__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_wt_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    const int wg = blockIdx.x;
+    const GemmParams p = g.p[gemm_find_problem(g, wg)];
     if (p.cfg == 4) {
         if (!p.b_rc) {
             if (p.shape == 0) gemm_wtile<16, 1, 1, 32, false, 2>(p, wg, gemm_smem);
@@ -930,12 +948,16 @@ static int gemm_fill_common(const pcrl_gemm_desc* d, GemmParams& p, GemmPlan& pl
     p.a_rc = !pl.a_kc; p.b_rc = !pl.b_kc;
     // dense_wtile.h: A staged in 16-byte pieces along k (K % 4 == 0: a piece lies inside K or outside), a contraction long enough to give
     // the eight k slices something to do, no column of ones
-    const bool a_stage = pl.a_kc && d->K % 4 == 0 && d->K >= 128 && d->ones_col < 0 && d->M > 0 && d->N > 0;
+    // (K >= 512: the 1 024-wide layers.  A short contraction -- K3 / K2's first layers, K = 196 -- pays the staging prologue for two chunks
+    // and measured slower than the split-K tiles inside the step, tools/r5_ab2.sh)
+    const bool a_stage = pl.a_kc && d->K % 4 == 0 && d->K >= 512 && d->ones_col < 0 && d->M > 0 && d->N > 0;
     pl.kind_f = a_stage && pl.b_kc;
     pl.kind_x = a_stage && !pl.b_kc && d->b_stride_n == 1;
     // ... weight gradient: both operands contiguous along their row index and readable in 16-byte pieces of four rows, the ones column last
     const int n_real = d->ones_col >= 0 ? d->ones_col : d->N;
-    pl.kind_w = a_rc && b_rc && d->M % 4 == 0 && n_real % 4 == 0 && d->M >= 64 && n_real >= 64 && d->K >= 1 &&
+    // ... and an output large enough to give the chip a few dozen 64 x 64 panels (the heads' 1 024-wide layers; the feature head's
+    // 128 x 256 weight gradient would be 8 workgroups)
+    pl.kind_w = a_rc && b_rc && d->M % 4 == 0 && n_real % 4 == 0 && d->M >= 256 && n_real >= 256 && d->K >= 1 &&
                 (d->ones_col < 0 || d->ones_col == d->N - 1);
     return PCRL_OK;
 }
@@ -967,7 +989,7 @@ static void gemm_pick_legacy(const pcrl_gemm_desc* d, GemmParams& p, int& tm, in
 }
 
 // Tile paths, workgroup ranges and the LDS size of one launch; src[i] = the caller's index of the launch's i-th problem.
-static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_t& lds, int& wg_total, int (&src)[kGemmGroup]) {
+static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_t& lds, int& wg_total_out, int (&src)[kGemmGroup], bool& use_wt_kernel) {
     if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
     // Workgroups are dispatched in index order: a problem with a long K loop and few tiles (the data gradient of a small batch:
     // K = 1 024, <= 256 tiles) goes first, so that its few long workgroups start at once and the many short ones of its
@@ -993,7 +1015,7 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         dd[g.n] = d; src[g.n] = order[oi];
         if (d->M > 0 && d->N > 0) ++g.n;        // empty problems contribute no workgroups
     }
-    wg_total = 0; lds = 0;
+    wg_total_out = 0; lds = 0; use_wt_kernel = false;
     if (g.n == 0) return PCRL_OK;
     const bool legacy = legacy_only(), force64 = tile64_min_tiles() <= 1;
     const int cus = num_cus();
@@ -1006,6 +1028,8 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
     }
     if (!force64 && tiles64 < tile64_min_tiles())
         for (int i = 0; i < g.n; ++i) use64[i] = false;
+    int wg_total = 0;
+    bool any_new = false;
     for (int i = 0; i < g.n; ++i) {
         const pcrl_gemm_desc* d = dd[i];
         GemmParams& p = g.p[i];
@@ -1038,12 +1062,15 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         } else {
             gemm_pick_legacy(d, p, tm, tn);
         }
+        any_new = any_new || p.cfg >= 4;
         gemm_set_tiles(p, tm, tn, n_cols, d->batch, wg_total);
         g.wg_begin[i] = p.wg_begin;
         const size_t need = gemm_lds_bytes(p);
         lds = need > lds ? need : lds;
     }
+    const bool wt_kernel = any_new;          // a launch without a round-5 path runs the rounds-1-4 kernel exactly as it was
     if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
+    wg_total_out = wg_total; use_wt_kernel = wt_kernel;
     return PCRL_OK;
 }
 
@@ -1051,11 +1078,18 @@ extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void*
     GemmGroup g;
     size_t lds;
     int wg_total, src[kGemmGroup];
-    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src)) return rc;
+    bool wt;
+    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src, wt)) return rc;
     if (g.n == 0 || wg_total == 0) return PCRL_OK;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), 160 * 1024)) return rc;
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
-    PCRL_CHECK_LAUNCH("gemm_f32_kernel");
+    if (wt) {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_wt_kernel), 160 * 1024)) return rc;
+        hipLaunchKernelGGL(gemm_f32_wt_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
+        PCRL_CHECK_LAUNCH("gemm_f32_wt_kernel");
+    } else {
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), kGemmLdsBytes)) return rc;
+        hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
+        PCRL_CHECK_LAUNCH("gemm_f32_kernel");
+    }
     return PCRL_OK;
 }
 
@@ -1064,7 +1098,8 @@ extern "C" int pcrl_gemm_group_plan_f32(const pcrl_gemm_desc* descs, int32_t n, 
     GemmGroup g;
     size_t lds;
     int wg_total, src[kGemmGroup];
-    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src)) return rc;
+    bool wt;
+    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src, wt)) return rc;
     for (int i = 0; i < n; ++i) { out[3 * i] = -1; out[3 * i + 1] = 0; out[3 * i + 2] = 0; }
     for (int i = 0; i < g.n; ++i) { out[3 * src[i]] = g.p[i].cfg; out[3 * src[i] + 1] = g.p[i].shape; out[3 * src[i] + 2] = g.p[i].tiles; }
     return PCRL_OK;

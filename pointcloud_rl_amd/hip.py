@@ -386,6 +386,10 @@ def gemm_group(descs):
         check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
 
 
+if os.environ.get("PCRL_GEMM_PATHS") == "legacy":      # measurement only (tools/r5_ab*.sh): the rounds-1-4 tile paths in this build
+    lib().pcrl_gemm_set_tile64_min(1 << 30)
+
+
 def gemm_plan(descs):
     """[(path, tile shape, workgroups)] pcrl_gemm_group_f32 would use for these problems (include/pcrl.h: pcrl_gemm_group_plan_f32)."""
     descs = [d for d in descs if d is not None]

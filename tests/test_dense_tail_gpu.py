@@ -92,7 +92,7 @@ def _weight_gradient_case(cuda, path, M, N, K, kind):
         bias, mask = g.randn(H, N).astype(np.float32), (g.rand(H, M, N) < 0.6).astype(np.float32)
         C = torch.full((H, M, N), float("nan"), device=cuda)
         plan = hip.gemm_plan([hip.gemm_desc(A_, B_, C, M, N, K, (1, M), (N, 1), N, batch=H, batch_strides=(K * M, K * N, M * N, N, M * N))])
-        assert plan[0][0] == (5 if path == "auto" and M % 4 == 0 and N % 4 == 0 else 3 if M % 2 == 0 else 2), plan
+        assert plan[0][0] == (5 if path == "auto" and M % 4 == 0 and N % 4 == 0 and min(M, N) >= 256 else 3 if M % 2 == 0 else 2), plan
         hip.gemm(A_, B_, C, M, N, K, (1, M), (N, 1), N, bias=T(bias, cuda), mask=T(mask, cuda), ld_mask=N, relu=True, batch=H,
                  batch_strides=(K * M, K * N, M * N, N, M * N))
         want = np.maximum(ref + bias[:, None, :], 0) * mask
@@ -107,7 +107,7 @@ def _weight_gradient_case(cuda, path, M, N, K, kind):
         d = hip.gemm_desc(A_, B1, C, M, N, K, (1, M), (N - 1, 1), N, ones_col=N - 1, batch=H, batch_strides=(K * M, K * (N - 1), M * N, 0, 0),
                           c_ones=ones, c_ones_batch_stride=M)
         if path == "auto":
-            assert (hip.gemm_plan([d])[0][0] == 5) == (M % 4 == 0 and (N - 1) % 4 == 0), hip.gemm_plan([d])
+            assert (hip.gemm_plan([d])[0][0] == 5) == (M % 4 == 0 and (N - 1) % 4 == 0 and min(M, N - 1) >= 256), hip.gemm_plan([d])
         hip.gemm_group([d])
         np.testing.assert_allclose(C[:, :, :N - 1].cpu().numpy(), ref[:, :, :N - 1], atol=2e-4, rtol=1e-5)
         np.testing.assert_allclose(ones.cpu().numpy(), a.astype(np.float64).sum(1), atol=2e-4, rtol=1e-5)
@@ -121,11 +121,11 @@ def _weight_gradient_case(cuda, path, M, N, K, kind):
 
 @pytest.mark.parametrize("kind", ["forward", "data-gradient"])
 @pytest.mark.parametrize("M,N,K,H,want_shape", [(32, 1024, 1024, 1, 0), (32, 1024, 1024, 4, 1), (64, 1024, 1024, 4, 2), (128, 1024, 1024, 1, 1),
-                                                (256, 1024, 1024, 1, 2), (256, 1024, 1024, 2, 3), (37, 50, 1000, 2, 0), (5, 3, 128, 1, 0),
-                                                (300, 1030, 196, 1, None), (256, 50, 1024, 2, 0), (100, 520, 260, 3, None), (128, 1024, 1024, 4, 3)])
+                                                (256, 1024, 1024, 1, 2), (256, 1024, 1024, 2, 3), (37, 50, 1000, 2, 0), (5, 3, 512, 1, 0),
+                                                (300, 1030, 516, 1, None), (256, 50, 1024, 2, 0), (100, 520, 772, 3, None), (128, 1024, 1024, 4, 3)])
 def test_wave_private_staged_tiles(cuda, kind, M, N, K, H, want_shape):
     """dense_wtile.h::gemm_wtile: every tile shape (16 x 16 ... 32 x 64 outputs, v_mfma_f32_16x16x4_f32 and 32x32x2 blocks), forward-shaped
-    (A, B k-contiguous) and data-gradient-shaped (B contiguous along n), ragged M / N / K (K % 4 == 0), heads batched; bias + ReLU resp.
+    (A, B k-contiguous) and data-gradient-shaped (B contiguous along n), ragged M / N / K (K % 4 == 0, K >= 512), heads batched; bias + ReLU resp.
     the ReLU mask of the layer input, and accumulation -- against float64.  The launch plan must say the shape is reached."""
     from pointcloud_rl_amd import hip
     g = np.random.RandomState(M + N + K + H)

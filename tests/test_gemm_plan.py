@@ -67,14 +67,16 @@ def test_weight_gradient_panels_and_their_fallbacks():
     assert plan([wgrad(1024, 1024, 256, 2)]) == [(5, 0, 256)]          # 64 x 128 panels: one per CU
     assert plan([wgrad(1024, 1024, 256, 1)]) == [(5, 1, 256)]          # 64 x 64
     assert plan([wgrad(1024, 1024, 32, 2)]) == [(5, 0, 256)]
-    assert plan([wgrad(1024, 56, 256, 2)]) == [(0, 0, 128)]            # fewer than 64 real columns: 32 x 32 split-K tiles
+    assert plan([wgrad(1024, 56, 256, 2)]) == [(0, 0, 128)]            # fewer than 256 real columns: 32 x 32 split-K tiles
+    assert plan([wgrad(128, 256, 512, 1)])[0][0] == 0                  # the feature head's weight gradient: too few panels to be worth it
     assert plan([wgrad(1022, 1024, 256, 2)])[0][0] == 3                # M % 4 != 0: a tile per wave (pairs of rows)
     assert plan([wgrad(1024, 1024, 256, 2, ones=False)]) == [(5, 0, 256)]
 
 
 def test_short_or_odd_contractions_keep_the_split_k_tiles():
-    assert plan([fwd(256, 1024, 56)])[0][0] == 0                       # K < 128
-    assert plan([fwd(256, 1024, 130)])[0][0] == 0                      # K % 4 != 0
+    assert plan([fwd(256, 1024, 56)])[0][0] == 0                       # K < 512
+    assert plan([fwd(512, 1024, 196)])[0][0] == 0                      # K3 / K2's first layers: the staging prologue does not pay for two chunks
+    assert plan([fwd(256, 1024, 1022)])[0][0] == 0                     # K % 4 != 0
     assert plan([fwd(256, 1024, 1024, a_off=1)])[0][0] == 0             # A not 16-byte aligned
     assert plan([desc(0, 5, 8, (8, 1), (1, 8))]) == [(-1, 0, 0)]       # empty problem
 
@@ -94,3 +96,10 @@ def test_a_group_keeps_each_problems_own_path_and_dispatches_the_long_k_problem_
     assert [g[0] for g in got] == [5, 4, 0, 4]
     with pytest.raises(_lib.PcrlError):
         plan([fwd(8, 8, 8)] * 5)
+
+
+def test_a_mixed_launch_keeps_each_problems_path():
+    # the four-head forward takes the 64 x 64 staged tiles, its neighbour its wave tiles
+    got = plan([fwd(256, 1024, 1024, 4), fwd(128, 1024, 1024)])
+    assert got[0][0] == 1 and got[1][0] == 4, got                # each problem keeps its own path: the launch takes the kernel that has both
+    assert plan([fwd(128, 1024, 1024)])[0][0] == 4

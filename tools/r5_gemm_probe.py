@@ -14,7 +14,7 @@ H = 1024
 def shapes(torch, hip, dev):
     def t(*s):
         return torch.randn(*s, device=dev)
-    for M in (32, 64, 128, 256):
+    for M in [int(x) for x in os.environ.get("GEMM_MS", "32,64,128,256").split(",")]:
         h4, W4 = t(4, M, H), t(4, H, H)
         for heads in (1, 2, 4):
             for K in (0, 32, 256, 1024):
@@ -52,7 +52,7 @@ def run(label_path):
 def fold(trace_dir, label_path):
     import csv, glob
     f = glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "gemm_f32_kernel" in r["Kernel_Name"]))
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "gemm_f32_" in r["Kernel_Name"]))
     labels = [l.split("\t") for l in open(label_path).read().strip().splitlines()]
     assert len(rows) == REPS * len(labels), (len(rows), len(labels))
     for i, (name, flops) in enumerate(labels):
