@@ -84,3 +84,39 @@ def test_parameter_draw_ranges_and_order():
     assert fac[0] is None and fac[1] is None and fac[3] is None and 0.5 <= fac[2] <= 1.5
     order, fac = cj.draw_params(1.5, 0, 0, 0)
     assert 0.0 <= fac[0] <= 2.5                                        # the lower end is clipped at 0
+
+
+def test_every_step_agrees_with_pillows_own_implementation_of_the_same_operations():
+    """An independent implementation: Pillow's ImageEnhance.Brightness / Contrast / Color and its RGB <-> HSV conversion are what
+    torchvision's OTHER backend (functional_pil) calls for the same four operations, and torchvision's own test-suite holds its tensor
+    backend (restated in oracle/color_jitter_ref.py) to the PIL backend within a count or two per channel.  Same bound here on a random
+    uint8 image: brightness / contrast / saturation within 1 count (PIL rounds where the tensor path truncates), hue within the few
+    counts PIL's 8-bit HSV round trip costs.  This does not pin the oracle to torchvision (N3 stays "parity unpinned"), it rules out
+    a wrong weight, blend direction, mean or rotation direction."""
+    import pytest
+    pytest.importorskip("PIL")
+    from PIL import Image, ImageEnhance
+    import numpy as np
+    from oracle import color_jitter_ref as cj
+    g = np.random.RandomState(0)
+    N = 4096
+    rgb = g.randint(0, 256, (1, 3, N)).astype(np.uint8)
+    img = Image.fromarray(np.ascontiguousarray(rgb[0].T.reshape(1, N, 3)), "RGB")            # a 1 x N image, as the reference views a cloud
+    t = torch.from_numpy(rgb)
+
+    def to_np(pil):
+        return np.asarray(pil).reshape(N, 3).T.astype(np.int32)
+    for op, enh in ((0, ImageEnhance.Brightness), (1, ImageEnhance.Contrast), (2, ImageEnhance.Color)):
+        for f in (0.5, 0.83, 1.0, 1.37):
+            factors = [None] * 4
+            factors[op] = f
+            got = cj.color_jitter(t, [op], factors)[0].numpy().astype(np.int32)
+            want = to_np(enh(img).enhance(f))
+            assert np.abs(got - want).max() <= 1, (op, f, np.abs(got - want).max())
+    for f in (-0.4, -0.1, 0.0, 0.25, 0.5):
+        got = cj.color_jitter(t, [3], [None, None, None, f])[0].numpy().astype(np.int32)
+        h, s, v = img.convert("HSV").split()
+        h = Image.fromarray(((np.asarray(h).astype(np.int32) + (int(f * 255) % 256)) % 256).astype(np.uint8), "L")   # functional_pil.adjust_hue
+        want = to_np(Image.merge("HSV", (h, s, v)).convert("RGB"))
+        d = np.abs(got - want)
+        assert d.mean() <= 2.5 and np.percentile(d, 99) <= 16, (f, d.mean(), d.max())     # (one step of PIL's 8-bit hue is up to ~6 counts of a saturated channel)
