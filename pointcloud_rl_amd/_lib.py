@@ -101,23 +101,58 @@ _lib = None
 RUNTIME_LINKS = os.path.join(_HERE, "_hiprt")
 
 
+def _needed_hip_soname():
+    """The name under which libpcrl_hip.so asks the loader for the HIP runtime (its DT_NEEDED entry, e.g. libamdhip64.so.7), read from the
+    built library itself; None when it cannot be read (library not built, no binutils)."""
+    import re
+    import subprocess
+    if not os.path.exists(LIB_PATH):
+        return None
+    for tool in ("readelf", "/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        try:
+            out = subprocess.run([tool, "-d", LIB_PATH], capture_output=True, text=True, timeout=30).stdout
+        except (OSError, subprocess.SubprocessError):
+            continue
+        m = re.search(r"\(NEEDED\)[^\[]*\[(libamdhip64\.so[^\]]*)\]", out)
+        if m:
+            return m.group(1)
+    return None
+
+
 def ensure_runtime_links():
     """Create pointcloud_rl_amd/_hiprt (machine-local, idempotent): symlinks to the HIP runtime torch's wheel bundles, which
     libpcrl_hip.so searches first (RPATH $ORIGIN/_hiprt, csrc/Makefile) -- so that a process holds ONE HIP runtime whether it maps
     the library before or after `import torch`.  Without torch installed nothing is created and the library uses /opt/rocm's.
-    torch is located, not imported.  Returns the directory or None."""
+    torch is located, not imported.  The link that satisfies the library's DT_NEEDED carries the name the LIBRARY asks for (read from its
+    dynamic section) and is only made when torch's bundled runtime reports the same soname -- a wheel bundling another ROCm major must
+    not be handed to a `.so.N` request.  Returns the directory or None."""
     import importlib.util
     spec = importlib.util.find_spec("torch")
     if spec is None or not spec.origin:
         return None
     src = os.path.join(os.path.dirname(spec.origin), "lib")
-    if not os.path.exists(os.path.join(src, "libamdhip64.so")):
+    bundled = os.path.join(src, "libamdhip64.so")
+    if not os.path.exists(bundled):
         return None
-    marker = os.path.join(RUNTIME_LINKS, "libamdhip64.so.7")
-    if os.path.islink(marker) and os.path.realpath(marker) == os.path.realpath(os.path.join(src, "libamdhip64.so")):
+    needed = _needed_hip_soname() or "libamdhip64.so.7"
+    if needed != "libamdhip64.so":
+        # torch's copy must BE that ABI: its own soname (when readable) has to match the request
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["readelf", "-d", bundled], capture_output=True, text=True, timeout=60).stdout
+            m = re.search(r"\(SONAME\)[^\[]*\[([^\]]*)\]", out)
+            if m and m.group(1) != needed:
+                return None
+        except (OSError, subprocess.SubprocessError):
+            pass
+    marker = os.path.join(RUNTIME_LINKS, needed)
+    fresh = lambda: os.path.islink(marker) and os.path.realpath(marker) == os.path.realpath(bundled)
+    if fresh():
         return RUNTIME_LINKS
-    # Built aside and moved into place in one rename: the ranks of a multi-GPU launch may all get here at once on a fresh machine,
-    # and a loader must never see a half-made directory.
+    # Built aside and moved into place by renames only: the ranks of a multi-GPU launch may all get here at once on a fresh machine, and
+    # a loader must never see a missing or half-made directory.  A stale set (another torch installation) is first renamed ASIDE, the new
+    # one renamed in, the old one deleted afterwards; whoever loses a rename re-checks the marker instead of deleting what a peer just made.
     import shutil
     tmp = f"{RUNTIME_LINKS}.tmp.{os.getpid()}"
     shutil.rmtree(tmp, ignore_errors=True)
@@ -125,14 +160,22 @@ def ensure_runtime_links():
     for name in sorted(os.listdir(src)):
         if ".so" in name and os.path.isfile(os.path.join(src, name)):
             os.symlink(os.path.join(src, name), os.path.join(tmp, name))
-    os.symlink(os.path.join(src, "libamdhip64.so"), os.path.join(tmp, "libamdhip64.so.7"))   # the name libpcrl_hip.so asks for (NEEDED = the soname)
-    if os.path.isdir(RUNTIME_LINKS):                  # a stale set (another torch installation): replace it
-        shutil.rmtree(RUNTIME_LINKS, ignore_errors=True)
+    if not os.path.lexists(os.path.join(tmp, needed)):
+        os.symlink(bundled, os.path.join(tmp, needed))
+    old = None
+    if os.path.isdir(RUNTIME_LINKS) and not fresh():
+        old = f"{RUNTIME_LINKS}.old.{os.getpid()}"
+        try:
+            os.rename(RUNTIME_LINKS, old)
+        except OSError:
+            old = None                                # a peer moved it first
     try:
         os.rename(tmp, RUNTIME_LINKS)
     except OSError:                                   # another process won the race: its directory is as good as this one
         shutil.rmtree(tmp, ignore_errors=True)
-    return RUNTIME_LINKS if os.path.islink(marker) else None
+    if old:
+        shutil.rmtree(old, ignore_errors=True)
+    return RUNTIME_LINKS if fresh() else None
 
 
 def lib():

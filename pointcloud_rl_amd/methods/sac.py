@@ -105,8 +105,26 @@ class HipAdam(torch.optim.Optimizer):
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.workspace = torch.empty(hip.adam_workspace_bytes(flat.data.numel()), dtype=torch.uint8, device=dev)
 
+    _OWN_STATE = ("flat", "exp_avg", "exp_avg_sq", "step_counter", "grad_norm", "workspace")
+
+    def __getstate__(self):
+        """pickle / copy.deepcopy: torch's Optimizer.__getstate__ keeps defaults / state / param_groups only -- the flat buffers, the
+        moments and the device step count are this optimizer's state and travel with it.  (A deep copy owns copies of the flat
+        buffers; the copied param_groups still name the ORIGINAL module's tensors, as for any torch optimizer copied without its module:
+        copy the agent, not the optimizer.)"""
+        state = super().__getstate__()
+        state.update({k: getattr(self, k) for k in self._OWN_STATE})
+        return state
+
+    def __setstate__(self, state):
+        own = {k: state.pop(k) for k in self._OWN_STATE if k in state}
+        super().__setstate__(state)
+        self.__dict__.update(own)
+
     def zero_grad(self, set_to_none=False):
-        """Gradients are views of the flat gradient buffer the kernels write: zeroed in place, never set to None."""
+        """Gradients are views of the flat gradient buffer the kernels write: zeroed in place, never set to None.  (The class-level
+        `step` is wrapped by torch's profile hook like every Optimizer's: a `record_function` per EAGER step; a replayed hipGraph
+        does not pass through it.)"""
         self.flat.zero_grad()
 
     def hyper(self):

@@ -107,3 +107,25 @@ def test_only_capture_and_collective_failures_select_the_segmented_schedule():
     for text in no:
         assert not _is_capture_error(RuntimeError(text)), text
     assert not _is_capture_error(AssertionError("stream is capturing"))
+
+
+def test_the_fused_optimizer_survives_deepcopy_and_pickle(monkeypatch):
+    """torch's Optimizer.__getstate__ keeps defaults / state / param_groups only; HipAdam's flat buffers, moments and device step count
+    travel with it.  Plain tensor bookkeeping: runs without a GPU."""
+    import copy
+    import pickle
+    import torch
+    import pointcloud_rl_amd.hip as hip
+    from pointcloud_rl_amd.methods.sac import FlatBuffer, HipAdam
+    monkeypatch.setattr(hip, "adam_workspace_bytes", lambda n: 64)
+    p1, p2 = torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(3, 2))
+    opt = HipAdam(FlatBuffer([("a", p1), ("b", p2)]), lr=3e-4)
+    opt.exp_avg.fill_(2.0)
+    opt.exp_avg_sq.fill_(0.5)
+    opt.step_counter.fill_(7)
+    for clone in (copy.deepcopy(opt), pickle.loads(pickle.dumps(opt))):
+        assert isinstance(clone, HipAdam) and len(clone.param_groups) == 2 and clone.param_groups[0]["lr"] == 3e-4
+        assert torch.equal(clone.exp_avg, opt.exp_avg) and torch.equal(clone.exp_avg_sq, opt.exp_avg_sq) and int(clone.step_counter) == 7
+        assert clone.flat is not opt.flat and torch.equal(clone.flat.data, opt.flat.data)
+        sd = clone.state_dict()
+        assert float(sd["state"][0]["step"]) == 7.0 and torch.equal(sd["state"][1]["exp_avg"], torch.full((3, 2), 2.0))
