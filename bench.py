@@ -203,8 +203,13 @@ def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, he
     heads = (2.5 * f_a + 11 * f_q) * b_global * num_aug
     peak = 2500.0 if is_bf16 else 157.3
     tf = (enc + heads) / (ms_per_step * 1e-3) / 1e12
+    # what is certainly EXECUTED: the 2.5 forward point-passes (2 + the actor's half) and the heads; the backward reaches <= c3 points of a cloud
+    fwd_only = ((2.0 * P + 0.5 * b_global * wl["N"]) * f_pt + heads) / (ms_per_step * 1e-3) / 1e12
     return {"canonical_gflop_per_step": (enc + heads) / 1e9, "encoder_gflop": enc / 1e9, "heads_gflop": heads / 1e9, "achieved": tf, "unit": "TFLOP/s",
-            "peak": peak, "frac": tf / peak, "note": "canonical (dense-backward) FLOPs of SURVEY.md 8(d) per measured step time; executed FLOPs are lower"}
+            "peak": peak, "frac": tf / peak, "executed_lower_bound_frac": fwd_only / peak,
+            "note": "canonical (dense-backward) FLOPs of SURVEY.md 8(d) per measured step time: a rate of USEFUL work, not pipe utilisation -- the "
+                    "max-pool's gradient reaches <= c3 points of a cloud, so the executed backward is a fraction c3 / N of the canonical one and `frac` "
+                    "may exceed 1 for large N (config 5); `executed_lower_bound_frac` counts the forward passes and the heads only"}
 
 
 def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True, roofline=False,
