@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void encoder_bwdg_prep_kernel(const BwdParams 
     extern __shared__ __attribute__((aligned(16))) unsigned s_words[];   // [nW] bitmap, then [nW] exclusive prefix popcounts
     __shared__ int s_scan[256];
     __shared__ __attribute__((aligned(4))) unsigned char s_slot[kC3];
+    __shared__ int s_lastpc;
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= p.cl.B) {          // the blocks behind the clouds build the Gram image
         gram_tile<kC2, kC3>(p.w2, p.mimg, (int)blockIdx.x - p.cl.B, tid, reinterpret_cast<float*>(s_words));
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void encoder_bwdg_prep_kernel(const BwdParams 
             p.slot[(long long)b * kC3 + tid] = live ? (unsigned char)slot : (unsigned char)0;
             if (live) {
                 p.act[(long long)b * kC3 + slot] = pc;               // every channel of the point writes the same value
+                if (slot == n_act - 1) s_lastpc = pc;
             } else {
                 float* pw = p.pw + (long long)b * p.pw_stride;
                 pw[GL.g2() + tid] = 0.0f;
@@ -266,14 +268,24 @@ __global__ __launch_bounds__(256) void encoder_bwdg_prep_kernel(const BwdParams 
             if (w < (tid >> 6)) base2 += s_scan[4 + w];
         int pos = base2 + inc2 - cnt;
         if (tid < kC3) p.own[(long long)b * kC3 + tid] = (unsigned)pos | ((unsigned)cnt << 16);
+        unsigned long long first8 = ~0ull;      // the slot's first eight channels, one byte each (0xFF: none) -- the team kernel's prefetch
+        int nth = 0;
 #pragma unroll
         for (int k = 0; k < kC3 / 32; ++k) {
             unsigned m = mine[k];
             while (m) {
-                p.own_chan[(long long)b * kC3 + pos] = (unsigned char)(32 * k + __builtin_ctz(m));
+                const unsigned c = (unsigned)(32 * k + __builtin_ctz(m));
+                p.own_chan[(long long)b * kC3 + pos] = (unsigned char)c;
+                if (nth < 8) first8 = (first8 & ~(0xFFull << (8 * nth))) | ((unsigned long long)c << (8 * nth));
                 m &= m - 1u;
-                ++pos;
+                ++pos; ++nth;
             }
+        }
+        if (tid < kC3) p.own_pack[(long long)b * kC3 + tid] = first8;
+        // the slots between n_act and the end of its tile repeat the last active point and own nothing: a tile's loads need no n_act
+        if (tid >= n_act && tid < ((n_act + 31) & ~31) && tid < kC3) {
+            p.act[(long long)b * kC3 + tid] = n_act > 0 ? s_lastpc : 0;
+            p.own[(long long)b * kC3 + tid] = 0u;
         }
     }
 }
@@ -1152,13 +1164,20 @@ __global__ __launch_bounds__(256) void encoder_bwdg_finish_kernel(const float* _
 }
 #endif  // PCRL_BWD_MODE == 4
 
+// floats of one workgroup row of the team kernel (FusedRow::total(), encoder_bwd_fused.h)
+__host__ __device__ constexpr int fused_row_floats(int C, int C1, int C2, int C3) {
+    return (C1 * C + C1 + C2 * C1 + 2 * C2 + 2 * C3 + (C2 / 32) * (C2 / 32 + 1) / 2 * 1024 + 2 * C2 + 63) & ~63;
+}
+
 static size_t bwdg_lds_bytes_points(int T0, int C1, int kC2, int kC3) {
     return sizeof(ChanSrc) * PCRL_MAX_CHANNELS + 4 * (size_t)(kMaxTileModeClouds + 8) +
            sizeof(float) * (2 * kC2 + 2 * kC3 + C1 + (size_t)(C1 / 32) * T0 * 64 + kC2 + (size_t)bwdg_m_lds_floats(kC2) + 4 * 8 * 33 * 4);
 }
 
+constexpr int kFusedMaxRows = 1024;     // workgroups of the team kernel (encoder_bwd_fused.h): two per CU
 struct BwdgWorkspace {
-    size_t ops, pw, nact, act, slot, own, own_chan, ptc, chc, n1part, gvu, mimg, total;
+    size_t ops, pw, nact, act, slot, own, own_chan, ptc, chc, n1part, gvu, mimg, wgrows, nitems, own_pack, total;
+    int fused_rows;
 };
 static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     const OpsLayoutG OL{C1 / 32, kC2 / 32, bwdg_np(kC3)};
@@ -1179,7 +1198,11 @@ static BwdgWorkspace bwdg_workspace(int B, int C, int C1, int kC2, int kC3) {
     w.n1part = al(w.chc + sizeof(float) * (size_t)B * kC3);
     w.gvu = al(w.n1part + sizeof(float) * (size_t)B * bwdg_tpc(kC3) * kC2 * 2);
     w.mimg = al(w.gvu + sizeof(float) * (size_t)GX.total());
-    w.total = al(w.mimg + sizeof(float) * ((size_t)kC2 * kC2 + kC2 + 3 * (size_t)kC2 * kC2 / 2));     // fp32 image, s, three bf16 term images
+    w.wgrows = al(w.mimg + sizeof(float) * ((size_t)kC2 * kC2 + kC2 + 3 * (size_t)kC2 * kC2 / 2));     // fp32 image, s, three bf16 term images
+    w.fused_rows = (int)std::min<size_t>(kFusedMaxRows, (size_t)B * bwdg_tpc(kC3));
+    w.nitems = al(w.wgrows + sizeof(float) * (size_t)w.fused_rows * fused_row_floats(C, C1, kC2, kC3));
+    w.own_pack = al(w.nitems + 64);
+    w.total = al(w.own_pack + sizeof(unsigned long long) * (size_t)B * kC3);
     return w;
 }
 
@@ -1187,6 +1210,9 @@ int encoder_bwdg_launch_f32(int T0, int c1, int c2, int c3, const BwdParams& p, 
 int encoder_bwdg_launch_split(int T0, int c1, int c2, int c3, const BwdParams& p, hipStream_t st);
 
 #if PCRL_BWD_MODE == 4
+#if PCRL_BWDG_ARITH == 0
+#include "encoder_bwd_fused.h"
+#endif
 // PCRL_BWDG_SYNC=1 (development): synchronise after every launch so that a faulting kernel is named.
 #define PCRL_BWDG_AFTER(name)                                                                                     \
     do {                                                                                                           \
@@ -1242,6 +1268,40 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
         PCRL_BWDG_AFTER("encoder_bwdg_prep_kernel");
     }
     if (p.phase == 1) return PCRL_OK;
+#if PCRL_BWDG_ARITH == 0
+    if constexpr (C2 == 128 && C3 == 256 && (C1 == 64 || C1 == 128)) {
+        if (p.fused) {
+            // the team kernel (encoder_bwd_fused.h): chain + weight-gradient sums in one launch, then the reduce over the workgroup rows
+            auto kern = encoder_bwdg_fused_kernel<T0, C1, C2, C3>;
+            const size_t flds = fused_lds_bytes(T0, C1, C2, C3);
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), flds)) return rc;
+            static int occ = 0;           // resident workgroups per CU (registers and LDS decide; the same for every shape of a build's C1)
+            int occ_now = occ;
+            if (!occ_now) {
+                int n = 0;
+                PCRL_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 64 * kFusedWaves, flds));
+                occ_now = n < 1 ? 1 : (n > 2 ? 2 : n);
+                occ = occ_now;
+            }
+            const int grid = std::min(std::min(num_cus() * occ_now, p.fused_rows), p.cl.B * bwdg_tpc(C3));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kFusedWaves), flds, stream, p);
+            PCRL_BWDG_AFTER("encoder_bwdg_fused_kernel");
+            const GradLayout GL{p.cl.C, C1, C2, C3};
+            const FusedRow FR{p.cl.C, C1, C2, C3};
+            const int row_blocks = (FR.total() + 63) / 64, main_blocks = row_blocks + C3 * C2 / 64;
+            hipLaunchKernelGGL(encoder_bwdg_reduce_fused_kernel<C2>, dim3(main_blocks + p.cs_blocks), dim3(1024), 0, stream, p.wgrows, grid, p.n_items, FR, GL,
+                               p.srows, p.chc, p.cl.B, p.grads, p.gvu, p.cs, row_blocks, main_blocks);
+            PCRL_BWDG_AFTER("encoder_bwdg_reduce_fused_kernel");
+            constexpr int rows = (256 / C2) * 2;
+            constexpr size_t fin_lds = sizeof(float) * ((size_t)C2 * C2 + (size_t)rows * C2);
+            auto fin = encoder_bwdg_finish_kernel<C2>;
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(fin), fin_lds)) return rc;
+            hipLaunchKernelGGL(fin, dim3((C3 + rows - 1) / rows), dim3(256), fin_lds, stream, p.w2, p.gvu, C3, p.grads + GL.w2());
+            PCRL_BWDG_AFTER("encoder_bwdg_finish_kernel");
+            return PCRL_OK;
+        }
+    }
+#endif
     const size_t lds = bwdg_lds_bytes_points(T0, C1, C2, C3);
     {   // (an eight-wave build -- two tiles in flight per SIMD, 256 registers each -- spilled ~150 registers and measured slower at
         // every batch size: B 256 175 vs 164 us, K3's 1024 clouds 864 vs 785 us, 512 x 8192 388 vs 339 us)
@@ -1306,6 +1366,11 @@ extern "C" int pcrl_debug_bwdg_stamps(unsigned long long* tiles_out, int n_items
     if (hipDeviceSynchronize() != hipSuccess) return -3;
     if (hipMemcpyFromSymbol(tiles_out, HIP_SYMBOL(pcrl::g_bwdg_stamps), sizeof(unsigned long long) * 12 * (size_t)n_items) != hipSuccess) return -3;
     if (hipMemcpyFromSymbol(waves_out, HIP_SYMBOL(pcrl::g_bwdg_wstamps), sizeof(unsigned long long) * 8 * (size_t)n_waves) != hipSuccess) return -3;
+    return 0;
+}
+extern "C" int pcrl_debug_fused_stamps(unsigned long long* out, int n_items) {
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcrl::g_fused_stamps), sizeof(unsigned long long) * 64 * (size_t)n_items) != hipSuccess) return -3;
     return 0;
 }
 #endif

@@ -99,6 +99,13 @@ struct BwdParams {
     float* mimg;             // [C2*C2 + C2] M = W2^T W2 in A-operand order, then s = W2^T 1 (built by the prep launch)
     int pw_stride;           // floats per cloud in pw (GradLayout.total() [+ C2*C2 + 2*C2 in the Gram form])
     int phase;               // Gram form, host side: 0 whole backward, 1 the prep launch only, 2 everything after it (pcrl_encoder_bwd_prepare_f32)
+    // team kernel (encoder_bwd_fused.h): one row of partial sums per workgroup, the sparse rows of dW2 per (cloud, channel)
+    int fused;               // host side: 1 = take the team kernel where it is built (pcrl_encoder_bwd_set_fused)
+    int fused_rows;          // rows the workspace has room for (= the largest grid)
+    float* wgrows;           // [fused_rows][FusedRow.total()]
+    float* srows;            // [B][C3][C2]
+    int* n_items;            // [1] tiles of the launch (written by the team kernel, read by the reduce launch)
+    unsigned long long* own_pack;  // [B][kC3] per active slot: its first eight channels, one byte each, 0xFF = none (c3 <= 256 prep only)
     // column-sum jobs riding on the reduce launch (pcrl_encoder_bwd_attach_colsum): cs_blocks extra workgroups behind its own
     ColsumParams cs;
     int cs_blocks;
@@ -1290,6 +1297,10 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     return PCRL_OK;
 }
 
+// pcrl_encoder_bwd_set_fused: 1 = the team kernel of encoder_bwd_fused.h where it is built, 0 = the round-3/4 launches
+static int g_bwd_fused = 0;      // (development: the team kernel is not yet faster at every batch size)
+extern "C" int pcrl_encoder_bwd_set_fused(int32_t on) { g_bwd_fused = on ? 1 : 0; return PCRL_OK; }
+
 // pcrl_encoder_bwd_attach_colsum: jobs handed over for the NEXT backward of this host thread
 static thread_local pcrl_colsum_job t_colsum_jobs[kColsumJobs];
 static thread_local int t_colsum_n = 0;
@@ -1354,6 +1365,10 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             p.own_chan = reinterpret_cast<unsigned char*>(base + wg.own_chan); p.ptc = reinterpret_cast<float4*>(base + wg.ptc);
             p.chc = reinterpret_cast<float*>(base + wg.chc); p.n1part = reinterpret_cast<float*>(base + wg.n1part);
             p.gvu = reinterpret_cast<float*>(base + wg.gvu); p.mimg = reinterpret_cast<float*>(base + wg.mimg);
+            p.wgrows = reinterpret_cast<float*>(base + wg.wgrows); p.n_items = reinterpret_cast<int*>(base + wg.nitems);
+            p.own_pack = reinterpret_cast<unsigned long long*>(base + wg.own_pack);
+            p.srows = p.ops;          // the team kernel writes no operand pieces: their region holds the sparse rows of dW2
+            p.fused = g_bwd_fused; p.fused_rows = wg.fused_rows;
             p.w2 = w->w2;
             p.pw_stride = GL.total() + GramExtra{w->c2}.total();
             p.tile_mode = 1;

@@ -390,6 +390,15 @@ if os.environ.get("PCRL_GEMM_PATHS") == "legacy":      # measurement only (tools
     lib().pcrl_gemm_set_tile64_min(1 << 30)
 
 
+def encoder_bwd_set_fused(on):
+    """include/pcrl.h: pcrl_encoder_bwd_set_fused -- the team kernel (True, default) or the round-3/4 launches of the Gram-form backward."""
+    check(lib().pcrl_encoder_bwd_set_fused(1 if on else 0))
+
+
+if os.environ.get("PCRL_BWD_PATHS") == "legacy":       # measurement only (same-box A/B): the round-3/4 backward launches in this build
+    lib().pcrl_encoder_bwd_set_fused(0)
+
+
 def gemm_plan(descs):
     """[(path, tile shape, workgroups)] pcrl_gemm_group_f32 would use for these problems (include/pcrl.h: pcrl_gemm_group_plan_f32)."""
     descs = [d for d in descs if d is not None]
