@@ -225,11 +225,13 @@ int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_
                                   const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                   float* grads, int32_t* n_active,
                                   void* workspace, size_t workspace_bytes, void* stream);
-/* Which kernels the Gram-form backward above launches for mlp_spec = [64 | 128, 128, 256] in exact fp32 (and for the bf16 mode's backward, which
- * runs them too): 1 (default) = the team kernel of csrc/encoder_bwd_fused.h -- the per-point chain and the weight-gradient sums in one
- * launch, four waves per 32-point tile --, 0 = the points / wgrad / reduce launches of csrc/encoder_bwd_gram.h.  Same gradients to fp32
- * summation order.  For tests and same-box comparisons; returns PCRL_OK. */
-int pcrl_encoder_bwd_set_fused(int32_t on);
+/* Which kernels the Gram-form backward above launches for mlp_spec = [64 | 128, 128, 256] in exact fp32 (and for the bf16 mode's backward,
+ * which runs them too).  mode 1 (default): launches of at most two 32-point tiles per CU (up to 64 clouds on 256 CUs: the per-GPU shares of
+ * a data-parallel batch) take the team kernel of csrc/encoder_bwd_fused.h -- the per-point chain and the weight-gradient sums in one
+ * launch, four waves per tile, no operand pieces in global memory --, larger launches the points / wgrad / reduce launches of
+ * csrc/encoder_bwd_gram.h (faster there: four independent tiles per CU).  mode 0: never the team kernel; mode 2: wherever it is built.
+ * Same gradients to fp32 summation order; each path bitwise reproducible.  Returns PCRL_OK, PCRL_E_ARG for another mode. */
+int pcrl_encoder_bwd_set_fused(int32_t mode);
 /* Backward of pcrl_encoder_fwd_bf16.  With `pooled` (and up to 2 048 clouds; PCRL_BWD_BF16_GRAM, default 1): the fp32 Gram-form
  * backward of pcrl_encoder_bwd_f32 at the bf16 forward's routing (its argmax, its pooled > 0 decisions) -- the exact fp32 gradient
  * along that routing (tests: 2e-4 of each tensor's largest entry against fp32 autograd routed the same way; up to ~6e-2 from autograd

@@ -177,7 +177,7 @@ __device__ __forceinline__ void fused_flush(const f32x16 (&acc)[FusedBlocks<MB1>
 constexpr int kFusedRound = 16;                 // owned channels of a point per round of the dot-product exchange (a point owns ~1.5)
 __host__ __device__ constexpr int fused_lds_floats(int T0, int C1, int kC2, int kC3) {
     return (4 + 2 * (C1 / 32) + 1) * kTrBlk                                     // R1 (h1 / dz1), R2 (h0), R4 (dz0), R3 (x | 1)
-           + 6 * 4 * 32 + kFusedRound * 4 * 32 + 4 * 3 * 32                    // s_red, s_dot, s_coef
+           + 6 * 4 * 32 + kFusedRound * 4 * 32 + 2 * kFusedRound * 32 + 4 * 3 * 32  // s_red, s_dot, s_dx / s_dy, s_coef
            + 2 * kC3 + 2 * kC2                                                 // s_g2, s_be2, s_n1
            + 2 * kC2 + kC3 + C1 + (C1 / 32) * T0 * 64 + kC2                    // ln1, gamma2, b0, w0, s
            + kMaxTileModeClouds + 8;                                           // tile prefix
@@ -187,7 +187,7 @@ static size_t fused_lds_bytes(int T0, int C1, int kC2, int kC3) {
 }
 
 template <int T0, int C1, int kC2, int kC3>
-__global__ __launch_bounds__(64 * kFusedWaves, C1 <= 64 ? 2 : 1) void encoder_bwdg_fused_kernel(const BwdParams p) {
+__global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel(const BwdParams p) {
     static_assert(kC2 == 128 && kC3 <= 256 && (C1 == 64 || C1 == 128), "team kernel: c2 = 128 (four row blocks = four waves), c3 <= 256");
     constexpr int NW = kFusedWaves;
     constexpr PackedLayout L{T0, C1, kC2, kC3};
@@ -204,7 +204,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, C1 <= 64 ? 2 : 1) void encoder_bw
     float* R3 = R4 + MB1 * kTrBlk;                                 // [kTrBlk]      x | 1
     float* s_red = R3 + kTrBlk;                                    // [6][4][32]
     float* s_dot = s_red + 6 * 4 * 32;                             // [kFusedRound][4][32]
-    float* s_coef = s_dot + kFusedRound * 4 * 32;                  // [4 waves][3][32]: a, rstd2 m1, a mu of the tile's points
+    float* s_dx = s_dot + kFusedRound * 4 * 32;                    // [kFusedRound][32] dx_c of the round's channels (wave 0 writes)
+    float* s_dy = s_dx + kFusedRound * 32;                         // [kFusedRound][32] grad_pooled[c]
+    float* s_coef = s_dy + kFusedRound * 32;                       // [4 waves][3][32]: a, rstd2 m1, a mu of the tile's points
     float* s_g2 = s_coef + 4 * 3 * 32;                             // [kC3] norm2.weight gradient of this workgroup's tiles
     float* s_be2 = s_g2 + kC3;
     float* s_n1 = s_be2 + kC3;                                     // [kC2][2] norm1 (weight, bias) gradients
@@ -218,18 +220,31 @@ __global__ __launch_bounds__(64 * kFusedWaves, C1 <= 64 ? 2 : 1) void encoder_bw
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5, l31 = lane & 31;
     {
-        // the clouds' tile counts: every load of a thread in flight (a loop over the clouds paid one global round trip per 64 clouds)
-        constexpr int PER = kMaxTileModeClouds / (64 * NW);
+        // every global load of the prologue in flight before the first LDS write (written as one loop per array each loop paid its own round
+        // trip): the clouds' tile counts, the per-channel tables, conv0's operands
+        constexpr int PER = kMaxTileModeClouds / (64 * NW), W0N = (MB1 * T0 * 64 + 64 * NW - 1) / (64 * NW);
         int nt[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) nt[k] = tid + 64 * NW * k < p.cl.B ? p.n_act[tid + 64 * NW * k] : 0;
-        for (int i = tid; i < kC2; i += 64 * NW) s_sv[i] = p.mimg[kC2 * kC2 + i];
-        for (int i = tid; i < MB1 * T0 * 64; i += 64 * NW) s_w0[i] = p.packed[L.w0() + i];
-        for (int i = tid; i < C1; i += 64 * NW) s_b0[i] = p.packed[L.b0() + i];
-        for (int i = tid; i < 2 * kC2; i += 64 * NW) { s_ln1[i] = p.packed[L.ln1() + i]; s_n1[i] = 0.0f; }
-        for (int i = tid; i < kC3; i += 64 * NW) { s_gam2[i] = p.packed[L.ln2() + 2 * i]; s_g2[i] = 0.0f; s_be2[i] = 0.0f; }
+        static_assert(2 * kC2 <= 64 * NW && kC3 <= 64 * NW && C1 <= 64 * NW, "one prologue element per thread");
+        const float v_sv = tid < kC2 ? p.mimg[kC2 * kC2 + tid] : 0.0f;
+        const float v_b0 = tid < C1 ? p.packed[L.b0() + tid] : 0.0f;
+        const float v_ln1 = tid < 2 * kC2 ? p.packed[L.ln1() + tid] : 0.0f;
+        const float v_g2 = tid < kC3 ? p.packed[L.ln2() + 2 * tid] : 0.0f;
+        float v_w0[W0N];
+#pragma unroll
+        for (int k = 0; k < W0N; ++k) v_w0[k] = tid + 64 * NW * k < MB1 * T0 * 64 ? p.packed[L.w0() + tid + 64 * NW * k] : 0.0f;
+        ChanSrc v_desc{};
+        if (tid < PCRL_MAX_CHANNELS) v_desc = p.cl.ch[tid];
+        if (tid < kC2) s_sv[tid] = v_sv;
+        if (tid < C1) s_b0[tid] = v_b0;
+        if (tid < 2 * kC2) { s_ln1[tid] = v_ln1; s_n1[tid] = 0.0f; }
+        if (tid < kC3) { s_gam2[tid] = v_g2; s_g2[tid] = 0.0f; s_be2[tid] = 0.0f; }
+#pragma unroll
+        for (int k = 0; k < W0N; ++k)
+            if (tid + 64 * NW * k < MB1 * T0 * 64) s_w0[tid + 64 * NW * k] = v_w0[k];
         for (int i = tid; i < kTrBlk; i += 64 * NW) R3[i] = 0.0f;
-        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = p.cl.ch[tid];
+        if (tid < PCRL_MAX_CHANNELS) s_desc[tid] = v_desc;
 #pragma unroll
         for (int k = 0; k < PER; ++k)
             if (tid + 64 * NW * k < p.cl.B) s_tstart[tid + 64 * NW * k + 1] = (nt[k] + 31) >> 5;
@@ -433,7 +448,10 @@ __global__ __launch_bounds__(64 * kFusedWaves, C1 <= 64 ? 2 : 1) void encoder_bw
                         gacc[r] = __builtin_fmaf(dx, w4[r >> 2][r & 3], gacc[r]);
                     }
                     both_halves(d, lo, hi);
-                    if (half == 0) s_dot[((i - r0) * 4 + wave) * 32 + l31] = lo + hi;
+                    if (half == 0) {
+                        s_dot[((i - r0) * 4 + wave) * 32 + l31] = lo + hi;
+                        if (wave == 0) { s_dx[(i - r0) * 32 + l31] = dx; s_dy[(i - r0) * 32 + l31] = dy; }
+                    }
                     t1 = t1 + dx;
                 };
                 if (nr > 0) fetch(r0, wA, dyA, cA);
@@ -463,39 +481,28 @@ __global__ __launch_bounds__(64 * kFusedWaves, C1 <= 64 ? 2 : 1) void encoder_bw
                 rstd2 = 1.0f / __builtin_sqrtf(__builtin_fmaxf(e, 0.0f) + p.eps);
             }
             // second pass: z_c - mu from the four shares, the two LayerNorm-2 sums, the sparse row of dW2, (wave 0) norm2's own gradients
-            for (int i0 = r0; i0 < r0 + nr; i0 += 4) {
-                int cc[4];
-                float dy[4];
+            for (int i = r0; i < r0 + nr; ++i) {
+                const float* dk = s_dot + ((i - r0) * 4) * 32 + l31;
+                const float zc = ((dk[0] + dk[32]) + (dk[64] + dk[96])) - mu;
+                const float dx = s_dx[(i - r0) * 32 + l31];
+                t2r = __builtin_fmaf(dx, zc, t2r);
+                if (i < cnt) {
+                    const int c = chan_of(i);
+                    const float co = dx != 0.0f ? dx * rstd2 : 0.0f;
+                    f32x4* dst = reinterpret_cast<f32x4*>(srow + (long long)c * kC2);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cc[k] = chan_of(i0 + k);
-                    dy[k] = (i0 + k < cnt) ? g_row[cc[k]] : 0.0f;
-                }
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = i0 + k;
-                    if (i >= r0 + nr) continue;
-                    const float* dk = s_dot + ((i - r0) * 4) * 32 + l31;
-                    const float zc = ((dk[0] + dk[32]) + (dk[64] + dk[96])) - mu;
-                    const float dx = dy[k] * s_gam2[cc[k]];
-                    t2r = __builtin_fmaf(dx, zc, t2r);
-                    if (i < cnt) {
-                        const int c = cc[k];
-                        const float co = dx != 0.0f ? dx * rstd2 : 0.0f;
-                        f32x4* dst = reinterpret_cast<f32x4*>(srow + (long long)c * kC2);
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = co != 0.0f ? co * a1[4 * g4 + e] : 0.0f;
-                            dst[2 * g4] = v;
-                        }
-                        if (wave == 0 && half == 0) {          // exactly one point per (cloud, channel): plain read-modify-write, tile order
-                            const float raw = dy[k] * zc;
-                            s_g2[c] = s_g2[c] + (raw != 0.0f ? raw * rstd2 : 0.0f);
-                            s_be2[c] = s_be2[c] + dy[k];
-                            p.chc[(long long)b * kC3 + c] = dx;
-                        }
+                        for (int e = 0; e < 4; ++e) v[e] = co != 0.0f ? co * a1[4 * g4 + e] : 0.0f;
+                        dst[2 * g4] = v;
+                    }
+                    if (wave == 0 && half == 0) {          // exactly one point per (cloud, channel): plain read-modify-write, tile order
+                        const float dy = s_dy[(i - r0) * 32 + l31];
+                        const float raw = dy * zc;
+                        s_g2[c] = s_g2[c] + (raw != 0.0f ? raw * rstd2 : 0.0f);
+                        s_be2[c] = s_be2[c] + dy;
+                        p.chc[(long long)b * kC3 + c] = dx;
                     }
                 }
             }

@@ -1270,7 +1270,7 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     if (p.phase == 1) return PCRL_OK;
 #if PCRL_BWDG_ARITH == 0
     if constexpr (C2 == 128 && C3 == 256 && (C1 == 64 || C1 == 128)) {
-        if (p.fused) {
+        if (p.fused == 2 || (p.fused == 1 && p.cl.B * bwdg_tpc(C3) <= 2 * num_cus())) {
             // the team kernel (encoder_bwd_fused.h): chain + weight-gradient sums in one launch, then the reduce over the workgroup rows
             auto kern = encoder_bwdg_fused_kernel<T0, C1, C2, C3>;
             const size_t flds = fused_lds_bytes(T0, C1, C2, C3);

@@ -100,7 +100,7 @@ struct BwdParams {
     int pw_stride;           // floats per cloud in pw (GradLayout.total() [+ C2*C2 + 2*C2 in the Gram form])
     int phase;               // Gram form, host side: 0 whole backward, 1 the prep launch only, 2 everything after it (pcrl_encoder_bwd_prepare_f32)
     // team kernel (encoder_bwd_fused.h): one row of partial sums per workgroup, the sparse rows of dW2 per (cloud, channel)
-    int fused;               // host side: 1 = take the team kernel where it is built (pcrl_encoder_bwd_set_fused)
+    int fused;               // host side: 0 never, 1 the team kernel for small launches (at most two tiles per CU), 2 wherever it is built
     int fused_rows;          // rows the workspace has room for (= the largest grid)
     float* wgrows;           // [fused_rows][FusedRow.total()]
     float* srows;            // [B][C3][C2]
@@ -1297,9 +1297,14 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
     return PCRL_OK;
 }
 
-// pcrl_encoder_bwd_set_fused: 1 = the team kernel of encoder_bwd_fused.h where it is built, 0 = the round-3/4 launches
-static int g_bwd_fused = 0;      // (development: the team kernel is not yet faster at every batch size)
-extern "C" int pcrl_encoder_bwd_set_fused(int32_t on) { g_bwd_fused = on ? 1 : 0; return PCRL_OK; }
+// pcrl_encoder_bwd_set_fused: 0 = the points / wgrad / reduce launches always, 1 (default) = the team kernel of encoder_bwd_fused.h for
+// launches of at most two tiles per CU (where it is faster: up to 64 clouds on 256 CUs), 2 = the team kernel wherever it is built
+static int g_bwd_fused = 1;
+extern "C" int pcrl_encoder_bwd_set_fused(int32_t mode) {
+    if (mode < 0 || mode > 2) return fail(PCRL_E_ARG, "pcrl_encoder_bwd_set_fused: mode 0, 1 or 2");
+    g_bwd_fused = mode;
+    return PCRL_OK;
+}
 
 // pcrl_encoder_bwd_attach_colsum: jobs handed over for the NEXT backward of this host thread
 static thread_local pcrl_colsum_job t_colsum_jobs[kColsumJobs];

@@ -390,13 +390,14 @@ if os.environ.get("PCRL_GEMM_PATHS") == "legacy":      # measurement only (tools
     lib().pcrl_gemm_set_tile64_min(1 << 30)
 
 
-def encoder_bwd_set_fused(on):
-    """include/pcrl.h: pcrl_encoder_bwd_set_fused -- the team kernel (True, default) or the round-3/4 launches of the Gram-form backward."""
-    check(lib().pcrl_encoder_bwd_set_fused(1 if on else 0))
+def encoder_bwd_set_fused(mode):
+    """include/pcrl.h: pcrl_encoder_bwd_set_fused -- 0 the points / wgrad / reduce launches, 1 (default) the team kernel for launches of at
+    most two tiles per CU, 2 the team kernel wherever it is built."""
+    check(lib().pcrl_encoder_bwd_set_fused(int(mode)))
 
 
-if os.environ.get("PCRL_BWD_PATHS") == "legacy":       # measurement only (same-box A/B): the round-3/4 backward launches in this build
-    lib().pcrl_encoder_bwd_set_fused(0)
+if os.environ.get("PCRL_BWD_PATHS") in ("legacy", "team"):       # measurement only (same-box A/B): one backward path for every launch
+    lib().pcrl_encoder_bwd_set_fused(0 if os.environ["PCRL_BWD_PATHS"] == "legacy" else 2)
 
 
 def gemm_plan(descs):

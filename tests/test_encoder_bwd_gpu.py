@@ -59,6 +59,16 @@ def assert_grads_close(got, ref):
         assert err < 2e-5, f"{name}: max rel-to-max err {err:.3e} (scale {scale:.3e})"
 
 
+@pytest.fixture(params=["auto", "launches", "team"])
+def bwd_path(request):
+    """The Gram-form backward's two launch schedules (include/pcrl.h: pcrl_encoder_bwd_set_fused): by size (the default), the points / wgrad /
+    reduce launches for every size, the team kernel for every size it is built for."""
+    from pointcloud_rl_amd import hip
+    hip.encoder_bwd_set_fused({"auto": 1, "launches": 0, "team": 2}[request.param])
+    yield request.param
+    hip.encoder_bwd_set_fused(1)
+
+
 @pytest.mark.parametrize("B,N,extra,c1", [
     (3, 64, dict(), 64),                 # n_active <= 64: two tiles per cloud at most
     (2, 400, dict(), 64),                # many active points, several waves busy
@@ -70,7 +80,7 @@ def assert_grads_close(got, ref):
     (300, 140, dict(), 32),              # the same nets, one workgroup per cloud (B >= #CUs)
     (260, 130, dict(seg=1), 128),        # cloud mode with the ManiSkill nets
 ])
-def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
+def test_bwd_matches_torch_autograd(cuda, bwd_path, B, N, extra, c1):
     obs = make_obs(B, N, seed=17 * B + N, **extra)
     C = sum(v.shape[1] for v in obs.values())
     c2, c3 = (64, 128) if c1 == 32 else (128, 256)
@@ -94,7 +104,7 @@ def test_bwd_matches_torch_autograd(cuda, B, N, extra, c1):
     assert_grads_close(got_dense, ref)
 
 
-def test_bwd_with_jitter_noise(cuda):
+def test_bwd_with_jitter_noise(cuda, bwd_path):
     obs = make_obs(3, 200, seed=5)
     w = make_encoder_weights(6, 64, 128, 256, seed=9)
     gpool = np.random.RandomState(1).randn(3, 256).astype(np.float32)
@@ -105,7 +115,7 @@ def test_bwd_with_jitter_noise(cuda):
     assert_grads_close(got, ref)
 
 
-def test_bwd_is_deterministic_and_linear(cuda):
+def test_bwd_is_deterministic_and_linear(cuda, bwd_path):
     # size-independent properties at the K1 launch geometry: bitwise reproducible, linear in grad_pooled
     obs = make_obs(256, 1024, seed=1)
     w = make_encoder_weights(6, 64, 128, 256, seed=0)
@@ -129,7 +139,7 @@ def test_bwd_is_deterministic_and_linear(cuda):
 
 
 @pytest.mark.parametrize("B,N,extra,c1,c3", [(5, 300, dict(), 64, 256), (130, 200, dict(seg=1), 128, 256), (3, 150, dict(), 64, 1024)])
-def test_bwd_in_two_calls_equals_one_call(cuda, B, N, extra, c1, c3):
+def test_bwd_in_two_calls_equals_one_call(cuda, bwd_path, B, N, extra, c1, c3):
     """pcrl_encoder_bwd_prepare_f32 (on another stream, before grad_pooled exists) + pcrl_encoder_bwd_prepared_f32 ==
     pcrl_encoder_bwd_f32, bit for bit; the prepare call refuses what the Gram form does not cover."""
     from pointcloud_rl_amd import hip
@@ -183,7 +193,7 @@ def _bf16_reference_grads(obs_np, w_np, gpool_np, eps=1e-6):
 
 
 @pytest.mark.parametrize("B,N,extra,c1", [(3, 200, dict(), 64), (2, 1200, dict(seg=1), 128)])
-def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, B, N, extra, c1):
+def test_bwd_bf16_matches_autograd_of_the_rounding_emulation(cuda, bwd_path, B, N, extra, c1):
     """Mixed-precision backward: gradients w.r.t. the fp32 master weights of the function the bf16 forward computes.
     The kernel's own argmax is used to pick the pooled points of the emulation (a rounding tie may move an argmax, which
     is a different -- equally valid -- subgradient).  Tolerance: 3e-2 of each tensor's largest gradient entry."""
@@ -236,7 +246,7 @@ def test_bwd_zero_gamma_falls_back_to_the_dense_path(cuda):
     assert_grads_close(got, ref)
 
 
-def test_bwd_cloud_whose_channels_are_all_dead(cuda):
+def test_bwd_cloud_whose_channels_are_all_dead(cuda, bwd_path):
     """norm2.bias far below zero on every channel: the forward leaves every channel at zero (argmax = point 0, torch's first index),
     no point receives gradient -- every gradient is exactly zero, n_active = 0 -- and a batch that mixes such a cloud (a cloud of
     identical points has zero variance, LayerNorm outputs = beta) with ordinary ones still matches autograd."""
@@ -277,7 +287,7 @@ def test_bwd_small_gamma_large_beta_stays_accurate(cuda):
 
 
 @pytest.mark.parametrize("offset,tol", [(2.0, 2e-5), (20.0, 5e-4)])
-def test_bwd_conv2_columns_with_a_large_common_component(cuda, offset, tol):
+def test_bwd_conv2_columns_with_a_large_common_component(cuda, bwd_path, offset, tol):
     """LayerNorm-2's variance in the Gram form comes from h1 . Mc h1 with the CENTRED Gram image Mc = M - s s^T / C3 (round 4; the
     round-3 form E z^2 - mu^2 cancelled when every column of W2 carries a large common offset: z2's channel mean is then >> its
     spread).  Reference: float64 autograd along the HIP forward's routing; the bound is the usual 2e-5 of each tensor's largest entry

@@ -39,7 +39,7 @@ print(f"B={a.B} c1={a.c1}: {n_tiles} tiles; tile (stamp 0 -> 14) median {np.medi
 for i, n in enumerate(names):
     per = "  ".join(f"{np.median(d[:, wv, i]):7.0f}" for wv in range(4))
     print(f"  {n:36s} waves: {per}   ({100 * np.median(d[:, :, i]) / np.median(tot):4.1f} %)")
-grid = int(os.environ.get("FUSED_GRID", "512"))
+grid = int(os.environ.get("FUSED_GRID", "256"))
 if n_tiles > grid:
     gap = st[grid:n_tiles, 0, 0] - st[:n_tiles - grid, 0, 14]
     print(f"  between a workgroup's consecutive tiles (stamp 14 -> next stamp 0): median {np.median(gap):.0f}  p90 {np.percentile(gap, 90):.0f}")

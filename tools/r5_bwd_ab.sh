@@ -6,7 +6,7 @@ for cfg in "--B 32 --N 1024" "--B 64 --N 1024" "--B 128 --N 1024" "--B 256 --N 1
   for paths in fused legacy; do
     OUT=gpurun_out/bwd_ab/$(echo $cfg | tr -d ' -')_$paths
     rm -rf $OUT; mkdir -p $OUT
-    if [ $paths = legacy ]; then export PCRL_BWD_PATHS=legacy; else unset PCRL_BWD_PATHS; fi
+    if [ $paths = legacy ]; then export PCRL_BWD_PATHS=legacy; else export PCRL_BWD_PATHS=team; fi
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 tools/bench_encoder.py $cfg --iters 30 > $OUT/log.txt 2>&1
     echo "== $cfg [$paths] $(tail -1 $OUT/log.txt)"
     python3 - "$OUT" <<'PY'
