@@ -30,15 +30,15 @@ n_tiles = min(int(((n_act.cpu().numpy() + 31) // 32).sum()), 8192)
 buf = (ctypes.c_ulonglong * (64 * n_tiles))()
 hip.check(hip.lib().pcrl_debug_fused_stamps(buf, n_tiles))
 st = np.frombuffer(buf, dtype=np.uint64).reshape(n_tiles, 4, 16).astype(np.int64)[:, :, :15]
-names = ["point load + conv0", "conv1 (block)", "LN1 sum -> B1", "centre, squares -> B2", "xhat, h1, transpose -> B3", "q = Mc h1 (block)",
-         "owned channels (both passes, B4)", "dH1, LN1 backward sums", "G blocks, v / u", "wait at B5", "dz1, transpose -> B6",
-         "dH0 (waves < MB1), dW1 blocks", "wait at B7", "dW0 blocks"]
+names = ["conv0 (the point arrived with the previous tile)", "conv1 (block)", "LN1 partial statistics -> B1", "h0, x | 1 transposes; statistics",
+         "xhat, h1, transpose -> B3", "owned channels, first pass", "q = Mc h1, B4, second pass, next tile's loads", "dH1, LN1 backward sums",
+         "G blocks, v / u", "wait at B5", "dz1, transpose -> B6", "dH0 (waves < c1/32), dW1 blocks", "wait at B7", "dW0 blocks"]
 d = np.diff(st, axis=2)
 tot = st[:, :, 14] - st[:, :, 0]
 print(f"B={a.B} c1={a.c1}: {n_tiles} tiles; tile (stamp 0 -> 14) median {np.median(tot):.0f} cycles (min {tot.min()}, max {tot.max()})")
 for i, n in enumerate(names):
     per = "  ".join(f"{np.median(d[:, wv, i]):7.0f}" for wv in range(4))
-    print(f"  {n:36s} waves: {per}   ({100 * np.median(d[:, :, i]) / np.median(tot):4.1f} %)")
+    print(f"  {n:52s} waves: {per}   ({100 * np.median(d[:, :, i]) / np.median(tot):4.1f} %)")
 grid = int(os.environ.get("FUSED_GRID", "256"))
 if n_tiles > grid:
     gap = st[grid:n_tiles, 0, 0] - st[:n_tiles - grid, 0, 14]
