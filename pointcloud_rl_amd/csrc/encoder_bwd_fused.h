@@ -44,6 +44,8 @@ struct FusedRow {
     __host__ __device__ constexpr int u() const { return v() + C2; }
     __host__ __device__ constexpr int total() const { return (u() + C2 + 63) & ~63; }
 };
+static_assert(FusedRow{6, 64, 128, 256}.total() == fused_row_floats(6, 64, 128, 256) && FusedRow{7, 128, 128, 256}.total() == fused_row_floats(7, 128, 128, 256),
+              "the workspace is sized with fused_row_floats (encoder_bwd_gram.h)");
 __host__ __device__ constexpr int fused_g_index(int MB2, int i, int j) { return i * MB2 - i * (i - 1) / 2 + (j - i); }   // i <= j
 
 // The weight-gradient blocks a wave accumulates: code = kind << 8 | i << 4 | j, kind 1: G(i, j) (i <= j), 2: dW1 (dz1 block i, h0 block j),
