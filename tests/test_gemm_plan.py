@@ -103,3 +103,25 @@ def test_a_mixed_launch_keeps_each_problems_path():
     got = plan([fwd(256, 1024, 1024, 4), fwd(128, 1024, 1024)])
     assert got[0][0] == 1 and got[1][0] == 4, got                # each problem keeps its own path: the launch takes the kernel that has both
     assert plan([fwd(128, 1024, 1024)])[0][0] == 4
+
+
+def test_encoder_backward_schedule_knob_validates_its_mode():
+    """pcrl_encoder_bwd_set_fused (include/pcrl.h): 0 / 1 / 2 are accepted, anything else is PCRL_E_ARG and changes nothing (no GPU needed:
+    the knob is host state read by the next backward)."""
+    import ctypes as ct
+    lib = _lib.lib()
+    workspace = {}
+    for B in (32, 1024):        # the workspace holds both schedules' regions whatever the mode: its size does not depend on the knob
+        sizes = []
+        for mode in (0, 2, 1):
+            assert lib.pcrl_encoder_bwd_set_fused(mode) == 0
+            n = ct.c_size_t()
+            _lib.check(lib.pcrl_encoder_bwd_workspace_bytes(B, 6, 64, 128, 256, ct.byref(n)))
+            sizes.append(n.value)
+        assert len(set(sizes)) == 1 and sizes[0] > 0
+        workspace[B] = sizes[0]
+    assert workspace[1024] > workspace[32]
+    for bad in (-1, 3, 17):
+        assert lib.pcrl_encoder_bwd_set_fused(bad) < 0
+        assert b"mode" in lib.pcrl_last_error()
+    assert lib.pcrl_encoder_bwd_set_fused(1) == 0
