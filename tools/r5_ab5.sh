@@ -10,8 +10,8 @@ for cfg in "--B 256 --N 1024" "--B 128 --N 1200 --c1 128 --seg 1" "--B 512 --N 1
     python3 - "$OUT" "$cfg [$lib]" <<'PY'
 import csv, glob, sys
 rows = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]))}
-pts = [v for k, v in rows.items() if "points_kernel" in k]
-print(f"{sys.argv[2]:50s} points {pts[0]:7.1f} us")
+pts = [v for k, v in rows.items() if "points_kernel" in k]; wg = [v for k, v in rows.items() if "wgrad_kernel" in k]
+print(f"{sys.argv[2]:50s} points {pts[0]:7.1f} us  wgrad {wg[0]:7.1f} us")
 PY
     find $OUT -name "*.csv" ! -name "*kernel_stats.csv" -delete
   done
