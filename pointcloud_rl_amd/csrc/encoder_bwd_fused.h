@@ -24,7 +24,7 @@
 constexpr int kFusedWaves = 4;
 #ifdef PCRL_BWDG_STAMPS
 // development build: shader-clock stamps of every wave at the phase boundaries of a tile (tools/fused_stamps.py)
-__device__ unsigned long long g_fused_stamps[8192][4][16];
+__device__ unsigned long long g_fused_stamps[8192][4][24];
 #define PCRL_FSTAMP(k) do { if (lane == 0 && item < 8192) g_fused_stamps[item][wave][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PCRL_FSTAMP(k) do { } while (0)
@@ -180,7 +180,7 @@ constexpr int kFusedRound = 16;                 // owned channels of a point per
 __host__ __device__ constexpr int fused_lds_floats(int T0, int C1, int kC2, int kC3) {
     return (4 + 2 * (C1 / 32) + 1) * kTrBlk                                     // R1 (h1 / dz1), R2 (h0), R4 (dz0), R3 (x | 1)
            + 6 * 4 * 32 + kFusedRound * 4 * 32 + 2 * kFusedRound * 32 + 4 * 3 * 32  // s_red, s_dot, s_dx / s_dy, s_coef
-           + 2 * kC3 + 2 * kC2                                                 // s_g2, s_be2, s_n1
+           + 2 * kC3 + 2 * kC2 + 16 * 32                                       // s_g2, s_be2, s_n1, the next tile's point features
            + 2 * kC2 + kC3 + C1 + (C1 / 32) * T0 * 64 + kC2                    // ln1, gamma2, b0, w0, s
            + kMaxTileModeClouds + 8;                                           // tile prefix
 }
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
     float* s_g2 = s_coef + 4 * 3 * 32;                             // [kC3] norm2.weight gradient of this workgroup's tiles
     float* s_be2 = s_g2 + kC3;
     float* s_n1 = s_be2 + kC3;                                     // [kC2][2] norm1 (weight, bias) gradients
-    float* s_ln1 = s_n1 + 2 * kC2;                                 // [kC2][2] (gamma, beta)
+    float* s_x = s_n1 + 2 * kC2;                                   // [16][32] the next tile's point features (wave 3 loads them)
+    float* s_ln1 = s_x + 16 * 32;                                  // [kC2][2] (gamma, beta)
     float* s_gam2 = s_ln1 + 2 * kC2;                               // [kC3]
     float* s_b0 = s_gam2 + kC3;
     float* s_w0 = s_b0 + C1;
@@ -475,8 +476,10 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
                 for (int r = 0; r < 16; ++r) pe = __builtin_fmaf(a1[r], q[r], pe);
                 both_halves(pe, lo, hi);
                 if (half == 0) s_red[(3 * 4 + wave) * 32 + l31] = lo + hi;
+                PCRL_FSTAMP(15);
             }
             __syncthreads();                                                                              // B4 (+ two per further round)
+            if (r0 == 0) PCRL_FSTAMP(16);
             if (r0 == 0) {
                 mu = ((s_red[(2 * 4 + 0) * 32 + l31] + s_red[(2 * 4 + 1) * 32 + l31]) + (s_red[(2 * 4 + 2) * 32 + l31] + s_red[(2 * 4 + 3) * 32 + l31])) / (float)kC3;
                 const float e = ((s_red[(3 * 4 + 0) * 32 + l31] + s_red[(3 * 4 + 1) * 32 + l31]) + (s_red[(3 * 4 + 2) * 32 + l31] + s_red[(3 * 4 + 3) * 32 + l31])) / (float)kC3;
@@ -510,8 +513,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
             }
             if (r0 + kFusedRound < cmax) __syncthreads();       // the next round overwrites the shares
         }
-        // the next tile's point features (their addresses arrived long ago; consumed at the bottom of the loop)
-        const f32x16 nx = load_point<T0>(p.cl, s_desc, nb, npidx);
+        PCRL_FSTAMP(17);
         PCRL_FSTAMP(7);
         // ---- dH1 block; LayerNorm-1 backward sums; G, v, u of this tile --------------------------------------------------------------------
         {
@@ -600,6 +602,16 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         else if (wave == 1) fused_accumulate<MB1, 1, 2>(acc, R1, R2, R3, R4, nullptr, lane);
         else if (wave == 2) fused_accumulate<MB1, 2, 2>(acc, R1, R2, R3, R4, nullptr, lane);
         else fused_accumulate<MB1, 3, 2>(acc, R1, R2, R3, R4, nullptr, lane);
+        // The next tile's point features: ONE wave loads them, in the slack it has in front of B7 (waves 2 and 3 wait there for dH0), and
+        // hands them over through LDS.  (load_point consumes its loads at once -- dtype conversion, augmentation -- so wherever it stands a
+        // wave stalls for a global round trip: ~4 k cycles per tile when every wave did it behind the owned channels.)
+        if (wave == NW - 1) {
+            const f32x16 nx = load_point<T0>(p.cl, s_desc, nb, npidx);
+            if (half == 0) {
+#pragma unroll
+                for (int c = 0; c < 2 * T0; ++c) s_x[c * 32 + l31] = nx[c];
+            }
+        }
         PCRL_FSTAMP(12);
         __syncthreads();                                                                                  // B7
         PCRL_FSTAMP(13);
@@ -608,7 +620,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         else if (wave == 2) fused_accumulate<MB1, 2, 3>(acc, R1, R2, R3, R4, nullptr, lane);
         else fused_accumulate<MB1, 3, 3>(acc, R1, R2, R3, R4, nullptr, lane);
         PCRL_FSTAMP(14);
-        b = nb; tile = ntile; pidx = npidx; own_w = nown; pack = npack; x = nx;
+        b = nb; tile = ntile; pidx = npidx; own_w = nown; pack = npack;
+#pragma unroll
+        for (int c = 0; c < 2 * T0; ++c) x[c] = s_x[c * 32 + l31];
     }
     // ---- this workgroup's row ----------------------------------------------------------------------------------------------------------------
     float* row = p.wgrows + (long long)blockIdx.x * FR.total();

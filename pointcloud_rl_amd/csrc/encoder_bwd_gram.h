@@ -1382,7 +1382,7 @@ extern "C" int pcrl_debug_bwdg_stamps(unsigned long long* tiles_out, int n_items
 }
 extern "C" int pcrl_debug_fused_stamps(unsigned long long* out, int n_items) {
     if (hipDeviceSynchronize() != hipSuccess) return -3;
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcrl::g_fused_stamps), sizeof(unsigned long long) * 64 * (size_t)n_items) != hipSuccess) return -3;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pcrl::g_fused_stamps), sizeof(unsigned long long) * 96 * (size_t)n_items) != hipSuccess) return -3;
     return 0;
 }
 #endif

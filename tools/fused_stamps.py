@@ -27,9 +27,10 @@ for _ in range(3):
     flat, n_act = hip.encoder_bwd(desc, ew, packed, argmax, gp, pooled=pooled, want_n_active=True)
 torch.cuda.synchronize()
 n_tiles = min(int(((n_act.cpu().numpy() + 31) // 32).sum()), 8192)
-buf = (ctypes.c_ulonglong * (64 * n_tiles))()
+buf = (ctypes.c_ulonglong * (96 * n_tiles))()
 hip.check(hip.lib().pcrl_debug_fused_stamps(buf, n_tiles))
-st = np.frombuffer(buf, dtype=np.uint64).reshape(n_tiles, 4, 16).astype(np.int64)[:, :, :15]
+full = np.frombuffer(buf, dtype=np.uint64).reshape(n_tiles, 4, 24).astype(np.int64)
+st = full[:, :, :15]
 names = ["conv0 (the point arrived with the previous tile)", "conv1 (block)", "LN1 partial statistics -> B1", "h0, x | 1 transposes; statistics",
          "xhat, h1, transpose -> B3", "owned channels, first pass", "q = Mc h1, B4, second pass, next tile's loads", "dH1, LN1 backward sums",
          "G blocks, v / u", "wait at B5", "dz1, transpose -> B6", "dH0 (waves < c1/32), dW1 blocks", "wait at B7", "dW0 blocks"]
@@ -39,6 +40,9 @@ print(f"B={a.B} c1={a.c1}: {n_tiles} tiles; tile (stamp 0 -> 14) median {np.medi
 for i, n in enumerate(names):
     per = "  ".join(f"{np.median(d[:, wv, i]):7.0f}" for wv in range(4))
     print(f"  {n:52s} waves: {per}   ({100 * np.median(d[:, :, i]) / np.median(tot):4.1f} %)")
+# inside the longest phase (stamps 15 .. 17): q done -> B4 -> second pass done -> next tile's point loads issued
+for a_, b_, n in ((6, 15, 'q = Mc h1 + its share of h1.q'), (15, 16, 'wait at B4'), (16, 17, 'second pass (rows of dW2, norm2 sums)'), (17, 7, "next tile's point loads")):
+    print(f"    {n:50s} waves: " + "  ".join(f"{np.median(full[:, wv, b_] - full[:, wv, a_]):7.0f}" for wv in range(4)))
 grid = int(os.environ.get("FUSED_GRID", "256"))
 if n_tiles > grid:
     gap = st[grid:n_tiles, 0, 0] - st[:n_tiles - grid, 0, 14]
