@@ -10,7 +10,7 @@
 //     and serves twice from there: as the B operand of the next layer for the other three waves (q = Mc h1, dH0 = W1^T dz1), and as
 //     the A / B operand pieces of the weight-gradient blocks -- which are therefore accumulated where their operands are produced:
 //     G (the ten upper 32 x 32 blocks), dW1, dW0 | b0 live in registers across all the tiles a workgroup takes, v / u in one register
-//     per thread, norm1 / norm2 sums in LDS, and leave once per workgroup.  No operand pieces in global memory (84 MB per K1 launch
+//     per thread, norm1 sums per lane, norm2 sums in LDS, and leave once per workgroup.  No operand pieces in global memory (84 MB per K1 launch
 //     before), no per-cloud wgrad launch; the reduce launch adds <= 2 x #CUs workgroup rows instead of B cloud rows;
 //   * the sparse rows of dW2, S[c,:] = rstd2 dx_c h1_p(c), still leave per (cloud, channel) -- one point owns the row, there is nothing to
 //     accumulate -- and the reduce launch adds them over the clouds, skipping the channels the forward left dead.
@@ -54,12 +54,13 @@ __host__ __device__ constexpr int fused_g_index(int MB2, int i, int j) { return 
 constexpr int FBc(int kind, int i, int j) { return kind << 8 | i << 4 | j; }
 template <int MB1> struct FusedBlocks;
 template <> struct FusedBlocks<2> {
-    static constexpr int NB = 6;
+    static constexpr int NB = 7;
     __host__ __device__ static constexpr int code(int w, int k) {
-        constexpr int t[4][6] = {{FBc(1, 0, 0), FBc(1, 0, 1), FBc(1, 0, 2), FBc(3, 0, 0), 0, 0},
-                                 {FBc(1, 1, 1), FBc(1, 1, 2), FBc(1, 1, 3), FBc(3, 1, 0), 0, 0},
-                                 {FBc(1, 2, 2), FBc(1, 2, 3), FBc(2, 0, 0), FBc(2, 0, 1), FBc(2, 1, 0), FBc(2, 1, 1)},
-                                 {FBc(1, 3, 3), FBc(1, 0, 3), FBc(2, 2, 0), FBc(2, 2, 1), FBc(2, 3, 0), FBc(2, 3, 1)}};
+        // the last phase: waves 0 and 1 form dH0 (64 MFMAs), wave 3 loads the next tile's point features -- wave 2 takes five of the eight dW1 blocks
+        constexpr int t[4][7] = {{FBc(1, 0, 0), FBc(1, 0, 1), FBc(1, 0, 2), FBc(3, 0, 0), 0, 0, 0},
+                                 {FBc(1, 1, 1), FBc(1, 1, 2), FBc(1, 1, 3), FBc(3, 1, 0), 0, 0, 0},
+                                 {FBc(1, 2, 2), FBc(1, 2, 3), FBc(2, 0, 0), FBc(2, 0, 1), FBc(2, 1, 0), FBc(2, 1, 1), FBc(2, 2, 0)},
+                                 {FBc(1, 3, 3), FBc(1, 0, 3), FBc(2, 2, 1), FBc(2, 3, 0), FBc(2, 3, 1), 0, 0}};
         return t[w][k];
     }
 };
@@ -94,12 +95,17 @@ __device__ __forceinline__ f32x4 tr_piece(const float* blk, int q, int lane) {
 // out = A[32 rows of block `blk`][:] . act over K = 128 channels: A pieces stream from L2 (image [block][K / 8][64 lanes][4], six in
 // flight, refills pinned), the B operand is the four transposed blocks in LDS (sixteen values per lane and block).
 template <int DEPTH>
-__device__ __forceinline__ f32x16 fused_layer_k128(const __amdgpu_buffer_rsrc_t& rs, unsigned img_bytes, int blk, const float* tr4, int l31, int half, unsigned lane16) {
-    constexpr int TQ = 16;
-    f32x4 ring[DEPTH];
-    const unsigned base = img_bytes + 4u * (unsigned)(blk * TQ * 256);
+__device__ __forceinline__ void fused_k128_preload(f32x4 (&ring)[DEPTH], const __amdgpu_buffer_rsrc_t& rs, unsigned img_bytes, int blk, unsigned lane16) {
+    const unsigned base = img_bytes + 4u * (unsigned)(blk * 16 * 256);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) ring[d] = buf_load_f4(rs, lane16 + base, 1024u * (unsigned)d);
+}
+// (ring: the first DEPTH pieces, requested by fused_k128_preload as early as the caller could -- ahead of the phase in front of this layer)
+template <int DEPTH>
+__device__ __forceinline__ f32x16 fused_layer_k128(f32x4 (&ring)[DEPTH], const __amdgpu_buffer_rsrc_t& rs, unsigned img_bytes, int blk, const float* tr4, int l31, int half,
+                                                   unsigned lane16) {
+    constexpr int TQ = 16;
+    const unsigned base = img_bytes + 4u * (unsigned)(blk * TQ * 256);
     float hb[2][16];
     tr_read_acc(tr4, hb[0], l31, half);
     __builtin_amdgcn_sched_barrier(0);
@@ -180,7 +186,7 @@ constexpr int kFusedRound = 16;                 // owned channels of a point per
 __host__ __device__ constexpr int fused_lds_floats(int T0, int C1, int kC2, int kC3) {
     return (4 + 2 * (C1 / 32) + 1) * kTrBlk                                     // R1 (h1 / dz1), R2 (h0), R4 (dz0), R3 (x | 1)
            + 6 * 4 * 32 + kFusedRound * 4 * 32 + 2 * kFusedRound * 32 + 4 * 3 * 32  // s_red, s_dot, s_dx / s_dy, s_coef
-           + 2 * kC3 + 2 * kC2 + 16 * 32                                       // s_g2, s_be2, s_n1, the next tile's point features
+           + 2 * kC3 + 16 * 32                                                 // s_g2, s_be2, the next tile's point features
            + 2 * kC2 + kC3 + C1 + (C1 / 32) * T0 * 64 + kC2                    // ln1, gamma2, b0, w0, s
            + kMaxTileModeClouds + 8;                                           // tile prefix
 }
@@ -211,8 +217,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
     float* s_coef = s_dy + kFusedRound * 32;                       // [4 waves][3][32]: a, rstd2 m1, a mu of the tile's points
     float* s_g2 = s_coef + 4 * 3 * 32;                             // [kC3] norm2.weight gradient of this workgroup's tiles
     float* s_be2 = s_g2 + kC3;
-    float* s_n1 = s_be2 + kC3;                                     // [kC2][2] norm1 (weight, bias) gradients
-    float* s_x = s_n1 + 2 * kC2;                                   // [16][32] the next tile's point features (wave 3 loads them)
+    float* s_x = s_be2 + kC3;                                      // [16][32] the next tile's point features (wave 3 loads them)
     float* s_ln1 = s_x + 16 * 32;                                  // [kC2][2] (gamma, beta)
     float* s_gam2 = s_ln1 + 2 * kC2;                               // [kC3]
     float* s_b0 = s_gam2 + kC3;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         if (tid < PCRL_MAX_CHANNELS) v_desc = p.cl.ch[tid];
         if (tid < kC2) s_sv[tid] = v_sv;
         if (tid < C1) s_b0[tid] = v_b0;
-        if (tid < 2 * kC2) { s_ln1[tid] = v_ln1; s_n1[tid] = 0.0f; }
+        if (tid < 2 * kC2) s_ln1[tid] = v_ln1;
         if (tid < kC3) { s_gam2[tid] = v_g2; s_g2[tid] = 0.0f; s_be2[tid] = 0.0f; }
 #pragma unroll
         for (int k = 0; k < W0N; ++k)
@@ -282,6 +287,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[k][r] = 0.0f;
     float vu_acc = 0.0f;
+    float n1g[16], n1b[16];        // norm1.weight / norm1.bias gradients of this lane's point over the workgroup's tiles (32-lane sums at the end)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { n1g[r] = 0.0f; n1b[r] = 0.0f; }
 
     // cloud and tile of an item: the largest b with s_tstart[b] <= item
     auto decode = [&](int item, int& b, int& tile) {
@@ -314,6 +322,13 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         const unsigned long long npack = p.own_pack[(long long)nb * kC3 + 32 * ntile + l31];
         PCRL_FSTAMP(0);
 
+        // conv1's first operand pieces are requested ahead of conv0 (their round trip hid nothing at the head of conv1)
+        constexpr int TQ1 = C1 / 8, DEPTH1 = 6;
+        const unsigned base1 = 4u * (unsigned)L.w1() + 4u * (unsigned)(wave * TQ1 * 256);
+        f32x4 ring1[DEPTH1];
+#pragma unroll
+        for (int d = 0; d < DEPTH1; ++d) ring1[d] = buf_load_f4(r_packed, lane16 + base1, 1024u * (unsigned)d);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- conv0 + ReLU: every wave forms all of h0 (the B operand of its conv1 block) ---------------------------------------------
         f32x16 a0[MB1];
         unsigned mask_own = 0u;
@@ -338,11 +353,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         // ---- conv1, row block `wave`: the forward's chain for that block (same order: the recompute of the block is bit-identical) -------
         f32x16 a1;
         {
-            constexpr int TQ = C1 / 8, DEPTH = 6;
-            const unsigned base = 4u * (unsigned)L.w1() + 4u * (unsigned)(wave * TQ * 256);
-            f32x4 ring[DEPTH];
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) ring[d] = buf_load_f4(r_packed, lane16 + base, 1024u * (unsigned)d);
+            constexpr int TQ = TQ1, DEPTH = DEPTH1;
+            const unsigned base = base1;
+            f32x4 (&ring)[DEPTH1] = ring1;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int tq = 0; tq < TQ; ++tq) {
@@ -416,6 +429,9 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
         PCRL_FSTAMP(5);
         // ---- the channels this point owns, first pass: the block's share of W2[c,:].h1 (to LDS) and of sum dx_c W2[c,:]; the W2 rows
         // of channel i + 1 are in flight while channel i is worked --------------------------------------------------------------------------
+        f32x4 ringq[6];              // q = Mc h1: its first operand pieces travel under the first pass over the owned channels
+        fused_k128_preload<6>(ringq, r_mimg, 0u, wave, lane16);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 gacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) gacc[r] = 0.0f;
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
             if (r0 == 0) {
                 PCRL_FSTAMP(6);
                 // ---- q = Mc h1, row block `wave`; its share of h1.q --------------------------------------------------------------------
-                q = fused_layer_k128<6>(r_mimg, 0u, wave, R1, l31, half, lane16);
+                q = fused_layer_k128<6>(ringq, r_mimg, 0u, wave, R1, l31, half, lane16);
                 float pe = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pe = __builtin_fmaf(a1[r], q[r], pe);
@@ -544,17 +560,8 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
                 s1 = s1 + dx;
                 s2 = __builtin_fmaf(dx, xh1[r], s2);
             }
-            allreduce_add32_x16(tg);
-            allreduce_add32_x16(tb);
-            if (l31 == 0) {
-                float2* n1 = reinterpret_cast<float2*>(s_n1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = acc_chan(wave * 16 + r, 0) + 4 * half;
-                    const float2 o = n1[ch];
-                    n1[ch] = float2{o.x + tg[r], o.y + tb[r]};
-                }
-            }
+            for (int r = 0; r < 16; ++r) { n1g[r] = n1g[r] + tg[r]; n1b[r] = n1b[r] + tb[r]; }
             both_halves(s1, lo, hi);
             if (half == 0) s_red[(4 * 4 + wave) * 32 + l31] = lo + hi;
             both_halves(s2, lo, hi);
@@ -588,12 +595,15 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) q[r] = rstd1 * ((q[r] - n1) - xh1[r] * n2);                      // dz1
         }
+        f32x4 ringd[6];              // dH0 = W1^T dz1 (waves < MB1): its first operand pieces travel under the transposition and B6
+        if (wave < MB1) fused_k128_preload<6>(ringd, r_packed, 4u * (unsigned)L.w1t(), wave, lane16);
+        __builtin_amdgcn_sched_barrier(0);
         tr_write(R1 + wave * kTrBlk, q, l31, half);
         __syncthreads();                                                                                  // B6
         PCRL_FSTAMP(11);
         // ---- dH0 = W1^T dz1 (waves < MB1, one row block each) -> dz0; the dW1 blocks ---------------------------------------------------------
         if (wave < MB1) {
-            f32x16 d0 = fused_layer_k128<6>(r_packed, 4u * (unsigned)L.w1t(), wave, R1, l31, half, lane16);
+            f32x16 d0 = fused_layer_k128<6>(ringd, r_packed, 4u * (unsigned)L.w1t(), wave, R1, l31, half, lane16);
 #pragma unroll
             for (int r = 0; r < 16; ++r) d0[r] = ((mask_own >> r) & 1u) ? d0[r] : 0.0f;
             tr_write(R4 + wave * kTrBlk, d0, l31, half);
@@ -633,7 +643,16 @@ __global__ __launch_bounds__(64 * kFusedWaves, 1) void encoder_bwdg_fused_kernel
     row[FR.v() + tid] = vu_acc;                                    // threads 0..127: v, 128..255: u
     __syncthreads();
     for (int i = tid; i < kC3; i += 64 * NW) { row[FR.g2() + i] = s_g2[i]; row[FR.be2() + i] = s_be2[i]; }
-    for (int i = tid; i < kC2; i += 64 * NW) { row[GL.g1() + i] = s_n1[2 * i]; row[GL.be1() + i] = s_n1[2 * i + 1]; }
+    allreduce_add32_x16(n1g);
+    allreduce_add32_x16(n1b);
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = acc_chan(wave * 16 + r, 0) + 4 * half;
+            row[GL.g1() + ch] = n1g[r];
+            row[GL.be1() + ch] = n1b[r];
+        }
+    }
 }
 
 // ---- reduce: the workgroup rows in row order, the sparse rows of dW2 in cloud order -------------------------------------------------------
