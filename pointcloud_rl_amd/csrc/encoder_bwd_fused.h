@@ -704,15 +704,19 @@ __global__ __launch_bounds__(1024) void encoder_bwdg_reduce_fused_kernel(const f
     {
         const int e = ((int)blockIdx.x - row_blocks) * 64 + c;          // element of S = [C3][C2]; 64 | C2: one channel per block
         const int ch = e / kC2;
+        // (the row of a dead channel holds whatever an earlier launch left there: it is loaded WITH the flag, not behind it, and dropped)
         int b = g;
         for (; b + 48 < B; b += 64) {
             const float c0 = chc[(long long)(b + 0) * FR.C3 + ch], c1 = chc[(long long)(b + 16) * FR.C3 + ch];
             const float c2 = chc[(long long)(b + 32) * FR.C3 + ch], c3 = chc[(long long)(b + 48) * FR.C3 + ch];
-            const float v0 = c0 != 0.0f ? srows[(long long)(b + 0) * FR.C3 * kC2 + e] : 0.0f, v1 = c1 != 0.0f ? srows[(long long)(b + 16) * FR.C3 * kC2 + e] : 0.0f;
-            const float v2 = c2 != 0.0f ? srows[(long long)(b + 32) * FR.C3 * kC2 + e] : 0.0f, v3 = c3 != 0.0f ? srows[(long long)(b + 48) * FR.C3 * kC2 + e] : 0.0f;
-            p0 = p0 + v0; p1 = p1 + v1; p2 = p2 + v2; p3 = p3 + v3;
+            const float r0 = srows[(long long)(b + 0) * FR.C3 * kC2 + e], r1 = srows[(long long)(b + 16) * FR.C3 * kC2 + e];
+            const float r2 = srows[(long long)(b + 32) * FR.C3 * kC2 + e], r3 = srows[(long long)(b + 48) * FR.C3 * kC2 + e];
+            p0 = p0 + (c0 != 0.0f ? r0 : 0.0f); p1 = p1 + (c1 != 0.0f ? r1 : 0.0f); p2 = p2 + (c2 != 0.0f ? r2 : 0.0f); p3 = p3 + (c3 != 0.0f ? r3 : 0.0f);
         }
-        for (; b < B; b += 16) p0 = p0 + (chc[(long long)b * FR.C3 + ch] != 0.0f ? srows[(long long)b * FR.C3 * kC2 + e] : 0.0f);
+        for (; b < B; b += 16) {
+            const float c0 = chc[(long long)b * FR.C3 + ch], r0 = srows[(long long)b * FR.C3 * kC2 + e];
+            p0 = p0 + (c0 != 0.0f ? r0 : 0.0f);
+        }
         s_part[g][c] = (p0 + p1) + (p2 + p3);
         __syncthreads();
         if (g == 0) {
