@@ -1287,15 +1287,8 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
             auto kern = encoder_bwdg_fused_kernel<T0, C1, C2, C3>;
             const size_t flds = fused_lds_bytes(T0, C1, C2, C3);
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), flds)) return rc;
-            static int occ = 0;           // resident workgroups per CU (registers and LDS decide; the same for every shape of a build's C1)
-            int occ_now = occ;
-            if (!occ_now) {
-                int n = 0;
-                PCRL_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 64 * kFusedWaves, flds));
-                occ_now = n < 1 ? 1 : (n > 2 ? 2 : n);
-                occ = occ_now;
-            }
-            const int grid = std::min(std::min(num_cus() * occ_now, p.fused_rows), p.cl.B * bwdg_tpc(C3));
+            // one workgroup per CU is resident (four waves of up to 512 registers: __launch_bounds__(256, 1)); tiles are dealt round-robin
+            const int grid = std::min(std::min(num_cus(), p.fused_rows), p.cl.B * bwdg_tpc(C3));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kFusedWaves), flds, stream, p);
             PCRL_BWDG_AFTER("encoder_bwdg_fused_kernel");
             const GradLayout GL{p.cl.C, C1, C2, C3};
