@@ -2,22 +2,24 @@
 //
 // Same algebra as encoder_bwd_gram.h (read its header first).  What changes is who does what:
 //
-//   * a 32-point tile is worked by a TEAM of four waves (one workgroup = one team, two workgroups per CU at c1 = 64), wave w owning row
-//     block w of every C2-wide quantity (h1, q = Mc h1, dH1, dz1).  Per-point scalars that need all C2 channels (LayerNorm-1's mean /
+//   * a 32-point tile is worked by a TEAM of four waves (one workgroup = one team = one CU: the waves use up to 512 registers), wave w owning
+//     row block w of every C2-wide quantity (h1, q = Mc h1, dH1, dz1).  Per-point scalars that need all C2 channels (LayerNorm-1's mean /
 //     variance and its backward sums, mu = s.h1 / C3, var = h1.q / C3, the owned channels' dot products W2[c,:].h1) are added
-//     over the four waves through small LDS arrays, seven workgroup barriers per tile;
+//     over the four waves through small LDS arrays, six workgroup barriers per tile (LayerNorm-1's statistics in one exchange);
 //   * each wave's row block is transposed ONCE into LDS (pitch 33 float4: both directions conflict-free, store_block_pieces' layout)
 //     and serves twice from there: as the B operand of the next layer for the other three waves (q = Mc h1, dH0 = W1^T dz1), and as
 //     the A / B operand pieces of the weight-gradient blocks -- which are therefore accumulated where their operands are produced:
 //     G (the ten upper 32 x 32 blocks), dW1, dW0 | b0 live in registers across all the tiles a workgroup takes, v / u in one register
 //     per thread, norm1 sums per lane, norm2 sums in LDS, and leave once per workgroup.  No operand pieces in global memory (84 MB per K1 launch
-//     before), no per-cloud wgrad launch; the reduce launch adds <= 2 x #CUs workgroup rows instead of B cloud rows;
+//     before), no per-cloud wgrad launch; the reduce launch adds <= #CUs workgroup rows instead of B cloud rows;
 //   * the sparse rows of dW2, S[c,:] = rstd2 dx_c h1_p(c), still leave per (cloud, channel) -- one point owns the row, there is nothing to
 //     accumulate -- and the reduce launch adds them over the clouds, skipping the channels the forward left dead.
 //
 // Sums over the four waves are formed in wave order, the tiles of a workgroup in tile order, the workgroup rows in row order: bitwise
 // reproducible for a given launch geometry; the split of a 128-term sum into 4 x 32 differs from encoder_bwd_gram.h's in the last bits.
 // Exact-fp32 arithmetic only (mode 0; the bf16 mode's backward runs these kernels too, see encoder_bwd_impl.h).
+// Used for launches of at most two tiles per CU (pcrl_encoder_bwd_set_fused, include/pcrl.h): one tile at a time per CU is what limits it --
+// measurements, per-phase stamps and the builds that tried to lift that limit: profiles/r05_bwd_team.md, DESIGN.md section 4.2.
 #pragma once
 // (included by encoder_bwd_gram.h inside namespace pcrl, mode 4 / arithmetic 0 only)
 
