@@ -1,5 +1,6 @@
-"""Soak run: 20 000 graph-replayed SAC steps (K1 shape) and 8 000 DrQ steps (rotation + scale + jitter) against a device replay whose ring keeps
-changing; every returned metric and every parameter must stay finite.    python tools/soak.py"""
+"""Soak run: 20 000 graph-replayed SAC steps (K1 shape), 8 000 DrQ steps (rotation + scale + jitter) and 20 000 SAC steps at a rank's 32-cloud
+share (the encoder backward's team kernel) against a device replay whose ring keeps changing; every returned metric and every parameter must
+stay finite.    python tools/soak.py"""
 import sys, math, time, torch
 sys.path.insert(0, '.')
 import bench
@@ -9,7 +10,8 @@ from pointcloud_rl_amd.replay import DeviceReplay
 from pointcloud_rl_amd.synthetic import make_batch_np
 dev = torch.device('cuda', 0)
 for name, cfgf, kw, B, N, A, steps in [('k1', configs.sac_dmc, dict(pcd_channels=6, action_dim=6, batch_size=256), 256, 1024, 6, 20000),
-                                        ('k2-like', configs.drq_dmc, dict(pcd_channels=6, action_dim=6, batch_size=128, obs_aug=[configs.ROT_SCALE, configs.JITTER]), 128, 1024, 6, 8000)]:
+                                        ('k2-like', configs.drq_dmc, dict(pcd_channels=6, action_dim=6, batch_size=128, obs_aug=[configs.ROT_SCALE, configs.JITTER]), 128, 1024, 6, 8000),
+                                        ('k1 share', configs.sac_dmc, dict(pcd_channels=6, action_dim=6, batch_size=32), 32, 1024, 6, 20000)]:
     cfg = cfgf(**kw)
     cfg['env_params'] = configs.env_params({'xyz': [3, N], 'rgb': [3, N]}, A)
     torch.manual_seed(0)
