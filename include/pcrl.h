@@ -232,6 +232,9 @@ int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_
  * csrc/encoder_bwd_gram.h (faster there: four independent tiles per CU).  mode 0: never the team kernel; mode 2: wherever it is built.
  * Same gradients to fp32 summation order; each path bitwise reproducible.  Returns PCRL_OK, PCRL_E_ARG for another mode. */
 int pcrl_encoder_bwd_set_fused(int32_t mode);
+/* What the last pcrl_encoder_bwd_* call of this host thread launched: 1 the round-2 kernels (no pooled values given), 2 the Gram form's points /
+ * wgrad / reduce launches, 3 the Gram form's team kernel; 0 before the first call.  For tests of the selection above. */
+int pcrl_encoder_bwd_last_schedule(void);
 /* Backward of pcrl_encoder_fwd_bf16.  With `pooled` (and up to 2 048 clouds; PCRL_BWD_BF16_GRAM, default 1): the fp32 Gram-form
  * backward of pcrl_encoder_bwd_f32 at the bf16 forward's routing (its argmax, its pooled > 0 decisions) -- the exact fp32 gradient
  * along that routing (tests: 2e-4 of each tensor's largest entry against fp32 autograd routed the same way; up to ~6e-2 from autograd

@@ -1284,6 +1284,7 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
     if constexpr (C2 == 128 && C3 == 256 && (C1 == 64 || C1 == 128)) {
         if (p.fused == 2 || (p.fused == 1 && p.cl.B * bwdg_tpc(C3) <= 2 * num_cus())) {
             // the team kernel (encoder_bwd_fused.h): chain + weight-gradient sums in one launch, then the reduce over the workgroup rows
+            if (p.schedule_out) *p.schedule_out = 3;
             auto kern = encoder_bwdg_fused_kernel<T0, C1, C2, C3>;
             const size_t flds = fused_lds_bytes(T0, C1, C2, C3);
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), flds)) return rc;

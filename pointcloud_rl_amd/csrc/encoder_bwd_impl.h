@@ -106,6 +106,7 @@ struct BwdParams {
     float* srows;            // [B][C3][C2]
     int* n_items;            // [1] tiles of the launch (written by the team kernel, read by the reduce launch)
     unsigned long long* own_pack;  // [B][kC3] per active slot: its first eight channels, one byte each, 0xFF = none (c3 <= 256 prep only)
+    int* schedule_out;       // host: which schedule the launch code took (pcrl_encoder_bwd_last_schedule), or NULL
     // column-sum jobs riding on the reduce launch (pcrl_encoder_bwd_attach_colsum): cs_blocks extra workgroups behind its own
     ColsumParams cs;
     int cs_blocks;
@@ -1306,6 +1307,10 @@ extern "C" int pcrl_encoder_bwd_set_fused(int32_t mode) {
     return PCRL_OK;
 }
 
+// pcrl_encoder_bwd_last_schedule: what the last backward of this host thread launched
+static thread_local int t_bwd_schedule = 0;
+extern "C" int pcrl_encoder_bwd_last_schedule(void) { return t_bwd_schedule; }
+
 // pcrl_encoder_bwd_attach_colsum: jobs handed over for the NEXT backward of this host thread
 static thread_local pcrl_colsum_job t_colsum_jobs[kColsumJobs];
 static thread_local int t_colsum_n = 0;
@@ -1374,6 +1379,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             p.own_pack = reinterpret_cast<unsigned long long*>(base + wg.own_pack);
             p.srows = p.ops;          // the team kernel writes no operand pieces: their region holds the sparse rows of dW2
             p.fused = g_bwd_fused; p.fused_rows = wg.fused_rows;
+            p.schedule_out = &t_bwd_schedule; t_bwd_schedule = 2;
             p.w2 = w->w2;
             p.pw_stride = GL.total() + GramExtra{w->c2}.total();
             p.tile_mode = 1;
@@ -1395,6 +1401,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             return fail(PCRL_E_ARG, "mlp_spec=[%d,%d,%d]: the wide last layer is built in Gram form only: fp32, the forward's pooled values "
                                     "given, at most %d clouds", w->c1, w->c2, w->c3, kMaxTileModeClouds);
     }
+    t_bwd_schedule = 1;
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);
     p.flag = reinterpret_cast<int*>(base + ws.flag); p.act = reinterpret_cast<int*>(base + ws.act);

@@ -396,6 +396,11 @@ def encoder_bwd_set_fused(mode):
     check(lib().pcrl_encoder_bwd_set_fused(int(mode)))
 
 
+def encoder_bwd_last_schedule():
+    """include/pcrl.h: pcrl_encoder_bwd_last_schedule -- 1 round-2 kernels, 2 Gram-form launches, 3 Gram-form team kernel (this thread's last call)."""
+    return int(lib().pcrl_encoder_bwd_last_schedule())
+
+
 if os.environ.get("PCRL_BWD_PATHS") in ("legacy", "team"):       # measurement only (same-box A/B): one backward path for every launch
     lib().pcrl_encoder_bwd_set_fused(0 if os.environ["PCRL_BWD_PATHS"] == "legacy" else 2)
 

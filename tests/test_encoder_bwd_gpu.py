@@ -104,6 +104,30 @@ def test_bwd_matches_torch_autograd(cuda, bwd_path, B, N, extra, c1):
     assert_grads_close(got_dense, ref)
 
 
+def test_bwd_schedule_follows_the_launch_size(cuda):
+    """include/pcrl.h: pcrl_encoder_bwd_set_fused(1), the default -- the team kernel for launches of at most two 32-point tiles per CU (8 B <=
+    2 x #CUs possible tiles), the points / wgrad / reduce launches beyond; a call without the forward's pooled values keeps the round-2 kernels;
+    the shapes the team kernel is not built for (c2 = 64) keep the launches."""
+    from pointcloud_rl_amd import hip
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    small, large = max(1, n_cu // 4), n_cu // 4 + 1
+    seen = {}
+    for B, c1 in ((small, 64), (large, 64), (3, 32)):
+        obs = make_obs(B, 70, seed=B)
+        c2, c3 = (64, 128) if c1 == 32 else (128, 256)
+        w = make_encoder_weights(6, c1, c2, c3, seed=1)
+        gpool = np.random.RandomState(B).randn(B, c3).astype(np.float32)
+        hip_grads(obs, w, gpool, cuda)
+        seen[(B, c1)] = hip.encoder_bwd_last_schedule()
+    assert seen == {(small, 64): 3, (large, 64): 2, (3, 32): 2}, seen
+    hip_grads(make_obs(2, 70, seed=1), make_encoder_weights(6, 64, 128, 256, seed=1), np.zeros((2, 256), np.float32), cuda, with_pooled=False)
+    assert hip.encoder_bwd_last_schedule() == 1
+    for mode, want in ((0, 2), (2, 3), (1, 3)):
+        hip.encoder_bwd_set_fused(mode)
+        hip_grads(make_obs(2, 70, seed=1), make_encoder_weights(6, 64, 128, 256, seed=1), np.zeros((2, 256), np.float32), cuda)
+        assert hip.encoder_bwd_last_schedule() == want, (mode, want)
+
+
 def test_bwd_with_jitter_noise(cuda, bwd_path):
     obs = make_obs(3, 200, seed=5)
     w = make_encoder_weights(6, 64, 128, 256, seed=9)
