@@ -134,6 +134,22 @@ def ensure_runtime_links():
     bundled = os.path.join(src, "libamdhip64.so")
     if not os.path.exists(bundled):
         return None
+    # fast path of every later process start: the stamp written with the links names the library build and the torch runtime they were
+    # made for -- no readelf child processes when nothing changed
+    stamp_path = os.path.join(RUNTIME_LINKS, ".stamp")
+    try:
+        stamp = f"{os.stat(LIB_PATH).st_mtime_ns}\n{os.path.realpath(bundled)}\n"
+    except OSError:
+        stamp = None
+    try:
+        with open(stamp_path) as f:
+            have = f.read()
+        if stamp and have.startswith(stamp):
+            cached = have[len(stamp):].strip()
+            if cached and os.path.realpath(os.path.join(RUNTIME_LINKS, cached)) == os.path.realpath(bundled):
+                return RUNTIME_LINKS
+    except OSError:
+        pass
     needed = _needed_hip_soname() or "libamdhip64.so.7"
     if needed != "libamdhip64.so":
         # torch's copy must BE that ABI: its own soname (when readable) has to match the request
@@ -150,32 +166,82 @@ def ensure_runtime_links():
     fresh = lambda: os.path.islink(marker) and os.path.realpath(marker) == os.path.realpath(bundled)
     if fresh():
         return RUNTIME_LINKS
-    # Built aside and moved into place by renames only: the ranks of a multi-GPU launch may all get here at once on a fresh machine, and
-    # a loader must never see a missing or half-made directory.  A stale set (another torch installation) is first renamed ASIDE, the new
-    # one renamed in, the old one deleted afterwards; whoever loses a rename re-checks the marker instead of deleting what a peer just made.
+    # `_hiprt` is a symbolic link to a directory of links built aside; putting it in place (or replacing a stale one: another torch
+    # installation) is ONE rename of the link (os.replace is atomic), so the ranks of a multi-GPU launch that all get here at once on a
+    # fresh machine, and every loader resolving $ORIGIN/_hiprt meanwhile, see the old set or the new one -- never a missing or half-made
+    # directory.  A real directory left by earlier versions of this function cannot be replaced by a link in one step: it is renamed aside
+    # first (the only non-atomic case, once per machine that has one).
     import shutil
-    tmp = f"{RUNTIME_LINKS}.tmp.{os.getpid()}"
-    shutil.rmtree(tmp, ignore_errors=True)
-    os.makedirs(tmp)
+    target = f"{RUNTIME_LINKS}.d.{os.getpid()}"
+    shutil.rmtree(target, ignore_errors=True)
+    os.makedirs(target)
     for name in sorted(os.listdir(src)):
         if ".so" in name and os.path.isfile(os.path.join(src, name)):
-            os.symlink(os.path.join(src, name), os.path.join(tmp, name))
-    if not os.path.lexists(os.path.join(tmp, needed)):
-        os.symlink(bundled, os.path.join(tmp, needed))
-    old = None
-    if os.path.isdir(RUNTIME_LINKS) and not fresh():
-        old = f"{RUNTIME_LINKS}.old.{os.getpid()}"
-        try:
-            os.rename(RUNTIME_LINKS, old)
-        except OSError:
-            old = None                                # a peer moved it first
+            os.symlink(os.path.join(src, name), os.path.join(target, name))
+    if not os.path.lexists(os.path.join(target, needed)):
+        os.symlink(bundled, os.path.join(target, needed))
+    if stamp:
+        with open(os.path.join(target, ".stamp"), "w") as f:
+            f.write(stamp + needed + "\n")
+    link_tmp = f"{RUNTIME_LINKS}.lnk.{os.getpid()}"
     try:
-        os.rename(tmp, RUNTIME_LINKS)
-    except OSError:                                   # another process won the race: its directory is as good as this one
-        shutil.rmtree(tmp, ignore_errors=True)
-    if old:
-        shutil.rmtree(old, ignore_errors=True)
+        if os.path.lexists(link_tmp):
+            os.unlink(link_tmp)
+        os.symlink(os.path.basename(target), link_tmp)
+        stale = os.path.realpath(RUNTIME_LINKS) if os.path.islink(RUNTIME_LINKS) else None
+        if os.path.isdir(RUNTIME_LINKS) and not os.path.islink(RUNTIME_LINKS):
+            aside = f"{RUNTIME_LINKS}.old.{os.getpid()}"
+            os.rename(RUNTIME_LINKS, aside)
+            shutil.rmtree(aside, ignore_errors=True)
+        os.replace(link_tmp, RUNTIME_LINKS)
+        if stale and stale != os.path.realpath(target) and os.path.basename(stale).startswith(os.path.basename(RUNTIME_LINKS) + ".d."):
+            shutil.rmtree(stale, ignore_errors=True)
+    except OSError:
+        if os.path.lexists(link_tmp):
+            os.unlink(link_tmp)
+        if not fresh():
+            shutil.rmtree(target, ignore_errors=True)
     return RUNTIME_LINKS if fresh() else None
+
+
+class _TracedLib:
+    """Debug switch PCRL_TRACE_LAUNCHES=<directory>: every pcrl_* entry point called through this binding writes `> name` to
+    <directory>/rank<RANK>_pid<pid>.trace BEFORE the call and `< name rc` after the device has finished it (a stream synchronisation
+    after every call unless PCRL_TRACE_SYNC=0 or the stream is capturing).  A rank that dies of an asynchronous GPU fault -- the queue
+    abort callback calls abort() from a runtime thread -- leaves the name of the launch in flight as the file's last line; a last line
+    `< name` says the fault came from work that is NOT this library's (torch, the collective's staging copies).  Written with os.write
+    on an O_APPEND descriptor: nothing is buffered in the process."""
+
+    def __init__(self, cdll, directory):
+        os.makedirs(directory, exist_ok=True)
+        self.__dict__["_cdll"] = cdll
+        self.__dict__["_fd"] = os.open(os.path.join(directory, f"rank{os.environ.get('RANK', '0')}_pid{os.getpid()}.trace"),
+                                       os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+        self.__dict__["_sync"] = os.environ.get("PCRL_TRACE_SYNC", "1") != "0"
+        self.__dict__["_wrapped"] = {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if not name.startswith("pcrl_") or name == "pcrl_last_error":
+            return fn
+        w = self._wrapped.get(name)
+        if w is None:
+            import torch
+            fd, sync = self._fd, self._sync
+            enter, leave = f"> {name}\n".encode(), f"< {name} ".encode()
+
+            def w(*args):
+                os.write(fd, enter)
+                rc = fn(*args)
+                if sync and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()
+                os.write(fd, leave + str(rc).encode() + b"\n")
+                return rc
+            self._wrapped[name] = w
+        return w
+
+    def __setattr__(self, name, value):
+        setattr(self._cdll, name, value)
 
 
 def lib():
@@ -196,6 +262,8 @@ def lib():
             pass                         # a read-only tree: the torch-first order above is what keeps this process on one runtime
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.pcrl_last_error.restype = ctypes.c_char_p
+        if os.environ.get("PCRL_TRACE_LAUNCHES"):
+            _lib = _TracedLib(_lib, os.environ["PCRL_TRACE_LAUNCHES"])
     return _lib
 
 
