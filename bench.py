@@ -93,6 +93,11 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=100)
     ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
+    ap.add_argument("--start-lock", type=int, default=1, help="ranks SHARING one GPU (--dry-run-ranks / --share-gpu) bring their GPU context up one after "
+                    "the other (a file lock around device initialisation, agent construction and the first synchronisation): eight processes "
+                    "initialising one MI355X at the same moment die of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in ~30 % of the launches, in torch's "
+                    "own start-up work, before the rank has launched a single kernel of this library (profiles/r06_dry_run_loop.md); 0 = off. "
+                    "Real multi-GPU runs (one device per rank) never take the lock")
     ap.add_argument("--dry-run-ranks", type=int, default=0, help="rehearsal of the multi-GPU run on a ONE-GPU box: the launcher starts this many ranks "
                     "exactly as `--gpus N` does (rendezvous on 127.0.0.1, to_ddp's broadcast, the sharded replay rings, the data-parallel step "
                     "schedule, the comm / no-comm timing, the extra workloads behind their watchdog, rank 0's line last on stdout), but the ranks "
@@ -188,12 +193,26 @@ def feature_dim(agent):
     return fm[0].out_features if fm is not None else agent.encoder.mlp_spec[-1]
 
 
-def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, head_hidden=1024, feat=None):
-    """Whole-step figure next to the dominant kernel's: SURVEY.md section 8(d)'s CANONICAL FLOPs per gradient step (encoder: next_obs fwd,
-    obs fwd + 2 x bwd, the actor's obs fwd every second step = 4.5 point-passes per point, DrQ's actor pass on augmentation #0 only; heads:
-    (2.5 F_a + 11 F_q) per sample) / ms_per_step / the dense MFMA peak of the encoder's arithmetic.  The implementation executes FEWER
-    FLOPs than canonical (the max-pool's gradient reaches <= c3 points per cloud), so this is a rate of useful work, not pipe utilisation."""
-    f_pt = 2.0 * (C * spec[0] + spec[0] * spec[1] + spec[1] * spec[2])
+def active_points_per_cloud(agent):
+    """Points per cloud the encoder backward of the last eager step actually visited: the distinct argmax positions of the gradient-carrying
+    pass (what the backward's prep launch counts into its bitmap), read from the step's own argmax tensor; None when the step kept none."""
+    am = getattr(getattr(agent, "_fused", None), "last_argmax", None)
+    if am is None or am.numel() == 0:
+        return None
+    srt = am.reshape(am.shape[0], -1).sort(dim=1).values
+    return float(((srt[:, 1:] != srt[:, :-1]).sum(1) + 1).float().mean().item())
+
+
+def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, head_hidden=1024, feat=None, active_pts=None):
+    """Whole-step figure next to the dominant kernel's.  `frac` = EXECUTED FLOPs / step time / the dense MFMA peak of the encoder's
+    arithmetic (<= 1 by construction); `useful_tflops` = SURVEY.md section 8(d)'s CANONICAL FLOPs (dense backward: 4.5 point-passes per
+    point, heads (2.5 F_a + 11 F_q) per sample) / step time -- the rate of useful work, which exceeds the executed rate because the
+    max-pool's gradient reaches only the argmax points of a cloud.
+    Executed = 2.5 forward point-passes + heads + the Gram-form backward on the ACTIVE points, per active point:
+    recompute conv0 / conv1 2 (C c1 + c1 c2), q = Mc h1 2 c2^2, dH0 = W1^T dz1 2 c1 c2, the 10 of 16 blocks of G 1.25 c2^2, dW1 2 c1 c2,
+    dW0 2 C c1; per cloud the owned channels' rows 6 c2 c3 (two dot-product passes and the dW2 rows)."""
+    c1, c2, c3 = spec
+    f_pt = 2.0 * (C * c1 + c1 * c2 + c2 * c3)
     P = b_global * num_aug * wl["N"]
     enc = (4.0 * P + 0.5 * b_global * wl["N"]) * f_pt
     F = feat if feat is not None else 50
@@ -202,14 +221,42 @@ def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, he
     f_q = 2.0 * ((d_a + A) * head_hidden + head_hidden ** 2 + head_hidden)
     heads = (2.5 * f_a + 11 * f_q) * b_global * num_aug
     peak = 2500.0 if is_bf16 else 157.3
-    tf = (enc + heads) / (ms_per_step * 1e-3) / 1e12
-    # what is certainly EXECUTED: the 2.5 forward point-passes (2 + the actor's half) and the heads; the backward reaches <= c3 points of a cloud
-    fwd_only = ((2.0 * P + 0.5 * b_global * wl["N"]) * f_pt + heads) / (ms_per_step * 1e-3) / 1e12
-    return {"canonical_gflop_per_step": (enc + heads) / 1e9, "encoder_gflop": enc / 1e9, "heads_gflop": heads / 1e9, "achieved": tf, "unit": "TFLOP/s",
-            "peak": peak, "frac": tf / peak, "executed_lower_bound_frac": fwd_only / peak,
-            "note": "canonical (dense-backward) FLOPs of SURVEY.md 8(d) per measured step time: a rate of USEFUL work, not pipe utilisation -- the "
-                    "max-pool's gradient reaches <= c3 points of a cloud, so the executed backward is a fraction c3 / N of the canonical one and `frac` "
-                    "may exceed 1 for large N (config 5); `executed_lower_bound_frac` counts the forward passes and the heads only"}
+    per_s = 1.0 / (ms_per_step * 1e-3) / 1e12
+    fwd = (2.0 * P + 0.5 * b_global * wl["N"]) * f_pt
+    n_act = min(active_pts if active_pts is not None else float(c3), float(wl["N"]), float(c3))
+    f_bwd_pt = 2.0 * (C * c1 + c1 * c2) + 2.0 * c2 * c2 + 2.0 * c1 * c2 + 1.25 * c2 * c2 + 2.0 * c1 * c2 + 2.0 * C * c1
+    bwd = b_global * num_aug * (n_act * f_bwd_pt + 6.0 * c2 * c3)
+    executed = fwd + heads + bwd
+    return {"executed_gflop_per_step": executed / 1e9, "achieved": executed * per_s, "unit": "TFLOP/s", "peak": peak, "frac": executed * per_s / peak,
+            "active_points_per_cloud": n_act, "active_points_source": "distinct argmax positions of the step's gradient-carrying pass" if active_pts is not None
+            else "upper bound c3 (not measured on this run)",
+            "encoder_fwd_gflop": fwd / 1e9, "encoder_bwd_gflop": bwd / 1e9, "heads_gflop": heads / 1e9,
+            "canonical_gflop_per_step": (enc + heads) / 1e9, "useful_tflops": (enc + heads) * per_s, "useful_frac": (enc + heads) * per_s / peak,
+            "note": "`frac` counts the FLOPs the kernels execute (forward passes, heads, the Gram-form backward on the active points: DESIGN.md 4.2); "
+                    "`useful_tflops` / `useful_frac` price SURVEY.md 8(d)'s canonical dense-backward FLOPs at the same step time and may exceed the peak "
+                    "(the max-pool's gradient reaches <= c3 points of a cloud): a rate of useful work, not pipe utilisation"}
+
+
+def gemm_roofline(timer, steps_timed):
+    """Second `roofline` object: the head GEMM launches (gemm_fam_kernel<...>, csrc/dense.hip) -- the kernel family furthest below its roofline
+    with a real share of the step.  FLOPs = 2 M N K of every problem launched under the timer, time = the launches' HIP-event spans."""
+    spans = timer.summary()
+    names = [k for k in spans if k == "gemm" or k.startswith("gemm ")]
+    n = sum(spans[k][0] for k in names)
+    total_ms = sum(spans[k][0] * spans[k][1] for k in names)
+    flops = timer.flops.get("gemm", 0.0)
+    if not n or total_ms <= 0:
+        return None
+    achieved = flops / (total_ms * 1e-3) / 1e12
+    busy, busy_src = None, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_matrix_busy.json")))
+    if cands:
+        bj = json.load(open(cands[-1]))
+        if bj.get("kernel_source_sha") == kernel_source_sha():
+            busy, busy_src = bj.get("matrix_busy"), os.path.relpath(cands[-1], ROOT)
+    return {"kernel": "gemm_fam_kernel<families, waves>", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+            "launches_per_step": n / max(steps_timed, 1), "us_per_step": total_ms * 1e3 / max(steps_timed, 1), "gflop_per_step": flops / 1e9 / max(steps_timed, 1),
+            "matrix_busy": busy, "matrix_busy_source": busy_src, "timed_with": "HIP events on the launch stream, eager pass"}
 
 
 def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=None, memory=None, graphs=True, roofline=False,
@@ -256,8 +303,6 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
     out = {"value": steps / dt, "unit": "gradient steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "global_batch": wl["B"], "batch_per_gpu": b_rank, "points": wl["N"], "n_gpus": world, "scaling": "strong",
            "exchange": exchange_mode(agent, dist_on), "dtype": {"bf16": "bf16", "f32split": "f32split"}.get(getattr(agent.encoder, "compute_dtype", "f32"), "f32")}
-    out["step"] = step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], out["ms_per_step"],
-                                getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent))
     if roofline:
         # per-kernel spans from an eager pass over the same ring and weights (a replayed graph's launches cannot be bracketed by
         # host-recorded events); every rank runs it (the step's collectives are inside), rank 0's spans are reported
@@ -279,6 +324,12 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
         n_fwd, ms_fwd = spans.get("encoder_fwd", (0, float("nan")))
         out["roofline"] = encoder_roofline(agent, wl, C, b_rank, n_fwd, ms_fwd, eager_steps, name, graphs, use_traffic=not dist_on)
         out["kernels_ms"] = {k: {"launches": n, "avg_ms": ms} for k, (n, ms) in spans.items()}
+        g = gemm_roofline(timer, eager_steps)
+        if g:
+            out["roofline_gemm"] = g
+    out["step"] = step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], out["ms_per_step"],
+                                getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent),
+                                active_pts=active_points_per_cloud(agent) if roofline else None)
     if cpu_steps and rank == 0:
         points = wl["B"] * wl["N"] * getattr(agent, "num_aug", 1)
         out["cpu_baseline"] = cpu_baseline(agent, wl, cpu_steps, cpu_threads, sample_batch=wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points)),
@@ -486,7 +537,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     if args.share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    lock_start = bool(args.share_gpu and world > 1 and args.start_lock)
+    if not lock_start:
+        torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_on = world > 1
     if args.single_rank_exchange and world == 1:
@@ -503,7 +556,19 @@ def main():
 
     from pointcloud_rl_amd import hip
     from pointcloud_rl_amd.synthetic import SyntheticReplay
+    start_lock = None
+    if lock_start:
+        # (the rendezvous above is gloo's, on the host; from here to the first synchronisation one rank at a time touches the device)
+        import fcntl
+        start_lock = open(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pcrl_bench_start_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+        fcntl.flock(start_lock, fcntl.LOCK_EX)
+        torch.cuda.set_device(local_rank)
     agent, C = build_agent(wl, b_rank, device, args.encoder_dtype)
+    if start_lock is not None:
+        torch.zeros(1 << 16, device=device).add_(1.0).sum().item()      # torch's first fill / elementwise / reduction kernels and the first copy back
+        torch.cuda.synchronize()
+        fcntl.flock(start_lock, fcntl.LOCK_UN)
+        start_lock.close()
     if dist_on:
         agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
@@ -627,7 +692,8 @@ def main():
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": roof,
             "step": step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], elapsed / args.steps * 1e3,
-                                  getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent)),
+                                  getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent), active_pts=active_points_per_cloud(agent)),
+            "roofline_gemm": gemm_roofline(timer, steps_timed),
             "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
         }
         if nocomm_ms is not None:

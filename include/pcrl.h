@@ -230,7 +230,9 @@ int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_
  * a data-parallel batch) take the team kernel of csrc/encoder_bwd_fused.h -- the per-point chain and the weight-gradient sums in one
  * launch, four waves per tile, no operand pieces in global memory --, larger launches the points / wgrad / reduce launches of
  * csrc/encoder_bwd_gram.h (faster there: four independent tiles per CU).  mode 0: never the team kernel; mode 2: wherever it is built.
- * Same gradients to fp32 summation order; each path bitwise reproducible.  Returns PCRL_OK, PCRL_E_ARG for another mode. */
+ * Same gradients to fp32 summation order; each path bitwise reproducible.  PROCESS-WIDE (one atomic read by every later backward of
+ * any host thread; with pcrl_gemm_set_tile64_min the library's only mutable global state): a knob for tests and A/B measurements, not
+ * a per-call option.  Returns PCRL_OK, PCRL_E_ARG for another mode. */
 int pcrl_encoder_bwd_set_fused(int32_t mode);
 /* What the last pcrl_encoder_bwd_* call of this host thread launched: 1 the round-2 kernels (no pooled values given), 2 the Gram form's points /
  * wgrad / reduce launches, 3 the Gram form's team kernel; 0 before the first call.  For tests of the selection above. */
@@ -352,7 +354,7 @@ int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void* stream);
  * LDS-staged 64 x 64 tiles when the launch has at least `min_tiles` of them (default 192), everything else as 32 x 32 split-K tiles.
  * Knob for tests and benchmarks: min_tiles <= 1 forces the 64 x 64 staged tiles for every problem they can compute (M, N >= 48,
  * K >= 64, any operand orientation); min_tiles >= 2^30 selects the paths of rounds 1-4 only (32 x 32 split-K tiles, a tile per wave
- * for the weight gradients).  Returns the previous value; a negative argument only queries. */
+ * for the weight gradients).  PROCESS-WIDE (an atomic).  Returns the previous value; a negative argument only queries. */
 int pcrl_gemm_set_tile64_min(int32_t min_tiles);
 /* What pcrl_gemm_group_f32 would launch for these problems, without launching: out[3 i .. 3 i + 2] = {path, tile shape, workgroups}
  * of problem i (path: 0 32 x 32 split-K, 1 64 x 64 staged, 2 / 3 a tile per wave, 4 wave-private staged tiles, 5 weight-gradient

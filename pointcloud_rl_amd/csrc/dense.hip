@@ -698,10 +698,23 @@ __host__ __device__ constexpr int wtile_tn(int shape, int brc) { return shape ==
 // cfg 5 panel shapes: 0 = 64 x 128 (no split-K), 1 = 64 x 64 (two k halves)
 __host__ __device__ constexpr int wpanel_tn(int shape) { return shape == 0 ? 128 : 64; }
 
-// Two kernels share the launch code.  `gemm_f32_kernel` holds the paths of rounds 1-4 (cfg 0-3) exactly as they were compiled then;
-// `gemm_f32_wt_kernel` holds every path (cfg 0-5) and runs the launches that contain a round-5 path.  ONE kernel for everything measured
-// 1-4 % slower on the 64 x 64 staged tiles (same source, another register allocation / code layout: K2's step +1.3 %), a kernel with ONLY
-// the round-5 paths measured 3.7 us slower on the grouped dW | dX launch (K1's step +4.5 us) -- tools/r5_ab2.sh, same box, three builds.
+// One kernel per tile-path FAMILY (round 6).  Rounds 1-5 ran every launch through one of two kernels that held several paths behind a
+// run-time switch, compiled for 128 registers (`__launch_bounds__(512, 4)`): every path got the budget of the hungriest one -- the
+// LDS-staged 64 x 64 tiles, which want 162 registers and spilled 53 of them into their k loop, although their 136 KB of LDS leave room
+// for ONE workgroup per CU (2 waves per SIMD = 256 registers) whatever the register count.  A kernel is now instantiated per set of
+// families, with the register budget of that set: a launch takes the kernel of exactly the families its problems use (the table
+// below), so a family's code is compiled on its own -- no spilled register in any k loop (checked with
+// -Rpass-analysis=kernel-resource-usage: VGPRs spilled 0 for every variant but the catch-all).
+//   legacy : cfg 0 (32 x 32 split-K), cfg 2 / 3 (a tile per wave)            96 / 95 / 111 registers   -> 4 waves per SIMD
+//   t64    : cfg 1 (64 x 64 tiles staged through 136 KB of LDS)              162                       -> 2 (LDS-bound to one workgroup per CU anyway)
+//   wt     : cfg 4, B k-contiguous (forward): 16 x 16 ... 32 x 64            68 ... 136                -> 2 (80 - 120 KB of LDS: one workgroup per CU)
+//   wtx    : cfg 4, B contiguous along n (data gradient)                     60 ... 94 (32 x 64: 166)  -> 4 (40 - 80 KB of LDS); the 32 x 64 shape only in 2-wave variants
+//   panel  : cfg 5 (weight-gradient panels)                                  66 / 67                   -> 4
+constexpr unsigned kFamLegacy = 1u, kFamT64 = 2u, kFamWt = 4u, kFamWtx = 8u, kFamPanel = 16u, kFamAll = 31u;
+__host__ __device__ constexpr unsigned gemm_family(int cfg, int b_rc) {
+    return cfg == 1 ? kFamT64 : cfg == 4 ? (b_rc ? kFamWtx : kFamWt) : cfg == 5 ? kFamPanel : kFamLegacy;
+}
+
 __device__ __forceinline__ int gemm_find_problem(const GemmGroup& g, int wg) {
     int gi = 0;
 #pragma unroll
@@ -710,38 +723,71 @@ __device__ __forceinline__ int gemm_find_problem(const GemmGroup& g, int wg) {
     return gi;
 }
 
-__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_kernel(const GemmGroup g) {
+// W = waves per SIMD the register allocation is made for (4: 128 registers, 2: 256).  The 32 x 64 data-gradient shape (wtx shape 3)
+// exists only where W == 2.
+template <unsigned FAM, int W>
+__global__ __launch_bounds__(64 * kGemmWaves, W) void gemm_fam_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     const int wg = blockIdx.x;
     const GemmParams p = g.p[gemm_find_problem(g, wg)];
-    if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
-    else if (p.cfg == 2) gemm_tile32_wave(p, wg);
-    else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
-    else gemm_tile32_splitk(p, wg, gemm_smem);
-}
-
-__global__ __launch_bounds__(64 * kGemmWaves, 4) void gemm_f32_wt_kernel(const GemmGroup g) {
-    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-    const int wg = blockIdx.x;
-    const GemmParams p = g.p[gemm_find_problem(g, wg)];
-    if (p.cfg == 4) {
-        if (!p.b_rc) {
+    constexpr bool single = (FAM & (FAM - 1)) == 0;          // one family: no dispatch on the problem's cfg
+    if constexpr ((FAM & kFamWt) != 0) {
+        if (single || (p.cfg == 4 && !p.b_rc)) {
             if (p.shape == 0) gemm_wtile<16, 1, 1, 32, false, 2>(p, wg, gemm_smem);
             else if (p.shape == 1) gemm_wtile<16, 1, 2, 32, false, 2>(p, wg, gemm_smem);
             else if (p.shape == 2) gemm_wtile<32, 1, 1, 16, false, 2>(p, wg, gemm_smem);
-            else gemm_wtile<32, 1, 2, 16, false, 1>(p, wg, gemm_smem);
-        } else {
+            else gemm_wtile<32, 1, 2, 16, false, W == 2 ? 2 : 1>(p, wg, gemm_smem);
+            return;
+        }
+    }
+    if constexpr ((FAM & kFamWtx) != 0) {
+        if (single || (p.cfg == 4 && p.b_rc)) {
             if (p.shape == 0) gemm_wtile<16, 1, 1, 32, true, 2>(p, wg, gemm_smem);
             else if (p.shape == 1) gemm_wtile<16, 2, 1, 32, true, 2>(p, wg, gemm_smem);
-            else gemm_wtile<32, 1, 1, 16, true, 2>(p, wg, gemm_smem);      // (a 32 x 64 tile of this kind spills at 128 registers and measured no faster)
+            else if (W != 2 || p.shape == 2) gemm_wtile<32, 1, 1, 16, true, 2>(p, wg, gemm_smem);
+            else if constexpr (W == 2) gemm_wtile<32, 1, 2, 16, true, 2>(p, wg, gemm_smem);
+            return;
         }
-    } else if (p.cfg == 5) {
-        if (p.shape == 0) gemm_wgrad_panel<2, 4, 32>(p, wg, gemm_smem);
-        else gemm_wgrad_panel<2, 2, 64>(p, wg, gemm_smem);
-    } else if (p.cfg == 1) gemm_tile64(p, wg, gemm_smem);
-    else if (p.cfg == 2) gemm_tile32_wave(p, wg);
-    else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
-    else gemm_tile32_splitk(p, wg, gemm_smem);
+    }
+    if constexpr ((FAM & kFamPanel) != 0) {
+        if (single || p.cfg == 5) {
+            if (p.shape == 0) gemm_wgrad_panel<2, 4, 32>(p, wg, gemm_smem);
+            else gemm_wgrad_panel<2, 2, 64>(p, wg, gemm_smem);
+            return;
+        }
+    }
+    if constexpr ((FAM & kFamT64) != 0) {
+        if (single || p.cfg == 1) { gemm_tile64(p, wg, gemm_smem); return; }
+    }
+    if constexpr ((FAM & kFamLegacy) != 0) {
+        if (p.cfg == 2) gemm_tile32_wave(p, wg);
+        else if (p.cfg == 3) gemm_tile64x32_wave(p, wg);
+        else gemm_tile32_splitk(p, wg, gemm_smem);
+    }
+}
+
+// The instantiated variants, most specific first: a launch takes the first one whose family set covers the launch's.
+struct GemmVariant { unsigned fam; int waves; const void* fn; const char* name; };
+#define PCRL_GEMM_VARIANT(F, W) GemmVariant{F, W, reinterpret_cast<const void*>(&gemm_fam_kernel<F, W>), "gemm_fam_kernel<" #F "," #W ">"}
+static const GemmVariant kGemmVariants[] = {
+    PCRL_GEMM_VARIANT(kFamLegacy, 4),
+    PCRL_GEMM_VARIANT(kFamT64, 2),
+    PCRL_GEMM_VARIANT(kFamWt, 2),
+    PCRL_GEMM_VARIANT(kFamWtx, 4),
+    PCRL_GEMM_VARIANT(kFamPanel, 4),
+    PCRL_GEMM_VARIANT(kFamPanel | kFamWtx, 4),                  // dW | dX of a 1 024-wide layer
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamWtx, 4),                 // dW0 | dX0 of the first layer
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamPanel | kFamWtx, 4),     // the policy's dW2 next to [dW1, dh1]
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamWt, 2),                  // a first layer sharing the launch of a 1 024-wide one
+    PCRL_GEMM_VARIANT(kFamPanel | kFamT64, 2),                  // dW | dX at 1 024 rows and more
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 2),
+    PCRL_GEMM_VARIANT(kFamAll, 2),                              // anything else
+};
+#undef PCRL_GEMM_VARIANT
+static const GemmVariant& gemm_variant(unsigned need) {
+    for (const GemmVariant& v : kGemmVariants)
+        if ((v.fam & need) == need) return v;
+    return kGemmVariants[sizeof(kGemmVariants) / sizeof(kGemmVariants[0]) - 1];
 }
 
 static size_t gemm_lds_bytes(const GemmParams& p) {
@@ -749,7 +795,7 @@ static size_t gemm_lds_bytes(const GemmParams& p) {
         if (!p.b_rc) return p.shape == 0 ? WTile<16, 1, 1, 32, false>::lds_bytes() : p.shape == 1 ? WTile<16, 1, 2, 32, false>::lds_bytes()
                           : p.shape == 2 ? WTile<32, 1, 1, 16, false>::lds_bytes() : WTile<32, 1, 2, 16, false>::lds_bytes();
         return p.shape == 0 ? WTile<16, 1, 1, 32, true>::lds_bytes() : p.shape == 1 ? WTile<16, 2, 1, 32, true>::lds_bytes()
-                            : WTile<32, 1, 1, 16, true>::lds_bytes();
+                            : p.shape == 2 ? WTile<32, 1, 1, 16, true>::lds_bytes() : WTile<32, 1, 2, 16, true>::lds_bytes();
     }
     if (p.cfg == 5) return p.shape == 0 ? WPanel<2, 4, 32>::lds_bytes() : WPanel<2, 2, 64>::lds_bytes();
     if (p.cfg == 1) return kGemmLdsBytes;
@@ -989,7 +1035,7 @@ static void gemm_pick_legacy(const pcrl_gemm_desc* d, GemmParams& p, int& tm, in
 }
 
 // Tile paths, workgroup ranges and the LDS size of one launch; src[i] = the caller's index of the launch's i-th problem.
-static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_t& lds, int& wg_total_out, int (&src)[kGemmGroup], bool& use_wt_kernel) {
+static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_t& lds, int& wg_total_out, int (&src)[kGemmGroup], unsigned& families) {
     if (!descs || n < 1 || n > kGemmGroup) return fail(PCRL_E_ARG, "pcrl_gemm_group_f32: 1 <= n <= %d problems", kGemmGroup);
     // Workgroups are dispatched in index order: a problem with a long K loop and few tiles (the data gradient of a small batch:
     // K = 1 024, <= 256 tiles) goes first, so that its few long workgroups start at once and the many short ones of its
@@ -1015,7 +1061,7 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         dd[g.n] = d; src[g.n] = order[oi];
         if (d->M > 0 && d->N > 0) ++g.n;        // empty problems contribute no workgroups
     }
-    wg_total_out = 0; lds = 0; use_wt_kernel = false;
+    wg_total_out = 0; lds = 0; families = 0;
     if (g.n == 0) return PCRL_OK;
     const bool legacy = legacy_only(), force64 = tile64_min_tiles() <= 1;
     const int cus = num_cus();
@@ -1029,7 +1075,7 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
     if (!force64 && tiles64 < tile64_min_tiles())
         for (int i = 0; i < g.n; ++i) use64[i] = false;
     int wg_total = 0;
-    bool any_new = false;
+    unsigned fams = 0;
     for (int i = 0; i < g.n; ++i) {
         const pcrl_gemm_desc* d = dd[i];
         GemmParams& p = g.p[i];
@@ -1062,15 +1108,14 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         } else {
             gemm_pick_legacy(d, p, tm, tn);
         }
-        any_new = any_new || p.cfg >= 4;
+        fams |= gemm_family(p.cfg, p.b_rc);
         gemm_set_tiles(p, tm, tn, n_cols, d->batch, wg_total);
         g.wg_begin[i] = p.wg_begin;
         const size_t need = gemm_lds_bytes(p);
         lds = need > lds ? need : lds;
     }
-    const bool wt_kernel = any_new;          // a launch without a round-5 path runs the rounds-1-4 kernel exactly as it was
     if (wg_total >= (1 << 20)) return fail(PCRL_E_ARG, "GEMM group too large (%d tiles)", wg_total);
-    wg_total_out = wg_total; use_wt_kernel = wt_kernel;
+    wg_total_out = wg_total; families = fams;
     return PCRL_OK;
 }
 
@@ -1078,18 +1123,14 @@ extern "C" int pcrl_gemm_group_f32(const pcrl_gemm_desc* descs, int32_t n, void*
     GemmGroup g;
     size_t lds;
     int wg_total, src[kGemmGroup];
-    bool wt;
-    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src, wt)) return rc;
+    unsigned fams;
+    if (int rc = gemm_plan(descs, n, g, lds, wg_total, src, fams)) return rc;
     if (g.n == 0 || wg_total == 0) return PCRL_OK;
-    if (wt) {
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_wt_kernel), 160 * 1024)) return rc;
-        hipLaunchKernelGGL(gemm_f32_wt_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
-        PCRL_CHECK_LAUNCH("gemm_f32_wt_kernel");
-    } else {
-        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_f32_kernel), kGemmLdsBytes)) return rc;
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3(wg_total), dim3(64 * kGemmWaves), lds, (hipStream_t)stream, g);
-        PCRL_CHECK_LAUNCH("gemm_f32_kernel");
-    }
+    const GemmVariant& v = gemm_variant(fams);
+    if (int rc = ensure_dynamic_lds(v.fn, 160 * 1024)) return rc;
+    void* args[] = {&g};
+    PCRL_CHECK_HIP(hipLaunchKernel(v.fn, dim3(wg_total), dim3(64 * kGemmWaves), args, lds, (hipStream_t)stream));
+    PCRL_CHECK_LAUNCH(v.name);
     return PCRL_OK;
 }
 
@@ -1098,7 +1139,7 @@ extern "C" int pcrl_gemm_group_plan_f32(const pcrl_gemm_desc* descs, int32_t n, 
     GemmGroup g;
     size_t lds;
     int wg_total, src[kGemmGroup];
-    bool wt;
+    unsigned wt;
     if (int rc = gemm_plan(descs, n, g, lds, wg_total, src, wt)) return rc;
     for (int i = 0; i < n; ++i) { out[3 * i] = -1; out[3 * i + 1] = 0; out[3 * i + 2] = 0; }
     for (int i = 0; i < g.n; ++i) { out[3 * src[i]] = g.p[i].cfg; out[3 * src[i] + 1] = g.p[i].shape; out[3 * src[i] + 2] = g.p[i].tiles; }

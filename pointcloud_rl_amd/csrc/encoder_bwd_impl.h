@@ -26,6 +26,7 @@
 //     fixed-order sum of the per-cloud partials -> one flat gradient buffer.  No float atomics:
 //     results are bit-reproducible run to run.
 #include <algorithm>
+#include <atomic>
 #include "encoder_common.h"
 
 // This file is compiled four times (encoder_bwd_{f32,bf16,split,f32_nw4}.hip define PCRL_BWD_MODE 0 / 1 / 2 / 3): each translation
@@ -1300,10 +1301,11 @@ extern "C" int pcrl_encoder_bwd_workspace_bytes(int32_t B, int32_t c_in, int32_t
 
 // pcrl_encoder_bwd_set_fused: 0 = the points / wgrad / reduce launches always, 1 (default) = the team kernel of encoder_bwd_fused.h for
 // launches of at most two tiles per CU (where it is faster: up to 64 clouds on 256 CUs), 2 = the team kernel wherever it is built
-static int g_bwd_fused = 1;
+// (process-wide, like pcrl_gemm_set_tile64_min: an atomic that every later launch of any host thread reads once)
+static std::atomic<int> g_bwd_fused{1};
 extern "C" int pcrl_encoder_bwd_set_fused(int32_t mode) {
     if (mode < 0 || mode > 2) return fail(PCRL_E_ARG, "pcrl_encoder_bwd_set_fused: mode 0, 1 or 2");
-    g_bwd_fused = mode;
+    g_bwd_fused.store(mode, std::memory_order_relaxed);
     return PCRL_OK;
 }
 
@@ -1378,7 +1380,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
             p.wgrows = reinterpret_cast<float*>(base + wg.wgrows); p.n_items = reinterpret_cast<int*>(base + wg.nitems);
             p.own_pack = reinterpret_cast<unsigned long long*>(base + wg.own_pack);
             p.srows = p.ops;          // the team kernel writes no operand pieces: their region holds the sparse rows of dW2
-            p.fused = g_bwd_fused; p.fused_rows = wg.fused_rows;
+            p.fused = g_bwd_fused.load(std::memory_order_relaxed); p.fused_rows = wg.fused_rows;
             p.schedule_out = &t_bwd_schedule; t_bwd_schedule = 2;
             p.w2 = w->w2;
             p.pw_stride = GL.total() + GramExtra{w->c2}.total();

@@ -20,6 +20,7 @@ class KernelTimer:
 
     def __init__(self):
         self.spans = {}
+        self.flops = {}            # name -> FLOPs issued under that span name (the GEMM launches count 2 M N K per problem)
 
     def span(self, name):
         return _Span(self, name)
@@ -382,6 +383,8 @@ def gemm_group(descs):
         return
     arr = (GemmDesc * len(descs))(*descs)
     name = "gemm " + " | ".join(f"M{d.M} N{d.N} K{d.K} b{d.batch}" for d in descs) if _SPAN_SHAPES else "gemm"
+    if TIMER is not None:
+        TIMER.flops["gemm"] = TIMER.flops.get("gemm", 0.0) + sum(2.0 * d.M * (d.ones_col if d.ones_col >= 0 else d.N) * d.K * max(d.batch, 1) for d in descs)
     with _span(name):
         check(lib().pcrl_gemm_group_f32(arr, len(descs), _stream()))
 

@@ -666,10 +666,16 @@ class SAC(BaseAgent):
                     # any other error of the step body (a kernel argument check, out of memory, an assertion) is a bug and is raised
                     if not _is_capture_error(err):
                         raise
+                    # ProcessGroupNCCL words a STICKY device fault (an illegal instruction, a memory fault) the same way
+                    # ("unhandled cuda error"): the fallback is only for a healthy context that refused the capture
+                    try:
+                        torch.cuda.synchronize()
+                    except RuntimeError as dead:
+                        raise RuntimeError(f"the device is in error after the failed capture ({str(dead).splitlines()[0]}): not a capture "
+                                           "refusal, no fallback") from err
                     import warnings
                     warnings.warn(f"capturing the gradient exchange failed ({str(err).splitlines()[0]}); cutting the step into segments instead")
                     os.environ["PCRL_CAPTURE_EXCHANGE"] = "0"
-                    torch.cuda.synchronize()
                     self._host_step_state(restore=host_state)    # the aborted capture ran the step body's host side once
             if captured is None:
                 captured = self._capture_segments(batch, do_actor, polyak, pre)
