@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=100)
     ap.add_argument("--extra-timeout", type=float, default=300.0, help="seconds the extra objects may take before the headline line is printed without them")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
+    ap.add_argument("--set-fused", action="append", default=[], metavar="ATTR=VALUE", help="analysis only: set an attribute of the fused step "
+                    "(methods/fused.py: e.g. publish_first=0) before the graphs are captured -- same-box A/B of a kept switch against its other arm")
     ap.add_argument("--start-lock", type=int, default=1, help="ranks SHARING one GPU (--dry-run-ranks / --share-gpu) bring their GPU context up one after "
                     "the other (a file lock around device initialisation, agent construction and the first synchronisation): eight processes "
                     "initialising one MI355X at the same moment die of HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in ~30 % of the launches, in torch's "
@@ -593,6 +595,12 @@ def main():
         from pointcloud_rl_amd.utils.torch_utils import to_torch
         memory.batch_np, memory.batch = shard, to_torch(shard, device=device)
     agent.train()
+    if args.set_fused:
+        agent._prepare()
+        for item in args.set_fused:
+            k, v = item.split("=", 1)
+            assert agent._fused is not None and hasattr(agent._fused, k), f"--set-fused: the fused step has no attribute {k}"
+            setattr(agent._fused, k, type(getattr(agent._fused, k))(int(v)) if isinstance(getattr(agent._fused, k), (bool, int)) else float(v))
     if not args.no_graphs:
         agent.enable_graphs()
 

@@ -287,6 +287,21 @@ int pcrl_adam_step_rider_f32(float* param, const float* grad, float* exp_avg, fl
                              float* target, size_t target_begin, size_t target_end, float tau,
                              void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
                              const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream);
+/* A step that publishes its metrics BEFORE its last optimizer pass (the host's turn-around to the next step then overlaps that pass):
+ *   pcrl_grad_norm_partials_f32  -- the pass's gradient-norm partial sums without the pass: same grid, element order and reduction tree as
+ *       pcrl_adam_step_f32, so the norm (module_utils.py:40-45) is bit for bit the one the pass would have reported; `pending` is filled as by
+ *       defer_finalize above and goes to pcrl_gather_scalars_f32, which forms the norm and ADVANCES the step count.  An optional rider (the
+ *       temperature: its whole Adam pass, sac.py:192-195, so that alpha = exp(log_alpha) is final before the metrics are gathered) runs in one
+ *       extra workgroup, its own `rider_pending` filled alike.
+ *   pcrl_adam_step_published_f32 -- the pass itself, launched AFTER that gather launch: reads *step_counter as already advanced (bias
+ *       corrections of step *step_counter), writes no partial sums and touches no counter.
+ * Parameters, moments and the Polyak target end up bit-identical to pcrl_adam_step_f32's. */
+int pcrl_grad_norm_partials_f32(const float* grad, size_t n, float grad_scale, int32_t* step_counter, float* grad_norm_out,
+                                void* workspace, size_t workspace_bytes, pcrl_adam_pending* pending,
+                                const pcrl_adam_rider* rider, pcrl_adam_pending* rider_pending, void* stream);
+int pcrl_adam_step_published_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                 float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* step_counter,
+                                 float* target, size_t target_begin, size_t target_end, float tau, void* stream);
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 

@@ -23,8 +23,9 @@ struct AdamParams {
     float* target;            // Polyak: target[i - t_begin] for t_begin <= i < t_end (may be NULL)
     long long t_begin, t_end;
     float tau;
-    float* partial;           // [gridDim.x] sum of (scaled) grad^2 per block
+    float* partial;           // [gridDim.x] sum of (scaled) grad^2 per block (NULL: the norm was taken by gradnorm_kernel before this pass)
     int main_blocks;          // blocks that sweep the buffer above; one more block (if any) does the rider
+    int step_add;             // 1: *step counts the steps BEFORE this one; 0: it has already been advanced (a pass published first)
 };
 
 // A second, tiny optimizer riding on the launch (SAC's temperature next to the actor: one float, its own betas, moments and
@@ -67,7 +68,7 @@ __device__ __forceinline__ void adam_rider_block(const AdamRider& r) {
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const AdamRider rider) {
     if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
-    const float step = (float)(p.step[0] + 1);
+    const float step = (float)(p.step[0] + p.step_add);
     const float bc1 = 1.0f - powf(p.beta1, step);
     const float bc2_sqrt = __builtin_sqrtf(1.0f - powf(p.beta2, step));
     const float step_size = p.lr / bc1;
@@ -108,7 +109,32 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const Ada
             }
         }
     }
+    if (!p.partial) return;    // (uniform over the launch)
     // block reduction of grad^2 in a fixed order (wave shuffle tree, then the 4 waves in order)
+    for (int off = 32; off > 0; off >>= 1) gsq += __shfl_down(gsq, off, 64);
+    __shared__ float s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// The gradient norm of a pass WITHOUT the pass: the same grid, the same per-thread element order and the same reduction tree as
+// adam_kernel, so the partial sums (and the norm the end-of-step launch forms from them) are bit for bit what the optimizer pass would
+// have produced.  Lets a step publish its metrics BEFORE its last optimizer launch (pcrl_grad_norm_partials_f32): 4 B per parameter read.
+struct GradNormParams { const float* grad; long long n; float grad_scale; float* partial; int main_blocks; };
+__global__ __launch_bounds__(256) void gradnorm_kernel(const GradNormParams p, const AdamRider rider) {
+    if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
+    float gsq = 0.0f;
+    const long long stride = (long long)p.main_blocks * blockDim.x * 4;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < p.n; i += stride) {
+        if (i + 3 < p.n) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.grad + i);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float g = g4[k] * p.grad_scale; gsq = __builtin_fmaf(g, g, gsq); }
+        } else {
+            for (long long j = i; j < p.n; ++j) { const float g = p.grad[j] * p.grad_scale; gsq = __builtin_fmaf(g, g, gsq); }
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) gsq += __shfl_down(gsq, off, 64);
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gsq;
@@ -159,9 +185,19 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
                        int32_t* step_counter, float* grad_norm_out,
                        float* target, size_t target_begin, size_t target_end, float tau,
                        void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
-                       const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream) {
+                       const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream, bool published = false) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return fail(PCRL_E_ARG, "NULL argument");
     if (n == 0) return PCRL_OK;
+    if (published) {
+        // the pass of a step whose norm and step count pcrl_grad_norm_partials_f32 + the gather launch have already taken care of
+        if (target && !(target_begin <= target_end && target_end <= n)) return fail(PCRL_E_ARG, "bad Polyak range");
+        const int grid = adam_grid((long long)n);
+        AdamParams p{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, grad_scale, step_counter,
+                     target, (long long)target_begin, (long long)target_end, tau, nullptr, grid, 0};
+        hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, AdamRider{});
+        PCRL_CHECK_LAUNCH("adam_kernel");
+        return PCRL_OK;
+    }
     if (target && !(target_begin <= target_end && target_end <= n)) return fail(PCRL_E_ARG, "bad Polyak range");
     const int grid = adam_grid((long long)n);
     if (!workspace || workspace_bytes < sizeof(float) * (size_t)grid) return fail(PCRL_E_WORKSPACE, "workspace too small");
@@ -174,7 +210,7 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
     }
     hipStream_t st = (hipStream_t)stream;
     AdamParams p{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, grad_scale, step_counter,
-                 target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace), grid};
+                 target, (long long)target_begin, (long long)target_end, tau, static_cast<float*>(workspace), grid, 1};
     hipLaunchKernelGGL(adam_kernel, dim3(grid + (rider ? 1 : 0)), dim3(256), 0, st, p, r);
     PCRL_CHECK_LAUNCH("adam_kernel");
     if (rider) {
@@ -214,6 +250,38 @@ extern "C" int pcrl_adam_step_rider_f32(float* param, const float* grad, float* 
     if (!rider) return fail(PCRL_E_ARG, "rider is NULL");
     return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, step_counter, grad_norm_out, target, target_begin,
                        target_end, tau, workspace, workspace_bytes, defer_finalize, rider, rider_defer, stream);
+}
+
+extern "C" int pcrl_grad_norm_partials_f32(const float* grad, size_t n, float grad_scale, int32_t* step_counter, float* grad_norm_out,
+                                           void* workspace, size_t workspace_bytes, pcrl_adam_pending* pending,
+                                           const pcrl_adam_rider* rider, pcrl_adam_pending* rider_pending, void* stream) {
+    if (!grad || !step_counter || !pending) return fail(PCRL_E_ARG, "NULL argument");
+    if (n == 0) return fail(PCRL_E_ARG, "pcrl_grad_norm_partials_f32: empty buffer");
+    const int grid = adam_grid((long long)n);
+    if (!workspace || workspace_bytes < sizeof(float) * (size_t)grid) return fail(PCRL_E_WORKSPACE, "workspace too small");
+    AdamRider r{};
+    if (rider) {
+        if (!rider->param || !rider->grad || !rider->exp_avg || !rider->exp_avg_sq || !rider->step_counter || !rider->partial || rider->n < 1 || rider->n > 4096 || !rider_pending)
+            return fail(PCRL_E_ARG, "adam rider: NULL argument or n outside [1, 4096]");
+        r = AdamRider{rider->param, rider->grad, rider->exp_avg, rider->exp_avg_sq, (long long)rider->n, rider->lr, rider->beta1, rider->beta2,
+                      rider->eps, rider->grad_scale, rider->step_counter, rider->partial};
+    }
+    GradNormParams p{grad, (long long)n, grad_scale, static_cast<float*>(workspace), grid};
+    hipLaunchKernelGGL(gradnorm_kernel, dim3(grid + (rider ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, p, r);
+    PCRL_CHECK_LAUNCH("gradnorm_kernel");
+    pending->partial = p.partial; pending->n_partial = grid; pending->grad_norm_out = grad_norm_out; pending->step_counter = step_counter;
+    if (rider) {
+        rider_pending->partial = rider->partial; rider_pending->n_partial = 1;
+        rider_pending->grad_norm_out = rider->grad_norm_out; rider_pending->step_counter = rider->step_counter;
+    }
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_adam_step_published_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                            float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* step_counter,
+                                            float* target, size_t target_begin, size_t target_end, float tau, void* stream) {
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_counter), nullptr, target,
+                       target_begin, target_end, tau, nullptr, 0, nullptr, nullptr, nullptr, stream, true);
 }
 
 extern "C" int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream) {

@@ -352,6 +352,39 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scal
     return pending
 
 
+def _rider_struct(rider):
+    return _lib.AdamRider(param=rider["param"].data_ptr(), grad=rider["grad"].data_ptr(), exp_avg=rider["exp_avg"].data_ptr(),
+                          exp_avg_sq=rider["exp_avg_sq"].data_ptr(), n=rider["param"].numel(), lr=rider["lr"], beta1=rider["beta1"],
+                          beta2=rider["beta2"], eps=rider["eps"], grad_scale=rider["grad_scale"], step_counter=rider["step_counter"].data_ptr(),
+                          grad_norm_out=rider["grad_norm_out"].data_ptr(), partial=rider["partial"].data_ptr())
+
+
+def grad_norm_partials(grad, grad_scale, step_counter, grad_norm_out, workspace, rider=None):
+    """include/pcrl.h: pcrl_grad_norm_partials_f32 -- an optimizer pass's gradient-norm partial sums WITHOUT the pass (bit for bit the
+    pass's own), so that the step can publish its metrics before that pass; returns the AdamPending for gather_scalars (which forms the
+    norm and advances the step count), or (pending, rider's pending) when a small optimizer (the temperature) rides on the launch."""
+    pending = _lib.AdamPending()
+    r = _rider_struct(rider) if rider is not None else None
+    r_pending = _lib.AdamPending() if rider is not None else None
+    with _span("grad_norm"):
+        check(lib().pcrl_grad_norm_partials_f32(_ptr(grad), ctypes.c_size_t(grad.numel()), ctypes.c_float(grad_scale), _ptr(step_counter),
+                                                _ptr(grad_norm_out), _ptr(workspace), ctypes.c_size_t(workspace.numel() * workspace.element_size()),
+                                                ctypes.byref(pending), ctypes.byref(r) if r is not None else None,
+                                                ctypes.byref(r_pending) if r is not None else None, _stream()))
+    return (pending, r_pending) if rider is not None else pending
+
+
+def adam_step_published(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, target=None, target_begin=0,
+                        target_end=0, tau=0.0):
+    """include/pcrl.h: pcrl_adam_step_published_f32 -- the optimizer pass of a step whose norm / step count went ahead of it
+    (grad_norm_partials + gather_scalars): reads the step count as already advanced."""
+    with _span("adam_step"):
+        check(lib().pcrl_adam_step_published_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
+                                                 ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                                 ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(target), ctypes.c_size_t(target_begin),
+                                                 ctypes.c_size_t(target_end), ctypes.c_float(tau), _stream()))
+
+
 def polyak(target, src, tau):
     check(lib().pcrl_polyak_f32(_ptr(target), _ptr(src), ctypes.c_size_t(target.numel()), ctypes.c_float(tau), _stream()))
 

@@ -217,6 +217,7 @@ class FusedStep:
         self.attach_colsum = True          # the step's leftover column sums ride on the encoder backward's reduce launch
         self.tail_bwd = True               # pcrl_policy_tail_bwd_f32: four launches of the actor's backward in one
         self.entry_pack = True             # the critic phase's re-pack rides on the replay's sampling launch
+        self.publish_first = True          # the metrics leave BEFORE the step's last optimizer pass (the host's turn-around overlaps it)
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
@@ -484,7 +485,17 @@ class FusedStep:
         enc.backward_raw(ctx_o, argmax_o, dpooled, fc.grad[:self.n_conv], prepared=prepared)
         scale = (yield ("finish", [fc.grad[:self.q_base]])) if exchanging else 1.0
         pending = []          # optimizer passes whose gradient norm / step count are finished by the end-of-step gather launch
-        stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
+        # The step's LAST optimizer pass goes behind the launch that publishes the metrics (a 4 B/parameter norm launch ahead of it instead):
+        # the host reads the metrics, returns and queues the next step while that pass still runs -- 12-14 us of idle device per step otherwise
+        # (profiles/r05_timeline_k1_b32.txt).  In a critic-only step that pass is the critic's, else the actor's.
+        last_pass = None
+        if self.publish_first and not do_actor:
+            split = a._optim_norm_first("critic", scale, pending)
+            if split is not None:
+                stats["critic_grad"], finish = split
+                last_pass = lambda: finish(polyak)
+        if last_pass is None:
+            stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
 
         # ---- actor + temperature (sac.py:161-205) --------------------------------------------------------
@@ -560,8 +571,14 @@ class FusedStep:
                                       d_act.data_ptr(), d_act.data_ptr() + 4 * Ma * ceil4(A), ceil4(A), self.d_nlp, dfeat, 2 * A)
                 mlp_backward(self.pi, XA_a, lda, Ma, p_h1, p_h2, dfeat, (2 * A, 1), 0, dp_h1, dp_h2, grad=fa.grad)
             scale = (yield ("finish", [a._actor_alpha_grad] if a.sync_alpha else [fa.grad])) if exchanging else 1.0
-            # the temperature (one float, its own betas / moments / step count) rides on the actor's optimizer launch
-            stats["actor_grad"] = a._optim_step("actor", scale, pending=pending, rider=("alpha", scale if a.sync_alpha else 1.0))
+            # the temperature (one float, its own betas / moments / step count) rides on the actor's optimizer launch -- or, with the
+            # actor's pass behind the metrics, on the norm launch ahead of them (alpha = exp(log_alpha) is one of the metrics)
+            split = a._optim_norm_first("actor", scale, pending, rider=("alpha", scale if a.sync_alpha else 1.0)) if self.publish_first else None
+            if split is not None:
+                stats["actor_grad"], finish_a = split
+                last_pass = lambda: finish_a(False)
+            else:
+                stats["actor_grad"] = a._optim_step("actor", scale, pending=pending, rider=("alpha", scale if a.sync_alpha else 1.0))
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
         # one launch gathers every reported scalar (and alpha = exp(log_alpha), sac.py:196) into one array
         names = list(stats.keys())
@@ -572,6 +589,8 @@ class FusedStep:
         if self.host_stats is None:
             self.host_stats = torch.zeros(32, dtype=torch.float32).pin_memory()
         hip.gather_scalars(entries, pending=pending, host_out=self.host_stats)
+        if last_pass is not None:
+            last_pass()
         packed = PackedStats((k, out[i]) for i, k in enumerate(names))
         packed.packed = out[:len(names)]
         packed.host = self.host_stats

@@ -158,6 +158,18 @@ class HipAdam(torch.optim.Optimizer):
                              g["eps"], grad_scale, self.step_counter, self.grad_norm, self.workspace,
                              target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau, defer=defer, rider=rider)
 
+    def norm_first(self, grad_scale=1.0, rider=None):
+        """First half of a pass that is published before it runs: the gradient norm's partial sums (and the rider's whole pass) now, the
+        pending half for hip.gather_scalars; `step_published` launches the pass itself after that gather launch."""
+        self.hyper()
+        return hip.grad_norm_partials(self.flat.grad, grad_scale, self.step_counter, self.grad_norm, self.workspace, rider=rider)
+
+    def step_published(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0):
+        g = self.param_groups[0]
+        self.hyper()
+        hip.adam_step_published(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                grad_scale, self.step_counter, target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau)
+
     def _views(self, flat_tensor):
         return self.flat.views(flat_tensor)
 
@@ -399,6 +411,33 @@ class SAC(BaseAgent):
         for enc in self._packed_owners.get(name, ()):
             enc.invalidate_packed()
         return fb.grad_norm_sq().sqrt()
+
+    def _optim_norm_first(self, name, scale, pending, rider=None):
+        """The step's LAST optimizer pass, split so that the metrics leave before it (csrc/optim.hip: gradnorm_kernel): its gradient norm's
+        partial sums (+ the temperature's whole pass as a rider) now; returns (norm tensor, finish) -- `finish()` launches the pass itself
+        and must be called right after the step's hip.gather_scalars.  None when this optimizer cannot be split (not the fused one)."""
+        opt = getattr(self, f"{name}_optim")
+        if not isinstance(opt, HipAdam) or pending is None:
+            return None
+        r_opt = getattr(self, f"{rider[0]}_optim") if rider is not None else None
+        if rider is not None and not (isinstance(r_opt, HipAdam) and self._flat[rider[0]].total <= 4096):
+            return None
+        if rider is not None:
+            pend, r_pend = opt.norm_first(scale, rider=r_opt.rider_args(rider[1]))
+            pending.append(r_pend)
+        else:
+            pend = opt.norm_first(scale)
+        pending.append(pend)
+        polyak = name == "critic"
+
+        def finish(do_polyak):
+            if do_polyak and polyak and self._target_flat is not None:
+                opt.step_published(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau)
+            else:
+                opt.step_published(scale)
+            for enc in self._packed_owners.get(name, ()):
+                enc.invalidate_packed()
+        return opt.grad_norm.reshape(()), finish
 
     def _encode(self, module_for_fallback, obs):
         """Visual feature of `obs` when the encoder is shared (else None: the module encodes itself)."""

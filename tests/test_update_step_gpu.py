@@ -417,6 +417,56 @@ def test_round4_launch_cuts_equal_the_launches_they_replace(cuda, monkeypatch, k
         assert (err <= 2e-6).float().mean() >= 0.999 and err.max() <= 2.1e-3, (n, float(err.max()))
 
 
+@pytest.mark.parametrize("graphs", [False, True], ids=["eager", "hipgraph"])
+def test_metrics_published_before_the_last_optimizer_pass_change_nothing(cuda, graphs):
+    """Round 6: the step's last optimizer pass runs BEHIND the launch that publishes the metrics (csrc/optim.hip: gradnorm_kernel takes the
+    pass's norm ahead of it, the temperature's pass rides there).  Same partial sums, same reduction tree, same bias corrections: every
+    metric of six updates (critic-only and actor steps alternate) and every parameter, moment and the target network are bit-identical
+    to the order of rounds 1-5, eager and replayed from the step's hipGraph."""
+    from pointcloud_rl_amd import configs
+    from pointcloud_rl_amd.methods import build_agent
+    from pointcloud_rl_amd.synthetic import SyntheticReplay
+    B, N, A = 8, 64, 6
+    g = torch.Generator().manual_seed(5)
+    eps = [[torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)] for _ in range(6)]
+
+    def run(first):
+        cfg = configs.sac_dmc(6, A, B, head_hidden=1024)
+        cfg["env_params"] = configs.env_params({"xyz": [3, N], "rgb": [3, N]}, A)
+        torch.manual_seed(0)
+        agent = build_agent(cfg).to(cuda)
+        agent._prepare()
+        agent._fused.publish_first = first
+        if graphs:
+            agent.enable_graphs()
+        mem = SyntheticReplay(B, N, A, seed=4, device=cuda)
+        rets = []
+        for u in range(1, 7):
+            if not graphs:
+                agent.actor.head.noise_override = [e.to(cuda) for e in eps[u - 1][:2 if u % 2 == 0 else 1]]
+            rets.append(agent.update_parameters(mem, u))
+        torch.cuda.synchronize()
+        return agent, rets
+
+    torch.manual_seed(11)
+    old, rets_o = run(False)
+    torch.manual_seed(11)
+    new, rets_n = run(True)
+    assert new._fused.publish_first and not old._fused.publish_first
+    for u, (ro, rn) in enumerate(zip(rets_o, rets_n)):
+        assert ro.keys() == rn.keys()
+        for k in ro:
+            assert ro[k] == rn[k] or (ro[k] != ro[k] and rn[k] != rn[k]), (u, k, ro[k], rn[k])
+    for (n, p), (_, q) in zip(old.named_parameters(), new.named_parameters()):
+        assert torch.equal(p, q), n
+    for (n, p), (_, q) in zip(old.target_critic.named_parameters(), new.target_critic.named_parameters()):
+        assert torch.equal(p, q), n
+    for name in ("critic", "actor", "alpha"):
+        a, b = getattr(old, f"{name}_optim"), getattr(new, f"{name}_optim")
+        assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq) and torch.equal(a.step_counter, b.step_counter), name
+        assert int(a.step_counter.item()) == (6 if name == "critic" else 3)
+
+
 def test_update_on_the_batch_the_reference_replay_container_produced(cuda):
     """tests/golden/ref_seam_batch_drq_maniskill.npz (tools/gen_golden_seam.py) is what the reference's ReplayMemory -> GDict.to_torch ->
     `agent._fetcher` handed to the step in the build container (configs/mfrl/drq/maniskill/pn_jitter.py: xyz f32, rgb u8, seg bool,
