@@ -1074,6 +1074,29 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
     }
     if (!force64 && tiles64 < tile64_min_tiles())
         for (int i = 0; i < g.n; ++i) use64[i] = false;
+    // TEMPORARY (round-6 planner experiments, removed once settled): PCRL_GEMM_EXP bit 0 = launch-level choice of the 64 x 64 staged
+    // tiles for forward-shaped problems, bit 1 = the 64 x 64 staged tiles for data-gradient-shaped problems of >= 256 rows
+    static const int exp_bits = []{ const char* e = getenv("PCRL_GEMM_EXP"); return e ? atoi(e) : 0; }();
+    bool exp64[kGemmGroup] = {false, false, false, false};
+    if (!legacy && !force64 && exp_bits) {
+        long long wt_wgs = 0, t64_tiles = 0;
+        bool all_ok = true;
+        for (int i = 0; i < g.n; ++i) {
+            if (!plan[i].kind_f) continue;
+            const pcrl_gemm_desc* d = dd[i];
+            int sh = 0;
+            long long wgs = 0;
+            for (; sh < 4; ++sh) { wgs = (long long)((d->M + wtile_tm(sh, 0) - 1) / wtile_tm(sh, 0)) * ((d->N + wtile_tn(sh, 0) - 1) / wtile_tn(sh, 0)) * d->batch; if (wgs <= cus) break; }
+            wt_wgs += wgs;
+            t64_tiles += (long long)((d->M + 63) / 64) * ((d->N + 63) / 64) * d->batch;
+            all_ok = all_ok && plan[i].t64_ok && d->M >= 64;
+        }
+        all_ok = all_ok && 4 * t64_tiles >= 3 * (long long)cus;
+        for (int i = 0; i < g.n; ++i) {
+            if ((exp_bits & 1) && plan[i].kind_f && all_ok && wt_wgs > cus) exp64[i] = true;
+            if ((exp_bits & 2) && plan[i].kind_x && plan[i].t64_ok && dd[i]->M >= 256) exp64[i] = true;
+        }
+    }
     int wg_total = 0;
     unsigned fams = 0;
     for (int i = 0; i < g.n; ++i) {
@@ -1081,7 +1104,9 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         GemmParams& p = g.p[i];
         int tm = 32, tn = 32, n_cols = d->N;
         const bool wt = !legacy && !force64 && (plan[i].kind_f || plan[i].kind_x);
-        if (wt) {
+        if (exp64[i]) {
+            p.cfg = 1; tm = tn = 64;
+        } else if (wt) {
             // the finest tile shape that still gives the chip at most one workgroup per CU (measured, tools/probes/gemm_staged.hip: a launch
             // is fastest with the largest number of workgroups <= #CUs); beyond the coarsest shape, the 64 x 64 staged tiles where they pay
             const int brc = plan[i].kind_x ? 1 : 0;

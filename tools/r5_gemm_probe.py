@@ -20,6 +20,8 @@ def shapes(torch, hip, dev):
             for K in (0, 32, 256, 1024):
                 yield f"fwd1 M{M} x{heads} K{K}", [hip.gemm_desc(h4, W4, t(heads, M, H), M, H, K, (H, 1), (1, H), H, relu=True, batch=heads,
                                                                  batch_strides=(M * H, H * H, M * H, 0, 0))]
+        two = [hip.gemm_desc(h4[2 * z:], W4[2 * z:], t(2, M, H), M, H, H, (H, 1), (1, H), H, relu=True, batch=2, batch_strides=(M * H, H * H, M * H, 0, 0)) for z in range(2)]
+        yield f"fwd1 M{M} 2p x2", two
         h, W1 = t(2, M, H), t(2, H, H)
         dW = hip.gemm_desc(h, h, t(2, H, H + 1), H, H + 1, M, (1, H), (H, 1), H + 1, ones_col=H, batch=2, batch_strides=(M * H, M * H, H * (H + 1), 0, 0))
         dX = hip.gemm_desc(h, W1, t(2, M, H), M, H, H, (H, 1), (H, 1), H, mask=h, ld_mask=H, batch=2, batch_strides=(M * H, H * H, M * H, 0, M * H))
@@ -52,7 +54,7 @@ def run(label_path):
 def fold(trace_dir, label_path):
     import csv, glob
     f = glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True)[0]
-    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "gemm_f32_" in r["Kernel_Name"]))
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "gemm_f" in r["Kernel_Name"]))
     labels = [l.split("\t") for l in open(label_path).read().strip().splitlines()]
     assert len(rows) == REPS * len(labels), (len(rows), len(labels))
     for i, (name, flops) in enumerate(labels):
