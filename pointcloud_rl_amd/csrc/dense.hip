@@ -725,8 +725,18 @@ __device__ __forceinline__ int gemm_find_problem(const GemmGroup& g, int wg) {
 
 // W = waves per SIMD the register allocation is made for (4: 128 registers, 2: 256).  The 32 x 64 data-gradient shape (wtx shape 3)
 // exists only where W == 2.
+#ifndef PCRL_GEMM_EU_EXACT
+#define PCRL_GEMM_EU_EXACT 1
+#endif
+#ifndef PCRL_GEMM_TABLE
+#define PCRL_GEMM_TABLE 0
+#endif
 template <unsigned FAM, int W>
+#if PCRL_GEMM_EU_EXACT
+__global__ __launch_bounds__(64 * kGemmWaves) __attribute__((amdgpu_waves_per_eu(W, W))) void gemm_fam_kernel(const GemmGroup g) {
+#else
 __global__ __launch_bounds__(64 * kGemmWaves, W) void gemm_fam_kernel(const GemmGroup g) {
+#endif
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     const int wg = blockIdx.x;
     const GemmParams p = g.p[gemm_find_problem(g, wg)];
@@ -770,18 +780,23 @@ __global__ __launch_bounds__(64 * kGemmWaves, W) void gemm_fam_kernel(const Gemm
 struct GemmVariant { unsigned fam; int waves; const void* fn; const char* name; };
 #define PCRL_GEMM_VARIANT(F, W) GemmVariant{F, W, reinterpret_cast<const void*>(&gemm_fam_kernel<F, W>), "gemm_fam_kernel<" #F "," #W ">"}
 static const GemmVariant kGemmVariants[] = {
+#if PCRL_GEMM_TABLE == 1      // the two kernels of round 5
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 4),
+    PCRL_GEMM_VARIANT(kFamAll, 4),
+#else
     PCRL_GEMM_VARIANT(kFamLegacy, 4),
-    PCRL_GEMM_VARIANT(kFamT64, 2),
-    PCRL_GEMM_VARIANT(kFamWt, 2),
+    PCRL_GEMM_VARIANT(kFamT64, 4),
+    PCRL_GEMM_VARIANT(kFamWt, 4),
     PCRL_GEMM_VARIANT(kFamWtx, 4),
     PCRL_GEMM_VARIANT(kFamPanel, 4),
     PCRL_GEMM_VARIANT(kFamPanel | kFamWtx, 4),                  // dW | dX of a 1 024-wide layer
     PCRL_GEMM_VARIANT(kFamLegacy | kFamWtx, 4),                 // dW0 | dX0 of the first layer
     PCRL_GEMM_VARIANT(kFamLegacy | kFamPanel | kFamWtx, 4),     // the policy's dW2 next to [dW1, dh1]
-    PCRL_GEMM_VARIANT(kFamLegacy | kFamWt, 2),                  // a first layer sharing the launch of a 1 024-wide one
-    PCRL_GEMM_VARIANT(kFamPanel | kFamT64, 2),                  // dW | dX at 1 024 rows and more
-    PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 2),
-    PCRL_GEMM_VARIANT(kFamAll, 2),                              // anything else
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamWt, 4),                  // a first layer sharing the launch of a 1 024-wide one
+    PCRL_GEMM_VARIANT(kFamPanel | kFamT64, 4),                  // dW | dX at 1 024 rows and more
+    PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 4),
+    PCRL_GEMM_VARIANT(kFamAll, 4),                              // anything else
+#endif
 };
 #undef PCRL_GEMM_VARIANT
 static const GemmVariant& gemm_variant(unsigned need) {
