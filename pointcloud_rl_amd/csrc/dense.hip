@@ -698,18 +698,19 @@ __host__ __device__ constexpr int wtile_tn(int shape, int brc) { return shape ==
 // cfg 5 panel shapes: 0 = 64 x 128 (no split-K), 1 = 64 x 64 (two k halves)
 __host__ __device__ constexpr int wpanel_tn(int shape) { return shape == 0 ? 128 : 64; }
 
-// One kernel per tile-path FAMILY (round 6).  Rounds 1-5 ran every launch through one of two kernels that held several paths behind a
-// run-time switch, compiled for 128 registers (`__launch_bounds__(512, 4)`): every path got the budget of the hungriest one -- the
-// LDS-staged 64 x 64 tiles, which want 162 registers and spilled 53 of them into their k loop, although their 136 KB of LDS leave room
-// for ONE workgroup per CU (2 waves per SIMD = 256 registers) whatever the register count.  A kernel is now instantiated per set of
-// families, with the register budget of that set: a launch takes the kernel of exactly the families its problems use (the table
-// below), so a family's code is compiled on its own -- no spilled register in any k loop (checked with
-// -Rpass-analysis=kernel-resource-usage: VGPRs spilled 0 for every variant but the catch-all).
-//   legacy : cfg 0 (32 x 32 split-K), cfg 2 / 3 (a tile per wave)            96 / 95 / 111 registers   -> 4 waves per SIMD
-//   t64    : cfg 1 (64 x 64 tiles staged through 136 KB of LDS)              162                       -> 2 (LDS-bound to one workgroup per CU anyway)
-//   wt     : cfg 4, B k-contiguous (forward): 16 x 16 ... 32 x 64            68 ... 136                -> 2 (80 - 120 KB of LDS: one workgroup per CU)
-//   wtx    : cfg 4, B contiguous along n (data gradient)                     60 ... 94 (32 x 64: 166)  -> 4 (40 - 80 KB of LDS); the 32 x 64 shape only in 2-wave variants
-//   panel  : cfg 5 (weight-gradient panels)                                  66 / 67                   -> 4
+// One kernel per set of tile-path FAMILIES (round 6).  Rounds 1-5 ran every launch through one of two kernels that held several paths
+// behind a run-time switch; a launch now takes the kernel instantiated for exactly the families its problems use (the table below), so a
+// family's code is compiled, register-allocated and fetched on its own.  -Rpass-analysis=kernel-resource-usage on this file:
+//   legacy : cfg 0 (32 x 32 split-K), cfg 2 / 3 (a tile per wave)            114 registers, 0 spilled
+//   wt     : cfg 4, B k-contiguous (forward): 16 x 16 ... 32 x 64            124, 0 spilled
+//   wtx    : cfg 4, B contiguous along n (data gradient)                      96, 0 spilled
+//   panel  : cfg 5 (weight-gradient panels)                                   68, 0 spilled
+//   t64    : cfg 1 (64 x 64 tiles staged through 68 KB of LDS)               128, 51 spilled -- kept ON PURPOSE: 68 KB of LDS lets TWO
+//            workgroups share a CU, which needs <= 128 registers; the spill-free 162-register build runs one workgroup per CU and measured
+//            13 % slower where the path matters (four heads at 1 024 rows: 81.3 -> 92.2 us, tools/r6_gemm_exp.sh, same box).  The scratch
+//            traffic sits in the data- / weight-gradient orientations (55 / 26 scratch instructions per 32 MFMAs of their k loops); the
+//            forward orientation's loop has 3.
+// Every family is compiled for 4 waves per SIMD (128 registers) -- see amdgpu_waves_per_eu below.
 constexpr unsigned kFamLegacy = 1u, kFamT64 = 2u, kFamWt = 4u, kFamWtx = 8u, kFamPanel = 16u, kFamAll = 31u;
 __host__ __device__ constexpr unsigned gemm_family(int cfg, int b_rc) {
     return cfg == 1 ? kFamT64 : cfg == 4 ? (b_rc ? kFamWtx : kFamWt) : cfg == 5 ? kFamPanel : kFamLegacy;
@@ -723,20 +724,13 @@ __device__ __forceinline__ int gemm_find_problem(const GemmGroup& g, int wg) {
     return gi;
 }
 
-// W = waves per SIMD the register allocation is made for (4: 128 registers, 2: 256).  The 32 x 64 data-gradient shape (wtx shape 3)
-// exists only where W == 2.
-#ifndef PCRL_GEMM_EU_EXACT
-#define PCRL_GEMM_EU_EXACT 1
-#endif
-#ifndef PCRL_GEMM_TABLE
-#define PCRL_GEMM_TABLE 0
-#endif
+// W = waves per SIMD the register allocation is made for (4: 128 registers, 2: 256; every instantiated variant uses 4).  A 32 x 64
+// data-gradient shape (wtx shape 3: 166 registers) exists only where W == 2 and is not planned for.
+// amdgpu_waves_per_eu(W, W) -- minimum AND maximum: with only the minimum (`__launch_bounds__(512, 4)`) the scheduler of a kernel that needs
+// 96 registers aims at the NEXT occupancy step and shortens its load rings for it (measured: the grouped dW | dX launch 27.4 -> 30.2 us);
+// the union kernels of round 5 were pinned at 128 registers by their hungriest path and never showed it.
 template <unsigned FAM, int W>
-#if PCRL_GEMM_EU_EXACT
 __global__ __launch_bounds__(64 * kGemmWaves) __attribute__((amdgpu_waves_per_eu(W, W))) void gemm_fam_kernel(const GemmGroup g) {
-#else
-__global__ __launch_bounds__(64 * kGemmWaves, W) void gemm_fam_kernel(const GemmGroup g) {
-#endif
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
     const int wg = blockIdx.x;
     const GemmParams p = g.p[gemm_find_problem(g, wg)];
@@ -780,10 +774,6 @@ __global__ __launch_bounds__(64 * kGemmWaves, W) void gemm_fam_kernel(const Gemm
 struct GemmVariant { unsigned fam; int waves; const void* fn; const char* name; };
 #define PCRL_GEMM_VARIANT(F, W) GemmVariant{F, W, reinterpret_cast<const void*>(&gemm_fam_kernel<F, W>), "gemm_fam_kernel<" #F "," #W ">"}
 static const GemmVariant kGemmVariants[] = {
-#if PCRL_GEMM_TABLE == 1      // the two kernels of round 5
-    PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 4),
-    PCRL_GEMM_VARIANT(kFamAll, 4),
-#else
     PCRL_GEMM_VARIANT(kFamLegacy, 4),
     PCRL_GEMM_VARIANT(kFamT64, 4),
     PCRL_GEMM_VARIANT(kFamWt, 4),
@@ -796,7 +786,6 @@ static const GemmVariant kGemmVariants[] = {
     PCRL_GEMM_VARIANT(kFamPanel | kFamT64, 4),                  // dW | dX at 1 024 rows and more
     PCRL_GEMM_VARIANT(kFamLegacy | kFamT64, 4),
     PCRL_GEMM_VARIANT(kFamAll, 4),                              // anything else
-#endif
 };
 #undef PCRL_GEMM_VARIANT
 static const GemmVariant& gemm_variant(unsigned need) {
@@ -1089,28 +1078,31 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
     }
     if (!force64 && tiles64 < tile64_min_tiles())
         for (int i = 0; i < g.n; ++i) use64[i] = false;
-    // TEMPORARY (round-6 planner experiments, removed once settled): PCRL_GEMM_EXP bit 0 = launch-level choice of the 64 x 64 staged
-    // tiles for forward-shaped problems, bit 1 = the 64 x 64 staged tiles for data-gradient-shaped problems of >= 256 rows
-    static const int exp_bits = []{ const char* e = getenv("PCRL_GEMM_EXP"); return e ? atoi(e) : 0; }();
-    bool exp64[kGemmGroup] = {false, false, false, false};
-    if (!legacy && !force64 && exp_bits) {
+    // Launch-level choice for the forward-shaped problems (round 6): the per-problem rule below picks, for each problem on its own, the
+    // finest wave-tile shape with at most one workgroup per CU -- two such problems in one launch (the target and the online Q heads'
+    // second layer at 256 rows: 2 x 256 workgroups of 32 x 64 outputs, 120 KB of LDS each) then run as two rounds.  When the launch's
+    // forward-shaped problems together exceed one round of wave tiles AND form at least 3/4 of a round of 64 x 64 staged tiles, they take
+    // those instead: one round, half the prologues / split-K reductions per FLOP (same box: 29.3 -> 25.2 us for that launch, K1's step
+    // -3.5 us; at 128 rows the 64 x 64 tiles would leave half the chip idle and the wave tiles stay).
+    bool launch64[kGemmGroup] = {false, false, false, false};
+    if (!legacy && !force64) {
         long long wt_wgs = 0, t64_tiles = 0;
         bool all_ok = true;
         for (int i = 0; i < g.n; ++i) {
             if (!plan[i].kind_f) continue;
             const pcrl_gemm_desc* d = dd[i];
-            int sh = 0;
             long long wgs = 0;
-            for (; sh < 4; ++sh) { wgs = (long long)((d->M + wtile_tm(sh, 0) - 1) / wtile_tm(sh, 0)) * ((d->N + wtile_tn(sh, 0) - 1) / wtile_tn(sh, 0)) * d->batch; if (wgs <= cus) break; }
+            for (int sh = 0; sh < wtile_shapes(0); ++sh) {
+                wgs = (long long)((d->M + wtile_tm(sh, 0) - 1) / wtile_tm(sh, 0)) * ((d->N + wtile_tn(sh, 0) - 1) / wtile_tn(sh, 0)) * d->batch;
+                if (wgs <= cus) break;
+            }
             wt_wgs += wgs;
             t64_tiles += (long long)((d->M + 63) / 64) * ((d->N + 63) / 64) * d->batch;
-            all_ok = all_ok && plan[i].t64_ok && d->M >= 64;
+            all_ok = all_ok && plan[i].t64_ok;
         }
-        all_ok = all_ok && 4 * t64_tiles >= 3 * (long long)cus;
-        for (int i = 0; i < g.n; ++i) {
-            if ((exp_bits & 1) && plan[i].kind_f && all_ok && wt_wgs > cus) exp64[i] = true;
-            if ((exp_bits & 2) && plan[i].kind_x && plan[i].t64_ok && dd[i]->M >= 256) exp64[i] = true;
-        }
+        if (all_ok && wt_wgs > cus && 4 * t64_tiles >= 3 * (long long)cus)
+            for (int i = 0; i < g.n; ++i)       // (a small neighbour -- fewer than a quarter round of 64 x 64 tiles -- keeps its wave tiles)
+                launch64[i] = plan[i].kind_f && 4LL * ((dd[i]->M + 63) / 64) * ((dd[i]->N + 63) / 64) * dd[i]->batch >= cus;
     }
     int wg_total = 0;
     unsigned fams = 0;
@@ -1119,7 +1111,7 @@ static int gemm_plan(const pcrl_gemm_desc* descs, int32_t n, GemmGroup& g, size_
         GemmParams& p = g.p[i];
         int tm = 32, tn = 32, n_cols = d->N;
         const bool wt = !legacy && !force64 && (plan[i].kind_f || plan[i].kind_x);
-        if (exp64[i]) {
+        if (launch64[i]) {
             p.cfg = 1; tm = tn = 64;
         } else if (wt) {
             // the finest tile shape that still gives the chip at most one workgroup per CU (measured, tools/probes/gemm_staged.hip: a launch

@@ -63,6 +63,18 @@ def test_the_finest_shape_with_at_most_one_workgroup_per_cu():
     assert plan([dgrad(256, 50, 1024, 2)]) == [(4, 0, 128)]            # the first layer's data gradient: 50 of the 56 input columns
 
 
+def test_two_forward_problems_of_one_launch_are_planned_together():
+    # the target and the online Q heads' second layer: each alone is one round of 32 x 64 wave tiles, together two -- one round of 64 x 64
+    # staged tiles instead (round 6); at 128 rows those would leave half the chip idle and the wave tiles stay
+    assert plan([fwd(256, 1024, 1024, 2), fwd(256, 1024, 1024, 2)]) == [(1, 0, 128), (1, 0, 128)]
+    assert plan([fwd(128, 1024, 1024, 2), fwd(128, 1024, 1024, 2)]) == [(4, 2, 256), (4, 2, 256)]
+    assert plan([fwd(256, 1024, 1024, 2)]) == [(4, 3, 256)]                                  # one problem, one round: unchanged
+    # a short first layer in the same launch keeps its own path and does not count
+    assert plan([fwd(256, 1024, 1024, 1), fwd(256, 1024, 56, 2)])[0] == (4, 2, 256)
+    # the weight / data gradient pair is not forward-shaped: unchanged
+    assert plan([wgrad(1024, 1024, 256, 2), dgrad(256, 1024, 1024, 2)]) == [(5, 0, 256), (4, 2, 512)]
+
+
 def test_weight_gradient_panels_and_their_fallbacks():
     assert plan([wgrad(1024, 1024, 256, 2)]) == [(5, 0, 256)]          # 64 x 128 panels: one per CU
     assert plan([wgrad(1024, 1024, 256, 1)]) == [(5, 1, 256)]          # 64 x 64

@@ -1,5 +1,7 @@
 #!/bin/bash
-# One GPU-box visit: GPU test suite, the headline bench line, a kernel-trace profile of the same command.
+# One GPU-box visit that ENDS a round: the library is rebuilt from the tree's sources, the whole `-m gpu` suite runs on exactly that binary
+# (kernel parity first, launcher rehearsals last: tests/conftest.py), and the binary's sha256 is written next to the log -- no csrc/ commit
+# may follow this log.  Then the headline bench line and a kernel-trace profile of the same command.
 #   tools/gpu_round.sh <tag> [workloads...]     (run through gpurun from the repo root; writes gpurun_out/<tag>/)
 set -u
 TAG=${1:-run}; shift || true
@@ -7,8 +9,12 @@ WLS=${@:-k1}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+make -C pointcloud_rl_amd/csrc > $OUT/make.log 2>&1; echo "make rc=$? ($(grep -c hipcc $OUT/make.log) compile/link commands: 1 = only the link check, the shipped objects were current)"
+sha256sum pointcloud_rl_amd/libpcrl_hip.so | tee $OUT/libpcrl_hip.sha256
+git -C . rev-parse HEAD 2>/dev/null | tee $OUT/head.txt || true
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -5 $OUT/pytest.log
+echo "library the suite ran on: $(cat $OUT/libpcrl_hip.sha256)" >> $OUT/pytest.log
 for wl in $WLS; do
   steps=2000; warm=500
   [ "$wl" = "k3" ] && { steps=400; warm=100; }
