@@ -58,6 +58,14 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def gemm_source_sha():
+    """Hash of the sources the head GEMM kernels are compiled from; tags profiles/*_gemm_matrix_busy.json."""
+    h = hashlib.sha256()
+    for name in ("dense.hip", "dense_wtile.h", "common.h"):
+        h.update(open(os.path.join(ROOT, "pointcloud_rl_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,8 +262,10 @@ def gemm_roofline(timer, steps_timed):
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_matrix_busy.json")))
     if cands:
         bj = json.load(open(cands[-1]))
-        if bj.get("kernel_source_sha") == kernel_source_sha():
+        if bj.get("kernel_source_sha") == gemm_source_sha():
             busy, busy_src = bj.get("matrix_busy"), os.path.relpath(cands[-1], ROOT)
+        else:
+            busy_src = f"{os.path.relpath(cands[-1], ROOT)} is stale (other kernel sources): not reported"
     return {"kernel": "gemm_fam_kernel<families, waves>", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
             "launches_per_step": n / max(steps_timed, 1), "us_per_step": total_ms * 1e3 / max(steps_timed, 1), "gflop_per_step": flops / 1e9 / max(steps_timed, 1),
             "matrix_busy": busy, "matrix_busy_source": busy_src, "timed_with": "HIP events on the launch stream, eager pass"}
