@@ -203,17 +203,27 @@ def feature_dim(agent):
     return fm[0].out_features if fm is not None else agent.encoder.mlp_spec[-1]
 
 
-def active_points_per_cloud(agent):
-    """Points per cloud the encoder backward of the last eager step actually visited: the distinct argmax positions of the gradient-carrying
-    pass (what the backward's prep launch counts into its bitmap), read from the step's own argmax tensor; None when the step kept none."""
-    am = getattr(getattr(agent, "_fused", None), "last_argmax", None)
+def active_points_per_cloud(agent, tiles=False):
+    """Points per cloud the encoder backward of the last eager step actually visited: the distinct argmax positions of the LIVE channels
+    (pooled value > 0: the backward's prep launch drops the others) of the gradient-carrying pass, read from the step's own tensors; None
+    when the step kept none.  tiles=True: (mean points per cloud, total 32-point tiles = sum over the clouds of ceil(points / 32))."""
+    fused = getattr(agent, "_fused", None)
+    am, pooled = getattr(fused, "last_argmax", None), getattr(fused, "last_pooled", None)
     if am is None or am.numel() == 0:
-        return None
-    srt = am.reshape(am.shape[0], -1).sort(dim=1).values
-    return float(((srt[:, 1:] != srt[:, :-1]).sum(1) + 1).float().mean().item())
+        return (None, None) if tiles else None
+    am = am.reshape(am.shape[0], -1).long()
+    if pooled is not None and pooled.shape == am.shape:
+        am = torch.where(pooled > 0, am, torch.full_like(am, 1 << 40))       # dead channels: one sentinel position, subtracted below
+        srt = am.sort(dim=1).values
+        n = (srt[:, 1:] != srt[:, :-1]).sum(1) + 1 - (srt[:, -1] == (1 << 40)).long()
+    else:
+        srt = am.sort(dim=1).values
+        n = (srt[:, 1:] != srt[:, :-1]).sum(1) + 1
+    mean = float(n.float().mean().item())
+    return (mean, int(((n + 31) // 32).sum().item())) if tiles else mean
 
 
-def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, head_hidden=1024, feat=None, active_pts=None):
+def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, head_hidden=1024, feat=None, active_pts=None, bwd_tiles=None):
     """Whole-step figure next to the dominant kernel's.  `frac` = EXECUTED FLOPs / step time / the dense MFMA peak of the encoder's
     arithmetic (<= 1 by construction); `useful_tflops` = SURVEY.md section 8(d)'s CANONICAL FLOPs (dense backward: 4.5 point-passes per
     point, heads (2.5 F_a + 11 F_q) per sample) / step time -- the rate of useful work, which exceeds the executed rate because the
@@ -238,6 +248,7 @@ def step_roofline(wl, C, spec, b_global, num_aug, A, S, ms_per_step, is_bf16, he
     bwd = b_global * num_aug * (n_act * f_bwd_pt + 6.0 * c2 * c3)
     executed = fwd + heads + bwd
     return {"executed_gflop_per_step": executed / 1e9, "achieved": executed * per_s, "unit": "TFLOP/s", "peak": peak, "frac": executed * per_s / peak,
+            "backward_tiles_per_rank": bwd_tiles, "backward_wave_slots": 4 * 256,
             "active_points_per_cloud": n_act, "active_points_source": "distinct argmax positions of the step's gradient-carrying pass" if active_pts is not None
             else "upper bound c3 (not measured on this run)",
             "encoder_fwd_gflop": fwd / 1e9, "encoder_bwd_gflop": bwd / 1e9, "heads_gflop": heads / 1e9,
@@ -341,7 +352,7 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
             out["roofline_gemm"] = g
     out["step"] = step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], out["ms_per_step"],
                                 getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent),
-                                active_pts=active_points_per_cloud(agent) if roofline else None)
+                                **(dict(zip(("active_pts", "bwd_tiles"), active_points_per_cloud(agent, tiles=True))) if roofline else {}))
     if cpu_steps and rank == 0:
         points = wl["B"] * wl["N"] * getattr(agent, "num_aug", 1)
         out["cpu_baseline"] = cpu_baseline(agent, wl, cpu_steps, cpu_threads, sample_batch=wl["B"] if points <= 300_000 else max(8, int(wl["B"] * 300_000 / points)),
@@ -710,7 +721,8 @@ def main():
                        "hip_graphs": graphed, "device_warmup_seconds": args.device_warmup_seconds, "replay": args.replay + (f" ring of {args.replay_capacity} transitions, B sampled per step" if args.replay == "device" else " batch")},
             "roofline": roof,
             "step": step_roofline(wl, C, agent.encoder.mlp_spec, wl["B"], getattr(agent, "num_aug", 1), wl["A"], wl["S"], elapsed / args.steps * 1e3,
-                                  getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent), active_pts=active_points_per_cloud(agent)),
+                                  getattr(agent.encoder, "compute_dtype", "f32") == "bf16", feat=feature_dim(agent),
+                                  **dict(zip(("active_pts", "bwd_tiles"), active_points_per_cloud(agent, tiles=True)))),
             "roofline_gemm": gemm_roofline(timer, steps_timed),
             "kernels_ms": {k: dict({"launches": n, "avg_ms": ms}, **span_detail.get(k, {})) for k, (n, ms) in spans.items()},
         }

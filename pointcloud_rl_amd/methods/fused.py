@@ -403,6 +403,7 @@ class FusedStep:
             head_o, ((xhat, rstd),) = self._feature_jobs([job_o(0)])
             pooled_o, argmax_o, ctx_o = enc.encode_raw(vis_o, head=head_o)
         self.last_argmax = argmax_o          # read by the parity tests (first-index argmax of the gradient-carrying pass)
+        self.last_pooled = pooled_o          # (with it: which channels are live -- bench.py counts the backward's active points and tiles)
         if fold_c:
             hip.pack_flush_cols()            # (a phase whose weights needed no re-pack: the gather as a launch of its own)
         prepared = self._fork_prepare(enc, ctx_o, argmax_o)
