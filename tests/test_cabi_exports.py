@@ -82,6 +82,26 @@ def test_binding_loads_torch_before_the_library():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+def test_launch_tracer_marks_every_entry_point(tmp_path):
+    """PCRL_TRACE_LAUNCHES=<dir> (pointcloud_rl_amd/_lib.py::_TracedLib): `> name` before and `< name rc` after every pcrl_* call, one file per
+    process, written unbuffered -- what names the launch in flight of a rank that dies of an asynchronous GPU fault (round 6: the 8-rank
+    rehearsal).  Host-only entry points here: no GPU."""
+    import subprocess
+    import sys
+    code = ("import ctypes; from pointcloud_rl_amd import _lib; l = _lib.lib(); assert l.pcrl_version() == 100; n = ctypes.c_size_t(); "
+            "assert l.pcrl_adam_workspace_bytes(ctypes.c_size_t(5000), ctypes.byref(n)) == 0 and n.value > 0; "
+            "assert l.pcrl_encoder_bwd_set_fused(7) != 0; assert b'mode' in l.pcrl_last_error(); print('ok')")
+    env = dict(os.environ, PCRL_TRACE_LAUNCHES=str(tmp_path), PCRL_TRACE_SYNC="0", RANK="3")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    files = list(tmp_path.glob("rank3_pid*.trace"))
+    assert len(files) == 1, list(tmp_path.iterdir())
+    lines = files[0].read_text().splitlines()
+    assert lines[:4] == ["> pcrl_version", "< pcrl_version 100", "> pcrl_adam_workspace_bytes", "< pcrl_adam_workspace_bytes 0"], lines
+    assert lines[4] == "> pcrl_encoder_bwd_set_fused" and lines[5].startswith("< pcrl_encoder_bwd_set_fused -"), lines      # pcrl_last_error is not traced
+    assert len(lines) == 6
+
+
 _ORDER_PROBE = """
 import ctypes, json, os, sys
 sys.path.insert(0, {root!r})
