@@ -541,6 +541,10 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if os.environ.get("PCRL_BENCH_DUMP_AFTER_S"):
+        # debugging a launch that does not come back: every thread's Python stack of THIS process to stderr after so many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PCRL_BENCH_DUMP_AFTER_S"]), exit=False)
     if args.dry_run_ranks:
         args.gpus, args.backend, args.share_gpu = args.dry_run_ranks, "gloo", True
     wl = dict(WORKLOADS[args.workload])

@@ -401,7 +401,13 @@ def test_bench_dry_run_of_the_eight_rank_launch(cuda):
     gc.collect()
     torch.cuda.empty_cache()                       # eight more processes are about to share this GPU with the test process
     t0 = time.time()
-    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420, env=env)
+    env["PCRL_BENCH_DUMP_AFTER_S"] = "240"         # a launch that does not come back says where every rank (and the launcher) stands
+    try:
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420, env=env)
+    except subprocess.TimeoutExpired as hang:
+        err = hang.stderr.decode(errors="replace") if isinstance(hang.stderr, bytes) else (hang.stderr or "")
+        keep = [l for l in err.splitlines() if "amdgpu.ids" not in l and "socket.cpp" not in l]
+        raise AssertionError("the rehearsal did not come back within 420 s; stderr (stacks after 240 s):\n" + "\n".join(keep)[-12000:]) from None
     took = time.time() - t0
     # (the ranks' stderr is interleaved: on failure show the first lines that name an error, not just the tail -- the tail is the peers
     # noticing that one rank is gone)
