@@ -33,7 +33,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from pointcloud_rl_amd.utils import dist as pdist      # collectives that know about ranks sharing one device (DeviceGate)
 
 WORKLOADS = {
     # name: (B, N, pcd channels extras, action_dim, agent_dim, config builder)
@@ -104,11 +103,10 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="seconds the launcher (plain `python bench.py --gpus N`) waits for its ranks")
     ap.add_argument("--set-fused", action="append", default=[], metavar="ATTR=VALUE", help="analysis only: set an attribute of the fused step "
                     "(methods/fused.py: e.g. publish_first=0) before the graphs are captured -- same-box A/B of a kept switch against its other arm")
-    ap.add_argument("--start-lock", type=int, default=1, help="ranks SHARING one GPU (--dry-run-ranks / --share-gpu) take turns on it: a rank holds a "
-                    "file lock (pointcloud_rl_amd/utils/dist.py: DeviceGate) whenever it has work on the device and gives it up, drained, around every "
-                    "collective, which then run on host copies.  Eight processes co-running on one MI355X lose a rank to HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION "
-                    "in ~26 %% of the launches -- in the victim's start-up work, before it has launched a kernel of this library "
-                    "(profiles/r06_dry_run_loop.md); 0 = off.  Real multi-GPU runs (one device per rank) never take the gate")
+    ap.add_argument("--start-lock", type=int, default=1, help="ranks SHARING one GPU (--dry-run-ranks / --share-gpu) bring their GPU context up one after "
+                    "the other (a file lock around device initialisation, agent construction and the first synchronisation) -- next to "
+                    "HSA_ENABLE_SDMA=0, which is what removes the multi-process fault of the rehearsal (profiles/r06_dry_run_loop.md); 0 = off. "
+                    "Real multi-GPU runs (one device per rank) take neither")
     ap.add_argument("--dry-run-ranks", type=int, default=0, help="rehearsal of the multi-GPU run on a ONE-GPU box: the launcher starts this many ranks "
                     "exactly as `--gpus N` does (rendezvous on 127.0.0.1, to_ddp's broadcast, the sharded replay rings, the data-parallel step "
                     "schedule, the comm / no-comm timing, the extra workloads behind their watchdog, rank 0's line last on stdout), but the ranks "
@@ -302,7 +300,7 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
 
     def sync():
         if dist_on:
-            pdist.barrier()
+            torch.distributed.barrier()
         torch.cuda.synchronize()
     u = 0
     for _ in range(warmup):
@@ -322,7 +320,7 @@ def side_rate(name, rank, world, device, dist_on, steps, warmup, encoder_dtype=N
     dt = time.perf_counter() - t0
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
-        pdist.all_reduce_(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     out = {"value": steps / dt, "unit": "gradient steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "global_batch": wl["B"], "batch_per_gpu": b_rank, "points": wl["N"], "n_gpus": world, "scaling": "strong",
@@ -489,6 +487,8 @@ def launch_ranks(args):
         base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                     HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **extra_env)
         base.setdefault("OMP_NUM_THREADS", "1")
+        if args.share_gpu or args.dry_run_ranks:
+            base.setdefault("HSA_ENABLE_SDMA", "0")       # ranks sharing one device: see main()
         base.setdefault("PCRL_STEP_TIMEOUT_S", "90")          # a step that publishes no metrics for 90 s ends its rank (and so the attempt)
         procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
                                   stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)) for r in range(n)]
@@ -547,6 +547,13 @@ def main():
         faulthandler.dump_traceback_later(float(os.environ["PCRL_BENCH_DUMP_AFTER_S"]), exit=False)
     if args.dry_run_ranks:
         args.gpus, args.backend, args.share_gpu = args.dry_run_ranks, "gloo", True
+    if args.share_gpu:
+        # Ranks that SHARE one device copy through the compute queues, not the SDMA engines (read by the HIP runtime when it initialises,
+        # i.e. below: nothing has touched the device yet).  With the engines, eight processes on one MI355X lose a rank to
+        # HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in 18 of 70 launches -- the victim is inside a host-to-device copy of its start-up, it has not
+        # launched a kernel of this library -- and hang in a pageable copy when the collectives are staged through host memory; without
+        # them 0 of 30 unlocked launches fail (profiles/r06_dry_run_loop.md).  A real multi-GPU run (a device per rank) keeps the engines.
+        os.environ.setdefault("HSA_ENABLE_SDMA", "0")
     wl = dict(WORKLOADS[args.workload])
     if not args.replay_capacity:
         args.replay_capacity = wl.get("capacity", 2048)
@@ -584,16 +591,19 @@ def main():
 
     from pointcloud_rl_amd import hip
     from pointcloud_rl_amd.synthetic import SyntheticReplay
-    device_gate = None
+    start_lock = None
     if lock_start:
-        # Ranks that SHARE the device take turns on it (pointcloud_rl_amd/utils/dist.py: DeviceGate): from here on this rank holds the gate
-        # whenever it has work on the device and gives it up, drained, around every collective (which then run on host copies).  The
-        # rendezvous above is gloo's, on the host.
-        os.environ["PCRL_SHARED_DEVICE_GATE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pcrl_bench_gate_{os.environ.get('MASTER_PORT', '0')}.lock")
-        device_gate = pdist.gate()
-        device_gate.acquire()
+        # (the rendezvous above is gloo's, on the host; from here to the first synchronisation one rank at a time touches the device)
+        import fcntl
+        start_lock = open(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"pcrl_bench_start_{os.environ.get('MASTER_PORT', '0')}.lock"), "w")
+        fcntl.flock(start_lock, fcntl.LOCK_EX)
         torch.cuda.set_device(local_rank)
     agent, C = build_agent(wl, b_rank, device, args.encoder_dtype)
+    if start_lock is not None:
+        torch.zeros(1 << 16, device=device).add_(1.0).sum().item()      # torch's first fill / elementwise / reduction kernels and the first copy back
+        torch.cuda.synchronize()
+        fcntl.flock(start_lock, fcntl.LOCK_UN)
+        start_lock.close()
     if dist_on:
         agent.to_ddp(device_ids=["cuda"])                 # broadcasts rank 0's weights (as DDP's constructor does) and turns the exchange on
     if args.replay == "device":
@@ -629,7 +639,7 @@ def main():
 
     def sync():
         if dist_on:
-            pdist.barrier()
+            torch.distributed.barrier()
         torch.cuda.synchronize()
 
     updates = 0
@@ -702,7 +712,7 @@ def main():
     timer, hip.TIMER = hip.TIMER, None
     if dist_on:
         t = torch.tensor([elapsed, nocomm_ms], device=device, dtype=torch.float64)
-        pdist.all_reduce_(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed, nocomm_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
@@ -733,7 +743,8 @@ def main():
             out["comm_ms_per_step"] = elapsed / args.steps * 1e3 - nocomm_ms
         if args.dry_run_ranks:
             out["dry_run"] = (f"{world} ranks sharing cuda:0 over gloo (host-side all-reduces): a rehearsal of launcher, rendezvous, to_ddp, the "
-                              "data-parallel schedule and the extras -- not a measurement")
+                              "data-parallel schedule and the extras -- not a measurement; HSA_ENABLE_SDMA=" + os.environ.get("HSA_ENABLE_SDMA", "unset")
+                              + (", contexts brought up one after the other" if lock_start else ""))
         if dist_on and world == 1:
             out["debug"] = f"single-rank exchange over backend {args.backend}: data-parallel schedule with a one-rank process group"
         if not dist_on and not args.no_cpu_baseline:
@@ -765,7 +776,7 @@ def main():
             print(json.dumps(d), flush=True)
         os._exit(0)
     if dist_on:
-        pdist.barrier()        # every rank starts its watchdog at the same point
+        torch.distributed.barrier()        # every rank starts its watchdog at the same point
     timer_x = threading.Timer(args.extra_timeout, give_up)
     timer_x.daemon = True
     timer_x.start()
@@ -791,10 +802,8 @@ def main():
         if extras:
             out.update(extras)
             line = json.dumps(out)
-    if device_gate is not None:
-        device_gate.release()              # drained: the last turn of this rank
     if dist_on:
-        pdist.barrier()
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
         # The JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio, which a pipe buffers

@@ -144,107 +144,12 @@ def quiesce_before_capture():
     time.sleep(0.35)
 
 
-class DeviceGate:
-    """Ranks that SHARE one device take turns on it.  Only for the one-GPU REHEARSAL of a multi-GPU launch (bench.py --dry-run-ranks /
-    --share-gpu sets PCRL_SHARED_DEVICE_GATE to a lock file): eight processes co-running on one MI355X intermittently lose one of them
-    to a queue abort in the platform's multi-process path (HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in a rank's start-up work; 18 of 70
-    launches, profiles/r06_dry_run_loop.md), which the run being rehearsed -- one device per rank -- cannot meet.  With the gate a rank
-    holds an exclusive file lock whenever it has work on the device and gives it up, drained, around every collective; the
-    collectives themselves run on host copies (gloo on CPU tensors: no device work outside a turn).  Launcher, rendezvous, sharding,
-    to_ddp, the exchange points of the step schedule, watchdogs and the result line are exercised as before; concurrency on the device
-    and gloo's device-tensor staging (never part of an RCCL run) are not.  Re-entrant within a process."""
-
-    def __init__(self, path):
-        self._file = open(path, "a+")
-        self._depth = 0
-
-    def acquire(self):
-        if self._depth == 0:
-            import fcntl
-            fcntl.flock(self._file, fcntl.LOCK_EX)
-        self._depth += 1
-
-    def release(self):
-        assert self._depth > 0
-        self._depth -= 1
-        if self._depth == 0:
-            self._unlock()
-
-    def _unlock(self):
-        import fcntl
-        import torch
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
-            torch.cuda.synchronize()                  # nothing of this rank is left on the device when the next one takes its turn
-        fcntl.flock(self._file, fcntl.LOCK_UN)
-
-    def yielded(self):
-        """Context: the turn is given up (whatever the nesting depth) for the duration of a host-side collective."""
-        return _Yielded(self)
-
-
-class _Yielded:
-    def __init__(self, g):
-        self.g = g
-
-    def __enter__(self):
-        self.depth, self.g._depth = self.g._depth, 0
-        if self.depth:
-            self.g._unlock()
-
-    def __exit__(self, *exc):
-        if self.depth:
-            import fcntl
-            fcntl.flock(self.g._file, fcntl.LOCK_EX)
-        self.g._depth = self.depth
-
-
-_GATE = None
-
-
-def gate():
-    """The process's DeviceGate when PCRL_SHARED_DEVICE_GATE names a lock file (ranks sharing one device), else None."""
-    global _GATE
-    path = os.environ.get("PCRL_SHARED_DEVICE_GATE")
-    if not path:
-        return None
-    if _GATE is None:
-        _GATE = DeviceGate(path)
-    return _GATE
-
-
-def barrier():
-    g = gate()
-    if g is None:
-        return dist.barrier()
-    with g.yielded():
-        dist.barrier()
-
-
-def all_reduce_(tensor, op=None):
-    """dist.all_reduce in place; under a DeviceGate through a host copy, the turn given up while the ranks meet."""
-    op = dist.ReduceOp.SUM if op is None else op
-    g = gate()
-    if g is None or not tensor.is_cuda:
-        if g is None:
-            return dist.all_reduce(tensor, op=op)
-        with g.yielded():
-            return dist.all_reduce(tensor, op=op)
-    g.acquire()
-    try:
-        host = tensor.detach().to("cpu")
-        with g.yielded():
-            dist.all_reduce(host, op=op)
-        tensor.copy_(host)
-    finally:
-        g.release()
-
-
 def allreduce_sum_(flat_grad, enabled=True):
     """In-place SUM all-reduce of a flat gradient buffer.  Returns the scale (1/world) the caller must
     apply to obtain the mean, 1.0 when nothing was exchanged."""
     if not enabled or not exchange_active():
         return 1.0
-    all_reduce_(flat_grad, op=dist.ReduceOp.SUM)
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / world_size()
 
 
@@ -263,9 +168,6 @@ class Exchange:
 
     def start(self, flat_piece):
         if self.enabled:
-            if gate() is not None:                    # ranks sharing a device (rehearsal): a blocking exchange on a host copy, no overlap
-                all_reduce_(flat_piece, op=dist.ReduceOp.SUM)
-                return
             self.pending.append(dist.all_reduce(flat_piece, op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
@@ -279,22 +181,10 @@ def broadcast_parameters_(module, src=0):
     """Make every rank start from rank `src`'s weights (what DDP's constructor does implicitly)."""
     if not exchange_active():
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
-    g = gate()
-    if g is not None:                                 # ranks sharing a device (rehearsal): host copies travel, the device sees one rank at a time
-        g.acquire()
-        try:
-            hosts = [t.detach().to("cpu") for t in tensors]
-            with g.yielded():
-                for h in hosts:
-                    dist.broadcast(h, src)
-            for t, h in zip(tensors, hosts):
-                t.copy_(h)
-        finally:
-            g.release()
-        return
-    for t in tensors:
-        dist.broadcast(t, src)
+    for p in module.parameters():
+        dist.broadcast(p.data, src)
+    for b in module.buffers():
+        dist.broadcast(b.data, src)
 
 
 def shard_slice(global_batch, rank, world):

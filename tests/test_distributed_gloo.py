@@ -92,65 +92,3 @@ def test_to_ddp_broadcasts_rank0_weights_like_ddp_does():
     assert not torch.equal(b0, b1)                            # different seeds: different replicas before
     assert torch.equal(a0, b0)                                # rank 0 keeps its weights
     assert torch.equal(a1, a0) and torch.equal(t1, t0)        # every parameter (incl. target critic, log_alpha) now rank 0's
-
-
-def _gate_worker(rank, world, port, gate_path, log_path, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PCRL_SHARED_DEVICE_GATE=gate_path)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import time
-    from pointcloud_rl_amd.utils import dist as pdist
-    from pointcloud_rl_amd.utils.dist import Exchange, broadcast_parameters_
-    g = pdist.gate()
-    assert g is not None and pdist.gate() is g
-    fd = os.open(log_path, os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
-    g.acquire()                                   # bench.py holds its turn from start-up to the end, nested acquires inside
-    torch.manual_seed(rank)
-    net = torch.nn.Linear(4, 3)
-    broadcast_parameters_(net)                    # (CPU tensors here: the gate is given up around the collective, taken back after it)
-    total = torch.zeros(3)
-    for step in range(6):
-        g.acquire()
-        os.write(fd, f"enter {rank}\n".encode())  # "device work" of this rank's turn: no other rank may be inside its own
-        time.sleep(0.01)
-        os.write(fd, f"exit {rank}\n".encode())
-        t = torch.full((3,), float(rank + 1 + step))
-        ex = Exchange()
-        ex.start(t)                               # a blocking exchange under the gate
-        assert ex.finish() == 1.0 / world and not ex.pending
-        total += t
-        pdist.barrier()
-        g.release()
-    m = torch.tensor([float(rank)])
-    pdist.all_reduce_(m, op=dist.ReduceOp.MAX)
-    g.release()
-    assert g._depth == 0
-    out[rank] = (net.weight.detach().clone(), total, float(m))
-    pdist.barrier()                               # without holding the gate: nothing to give up
-    dist.destroy_process_group()
-
-
-def test_ranks_sharing_a_device_take_turns_and_still_meet_in_their_collectives(tmp_path):
-    """utils/dist.py::DeviceGate (bench.py --dry-run-ranks: eight ranks on ONE GPU): a rank holds an exclusive file lock whenever it has work
-    on the device and gives it up around every collective -- turns never overlap, no rank waits in a collective while it holds the gate
-    (no deadlock), broadcast / exchange / barrier / all-reduce give what the ungated ones give."""
-    world, port = 3, _free_port()
-    mgr = mp.Manager()
-    out = mgr.dict()
-    log = tmp_path / "turns.log"
-    mp.spawn(_gate_worker, args=(world, port, str(tmp_path / "gate.lock"), str(log), out), nprocs=world, join=True)
-    w = [out[r][0] for r in range(world)]
-    assert all(torch.equal(w[0], x) for x in w)                          # rank 0's weights everywhere
-    want = sum(torch.full((3,), float(sum(r + 1 + s for r in range(world)))) for s in range(6))
-    assert all(torch.equal(out[r][1], want) for r in range(world))       # SUM over the ranks, every step
-    assert all(out[r][2] == float(world - 1) for r in range(world))
-    inside = None
-    lines = log.read_text().split("\n")[:-1]
-    assert len(lines) == 2 * 6 * world
-    for l in lines:                                                        # turns never overlap
-        kind, r = l.split()
-        if kind == "enter":
-            assert inside is None, lines
-            inside = r
-        else:
-            assert inside == r, lines
-            inside = None
