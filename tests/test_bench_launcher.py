@@ -43,6 +43,30 @@ def test_a_rank_sees_the_launchers_rendezvous_variables(tmp_path):
     assert seen[0][4] == seen[1][4] and int(seen[0][4]) > 1024
 
 
+def test_ranks_that_share_a_device_run_without_the_sdma_engines(tmp_path):
+    """Round 6 (profiles/r06_dry_run_loop.md): eight processes on ONE device trip over the platform's SDMA copy-engine path (a rank lost to
+    HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION in 18 of 70 launches, 0 of 30 with the engines off) -- the rehearsal's ranks are started with
+    HSA_ENABLE_SDMA=0, the ranks of a real multi-GPU launch (a device and its engines each) are not, and a caller's own setting is kept."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the rehearsal itself is the test (tests/test_data_parallel_gpu.py)")
+    hook = tmp_path / "sitecustomize.py"
+    hook.write_text(
+        "import os, sys\n"
+        "if os.environ.get('WORLD_SIZE') and sys.argv and sys.argv[0].endswith('bench.py'):\n"
+        "    open(os.path.join(os.environ['PCRL_TEST_DIR'], 'rank' + os.environ['RANK']), 'w').write(os.environ.get('HSA_ENABLE_SDMA', 'unset'))\n")
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_SDMA")}
+    for name, argv, extra, want in (("rehearsal", ["--dry-run-ranks", "2"], {}, "0"), ("real", ["--gpus", "2"], {}, "unset"),
+                                    ("share", ["--gpus", "2", "--share-gpu", "--backend", "gloo"], {}, "0"),
+                                    ("kept", ["--dry-run-ranks", "2"], {"HSA_ENABLE_SDMA": "1"}, "1")):
+        d = tmp_path / name
+        d.mkdir()
+        env = dict(base, PYTHONPATH=str(tmp_path) + os.pathsep + base.get("PYTHONPATH", ""), PCRL_TEST_DIR=str(d), **extra)
+        subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert sorted((d / f"rank{r}").read_text() for r in range(2)) == [want, want], name
+
+
 def test_the_launcher_retries_only_on_the_dedicated_signal(tmp_path):
     """A failed first attempt is repeated with PCRL_CAPTURE_EXCHANGE=0 ONLY when a rank left with RC_EXCHANGE_IN_GRAPH (the step's
     captured all-reduces failed while replaying); an ordinary failure (here: no GPU -> SystemExit, rc 1) is reported once, with no
