@@ -365,3 +365,29 @@ def test_tstep_index_blocks_reproduce_the_reference_sampler():
             assert blocks.shape == want.shape[:2] and np.array_equal(mask, d[f"{tag}/sample{s_}/is_valid"]), (tag, s_)
             assert np.array_equal(ring[blocks], want), (tag, s_)
 
+
+
+def test_bench_counts_the_backward_s_active_points_and_tiles_from_the_step_s_own_tensors():
+    """bench.py::active_points_per_cloud (the `step` object's active_points_per_cloud / backward_tiles_per_rank): distinct argmax positions of
+    the LIVE channels (pooled > 0) per cloud, and the 32-point tiles they make -- what the backward's prep launch builds its lists from."""
+    import types
+    import bench
+    am = torch.tensor([[0, 0, 5, 5, 9, 40, 40, 41],          # cloud 0: positions {0, 5, 9, 40, 41}; channel 1 (position 0) dead, channel 4 (9) dead
+                       [3, 3, 3, 3, 3, 3, 3, 3],             # cloud 1: one point
+                       [0, 1, 2, 3, 4, 5, 6, 7]], dtype=torch.int32)           # cloud 2: eight points, all channels dead but two
+    pooled = torch.tensor([[1.0, 0.0, 2.0, 0.5, 0.0, 1.0, 1.0, 3.0],
+                           [1.0] * 8,
+                           [0.0, 0.0, 0.0, 4.0, 0.0, 0.0, 0.0, 0.1]])
+    agent = types.SimpleNamespace(_fused=types.SimpleNamespace(last_argmax=am, last_pooled=pooled))
+    mean, tiles = bench.active_points_per_cloud(agent, tiles=True)
+    # live positions: cloud 0 -> {0, 5, 40, 41} = 4, cloud 1 -> {3} = 1, cloud 2 -> {3, 7} = 2
+    assert abs(mean - (4 + 1 + 2) / 3) < 1e-6 and tiles == 3
+    assert abs(bench.active_points_per_cloud(agent) - mean) < 1e-9
+    agent._fused.last_pooled = None                           # without the pooled values: every channel counts
+    assert abs(bench.active_points_per_cloud(agent) - (5 + 1 + 8) / 3) < 1e-6
+    big = torch.arange(40, dtype=torch.int32).repeat(2, 1)    # 40 distinct points per cloud -> two tiles each
+    agent = types.SimpleNamespace(_fused=types.SimpleNamespace(last_argmax=big, last_pooled=torch.ones(2, 40)))
+    assert bench.active_points_per_cloud(agent, tiles=True) == (40.0, 4)
+    assert bench.active_points_per_cloud(types.SimpleNamespace(_fused=None), tiles=True) == (None, None)
+    s = bench.step_roofline(bench.WORKLOADS["k1"], 6, [64, 128, 256], 256, 1, 6, 0, 0.81, False, feat=50, active_pts=118.0, bwd_tiles=1075)
+    assert 0.45 < s["frac"] < 0.6 and s["frac"] <= 1.0 and 0.78 < s["useful_frac"] < 0.88 and s["backward_tiles_per_rank"] == 1075
