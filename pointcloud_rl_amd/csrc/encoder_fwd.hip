@@ -227,6 +227,23 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
     const unsigned lane16 = 16u * (unsigned)lane;
     const f32x4* s_w2v = reinterpret_cast<const f32x4*>(s_w2);
     const f32x4* s_w1v = reinterpret_cast<const f32x4*>(s_w1);
+    // [r6] The conv1 / conv2 operand reads of the exact fp32 path address the 24 + 128 KB of LDS images as (lane's 16 bytes) + a compile-time
+    // offset of up to 160 KB, and a DS instruction carries 16 bits of it.  Left to itself the compiler formed ~10 base registers for the
+    // reads of one tile and, at 256 registers, SPILLED them: 12 scratch reloads inside conv2's MFMA stream, each in front of the
+    // ds_read_b128 it feeds.  Three explicit window bases (lane16 + 0 / 64 KB / 128 KB), the upper two hidden from the optimiser, cover
+    // everything: every read is base register + immediate.
+    typedef __attribute__((address_space(3))) const f32x4 lds_f4;
+    const unsigned lds_w0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem) + lane16;
+    unsigned lds_w1 = lds_w0 + 65536u, lds_w2 = lds_w0 + 131072u;
+    asm volatile("" : "+v"(lds_w1), "+v"(lds_w2));
+    constexpr unsigned kW1Off = (unsigned)(sizeof(ChanSrc) * PCRL_MAX_CHANNELS + sizeof(unsigned long long) * C3 +
+                                           sizeof(float) * (2 * C2 + 2 * C3 + C1 + MB1 * T0 * 64));
+    constexpr unsigned kW2Off = kW1Off + (unsigned)sizeof(float) * W1L * 32 * C1;
+    auto lds_image = [&](unsigned byte) -> f32x4 {       // `byte` is a constant after unrolling: the window select folds away
+        const unsigned win = byte >> 16, imm = byte & 0xFFFFu;
+        const unsigned base = win == 0 ? lds_w0 : win == 1 ? lds_w1 : lds_w2;
+        return *(lds_f4*)(unsigned long)(base + imm);
+    };
 
     // SUBSAMPLE with a count decided on the device (CloudParams::n_ptr): positions [n_pts, N) do not exist in this call -- their tiles are
     // skipped, and the lanes of the last live tile past n_pts hold copies of point n_pts - 1, exactly like the lanes past N of a ragged cloud
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                 // (the L2-fed row blocks' operand ring is pinned: left to the scheduler every load sank to just in front of its wait)
                 dense_layer_mfma_stream<MB2, C1 / 8, PCRL_FWD_RING>(
                     a1, [&](int mb, int tq) {
-                        return mb < W1L ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane]
+                        return mb < W1L ? ((BF16 || SPLIT) ? s_w1v[(mb * (C1 / 8) + tq) * 64 + lane] : lds_image(kW1Off + 1024u * (unsigned)(mb * (C1 / 8) + tq)))
                                         : buf_load_f4(r_packed, lane16, 4u * (unsigned)(L.w1() + (mb * (C1 / 8) + tq) * 256)); },
                     [&](int t) { return a0[t >> 4][t & 15]; });
             PCRL_FSTAMP(2);
@@ -313,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void encoder_fwd_kernel(const FwdParams p) 
                     [&](int t) { return a1[t >> 4][t & 15]; });
             else
                 dense_layer_mfma<MB3, C2 / 8, 2>(
-                    a2, [&](int mb, int tq) { return s_w2v[(mb * (C2 / 8) + tq) * 64 + lane]; },
+                    a2, [&](int mb, int tq) { return lds_image(kW2Off + 1024u * (unsigned)(mb * (C2 / 8) + tq)); },
                     [&](int t) { return a1[t >> 4][t & 15]; });
             PCRL_FSTAMP(4);
 #ifdef PCRL_FWD_ABLATE_TAIL
