@@ -225,6 +225,14 @@ int pcrl_encoder_bwd_prepared_f32(const pcrl_cloud_desc* clouds, const pcrl_aug_
                                   const int32_t* argmax, const float* grad_pooled, const float* pooled,
                                   float* grads, int32_t* n_active,
                                   void* workspace, size_t workspace_bytes, void* stream);
+/* A row-wise LayerNorm backward (the arguments of pcrl_layernorm_rows_bwd_partials_f32 below: PointNet.final_mlp[1], pointnet.py:110) handed
+ * over to the NEXT pcrl_encoder_bwd_prepare_f32 / pcrl_encoder_bwd_* call of this host thread: it runs as extra workgroups of that call's prep
+ * launch -- which reads nothing the LayerNorm backward writes and writes nothing it reads -- instead of as a launch of its own (one graph node
+ * fewer per update step); where the call launches no such prep kernel (round-2 kernels, the wide last layer, B = 0) it is launched on its
+ * own in front of everything.  Bit-identical results either way.  (NULL dy0 with M = 0 drops a pending job.) */
+int pcrl_encoder_bwd_attach_ln_bwd(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                   const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                   void* workspace, size_t workspace_bytes);
 /* Which kernels the Gram-form backward above launches for mlp_spec = [64 | 128, 128, 256] in exact fp32 (and for the bf16 mode's backward,
  * which runs them too).  mode 1 (default): launches of at most two 32-point tiles per CU (up to 64 clouds on 256 CUs: the per-GPU shares of
  * a data-parallel batch) take the team kernel of csrc/encoder_bwd_fused.h -- the per-point chain and the weight-gradient sums in one

@@ -207,6 +207,54 @@ __host__ __device__ inline float u01_to_range(uint32_t w, float lo, float hi) {
     return lo + (float)(w >> 8) * (1.0f / 16777216.0f) * (hi - lo);
 }
 
+// ---- backward of a row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1]), four rows per 256-thread block: dx and the per-block
+// partial sums of dgamma / dbeta.  One block function, two hosts: layernorm_rows_bwd_kernel (csrc/dense.hip) and -- riding on the encoder
+// backward's prep launch, which needs nothing it writes (pcrl_encoder_bwd_attach_ln_bwd) -- encoder_bwdg_prep_kernel. ------------------------
+struct LnBwdParams {
+    const float* dy0; const float* dy1; long long lddy;   // dy1 may be NULL
+    const float* xhat; const float* rstd; const float* gamma;
+    int M, F;
+    float* dx; long long lddx;
+    float* part;             // [blocks][2][F] partial sums of dy*xhat and dy
+};
+// s_acc: 4 * 2 * 256 floats of LDS; blk = which group of four rows; tid in [0, 256)
+__device__ __forceinline__ void layernorm_rows_bwd_block(const LnBwdParams& p, int blk, int tid, float* s_acc) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int row = blk * 4 + wave;
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < p.M) {
+        float dxh[4], xh[4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = lane + 64 * j;
+            dxh[j] = xh[j] = 0.0f;
+            if (f < p.F) {
+                float dy = p.dy0[(long long)row * p.lddy + f];
+                if (p.dy1) dy += p.dy1[(long long)row * p.lddy + f];
+                xh[j] = p.xhat[(long long)row * p.F + f];
+                dg[j] = dy * xh[j]; db[j] = dy;
+                dxh[j] = dy * p.gamma[f];
+                s1 += dxh[j]; s2 += dxh[j] * xh[j];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+        const float m1 = s1 / (float)p.F, m2 = s2 / (float)p.F, rstd = p.rstd[row];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = lane + 64 * j;
+            if (f < p.F) p.dx[(long long)row * p.lddx + f] = rstd * ((dxh[j] - m1) - xh[j] * m2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_acc[(wave * 2 + 0) * 256 + lane + 64 * j] = dg[j]; s_acc[(wave * 2 + 1) * 256 + lane + 64 * j] = db[j]; }
+    __syncthreads();
+    const int f = tid;
+    if (f < p.F) {
+        p.part[((long long)blk * 2 + 0) * p.F + f] = (s_acc[(0 * 2 + 0) * 256 + f] + s_acc[(1 * 2 + 0) * 256 + f]) + (s_acc[(2 * 2 + 0) * 256 + f] + s_acc[(3 * 2 + 0) * 256 + f]);
+        p.part[((long long)blk * 2 + 1) * p.F + f] = (s_acc[(0 * 2 + 1) * 256 + f] + s_acc[(1 * 2 + 1) * 256 + f]) + (s_acc[(2 * 2 + 1) * 256 + f] + s_acc[(3 * 2 + 1) * 256 + f]);
+    }
+}
+
 // ---- fixed-order column reductions of per-workgroup partials (pcrl_colsum_jobs_f32; also riding on the encoder backward's reduce
 // launch, pcrl_encoder_bwd_attach_colsum) ----------------------------------------------------------------------------------------
 constexpr int kColsumJobs = 12;

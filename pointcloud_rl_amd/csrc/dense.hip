@@ -863,50 +863,9 @@ __global__ __launch_bounds__(256) void layernorm_rows_fwd_kernel(const LnParams 
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)), dxhat = dy * gamma, where dy is the
 // sum of up to two upstream gradients (one per Q head); per-block partial dgamma / dbeta.
-struct LnBwdParams {
-    const float* dy0; const float* dy1; long long lddy;   // dy1 may be NULL
-    const float* xhat; const float* rstd; const float* gamma;
-    int M, F;
-    float* dx; long long lddx;
-    float* part;             // [gridDim.x][2][F] partial sums of dy*xhat and dy
-};
-
 __global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const LnBwdParams p) {
-    __shared__ float s_acc[4][2][256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + wave;
-    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row < p.M) {
-        float dxh[4], xh[4], s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = lane + 64 * j;
-            dxh[j] = xh[j] = 0.0f;
-            if (f < p.F) {
-                float dy = p.dy0[(long long)row * p.lddy + f];
-                if (p.dy1) dy += p.dy1[(long long)row * p.lddy + f];
-                xh[j] = p.xhat[(long long)row * p.F + f];
-                dg[j] = dy * xh[j]; db[j] = dy;
-                dxh[j] = dy * p.gamma[f];
-                s1 += dxh[j]; s2 += dxh[j] * xh[j];
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-        const float m1 = s1 / (float)p.F, m2 = s2 / (float)p.F, rstd = p.rstd[row];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = lane + 64 * j;
-            if (f < p.F) p.dx[(long long)row * p.lddx + f] = rstd * ((dxh[j] - m1) - xh[j] * m2);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s_acc[wave][0][lane + 64 * j] = dg[j]; s_acc[wave][1][lane + 64 * j] = db[j]; }
-    __syncthreads();
-    const int f = threadIdx.x;
-    if (f < p.F) {
-        p.part[((long long)blockIdx.x * 2 + 0) * p.F + f] = (s_acc[0][0][f] + s_acc[1][0][f]) + (s_acc[2][0][f] + s_acc[3][0][f]);
-        p.part[((long long)blockIdx.x * 2 + 1) * p.F + f] = (s_acc[0][1][f] + s_acc[1][1][f]) + (s_acc[2][1][f] + s_acc[3][1][f]);
-    }
+    __shared__ float s_acc[4 * 2 * 256];
+    layernorm_rows_bwd_block(p, (int)blockIdx.x, (int)threadIdx.x, s_acc);
 }
 
 __global__ void colsum_partials_kernel(const float* part, int nblk, int n, float* out0, float* out1, int half, int accumulate) {

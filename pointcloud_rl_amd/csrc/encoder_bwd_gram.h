@@ -166,6 +166,10 @@ __global__ __launch_bounds__(256) void encoder_bwdg_prep_kernel(const BwdParams 
     __shared__ __attribute__((aligned(4))) unsigned char s_slot[kC3];
     __shared__ int s_lastpc;
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= p.cl.B + (kC2 / 16) * (kC2 / 16)) {      // a LayerNorm backward riding on this launch (pcrl_encoder_bwd_attach_ln_bwd)
+        layernorm_rows_bwd_block(p.ln, (int)blockIdx.x - p.cl.B - (kC2 / 16) * (kC2 / 16), tid, reinterpret_cast<float*>(s_words));
+        return;
+    }
     if ((int)blockIdx.x >= p.cl.B) {          // the blocks behind the clouds build the Gram image
         gram_tile<kC2, kC3>(p.w2, p.mimg, (int)blockIdx.x - p.cl.B, tid, reinterpret_cast<float*>(s_words));
         return;
@@ -1276,7 +1280,8 @@ static int launch_bwdg(const BwdParams& p, hipStream_t stream) {
         auto prep = encoder_bwdg_prep_kernel<C1, C2, C3>;
         if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(prep), 2 * sizeof(unsigned) * (size_t)kBitmapMaxWords)) return rc;
         const size_t prep_lds = std::max(2 * sizeof(unsigned) * (size_t)nW, (size_t)kGramTileLds);
-        hipLaunchKernelGGL(prep, dim3(p.cl.B + (C2 / 16) * (C2 / 16)), dim3(256), prep_lds, stream, p);   // behind the clouds: the Gram image's 16 x 16 tiles
+        // behind the clouds: the Gram image's 16 x 16 tiles, then the workgroups of an attached LayerNorm backward (8 KB of the same LDS)
+        hipLaunchKernelGGL(prep, dim3(p.cl.B + (C2 / 16) * (C2 / 16) + p.ln_blocks), dim3(256), prep_lds, stream, p);
         PCRL_BWDG_AFTER("encoder_bwdg_prep_kernel");
     }
     if (p.phase == 1) return PCRL_OK;

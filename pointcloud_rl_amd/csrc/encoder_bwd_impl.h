@@ -111,6 +111,10 @@ struct BwdParams {
     // column-sum jobs riding on the reduce launch (pcrl_encoder_bwd_attach_colsum): cs_blocks extra workgroups behind its own
     ColsumParams cs;
     int cs_blocks;
+    // a row-wise LayerNorm backward riding on the PREP launch (pcrl_encoder_bwd_attach_ln_bwd): ln_blocks extra workgroups behind the clouds'
+    // and the Gram image's (the feature head's LayerNorm: the prep launch needs nothing it writes, and nothing it reads is written by prep)
+    LnBwdParams ln;
+    int ln_blocks;
 };
 
 // LayerNorm statistics in the forward's canonical order; `a` becomes xhat = (a - mean) * rstd.
@@ -1327,6 +1331,29 @@ extern "C" int pcrl_encoder_bwd_attach_colsum(const pcrl_colsum_job* jobs, int32
     return PCRL_OK;
 }
 
+// pcrl_encoder_bwd_attach_ln_bwd: a LayerNorm backward handed over for the NEXT prep launch of this host thread
+static thread_local LnBwdParams t_ln_job;
+static thread_local size_t t_ln_ws_bytes = 0;
+static thread_local bool t_ln_on = false;
+
+extern "C" int pcrl_encoder_bwd_attach_ln_bwd(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                              const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                              void* workspace, size_t workspace_bytes) {
+    if (!dy0 && M == 0) { t_ln_on = false; return PCRL_OK; }
+    if (!dy0 || !xhat || !rstd || !gamma || !dx) return fail(PCRL_E_ARG, "NULL argument");
+    if (F < 1 || F > 256 || M < 1) return fail(PCRL_E_ARG, "LayerNorm rows: 1 <= F <= 256, M >= 1");
+    const size_t need = sizeof(float) * (size_t)((M + 3) / 4) * 2 * F;
+    if (!workspace || workspace_bytes < need) return fail(PCRL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+    t_ln_job = LnBwdParams{dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, static_cast<float*>(workspace)};
+    t_ln_ws_bytes = workspace_bytes;
+    t_ln_on = true;
+    return PCRL_OK;
+}
+
+extern "C" int pcrl_layernorm_rows_bwd_partials_f32(const float* dy0, const float* dy1, int64_t lddy, const float* xhat, const float* rstd,
+                                                    const float* gamma, int32_t M, int32_t F, float* dx, int64_t lddx,
+                                                    void* workspace, size_t workspace_bytes, void* stream);
+
 static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_cloud_desc* clouds, const pcrl_aug_desc* aug,
                             const pcrl_encoder_weights* w, const void* packed,
                             const int32_t* argmax, const float* grad_pooled, const float* pooled,
@@ -1341,6 +1368,15 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         for (int i = 0; i < cs_n; ++i) cs_jobs[i] = t_colsum_jobs[i];
         t_colsum_n = 0;
     }
+    // an attached LayerNorm backward belongs to the call that launches prep (phase 0 or 1): it rides there when that is the Gram form's prep
+    // launch for c3 <= 256, and is a launch of its own in front of everything otherwise -- whatever path this call takes, it is consumed
+    LnBwdParams ln_job{};
+    bool ln_on = false;
+    if (phase != 2 && t_ln_on) { ln_job = t_ln_job; ln_on = true; t_ln_on = false; }
+    auto ln_alone = [&]() -> int {
+        return pcrl_layernorm_rows_bwd_partials_f32(ln_job.dy0, ln_job.dy1, ln_job.lddy, ln_job.xhat, ln_job.rstd, ln_job.gamma, ln_job.M, ln_job.F,
+                                                    ln_job.dx, ln_job.lddx, ln_job.part, t_ln_ws_bytes, stream);
+    };
     if (!clouds || !w || !packed || !argmax || (phase != 1 && (!grad_pooled || !grads))) return fail(PCRL_E_ARG, "NULL argument");
     size_t need;
     if (int rc = pcrl_encoder_packed_bytes(w->c_in, w->c1, w->c2, w->c3, &need)) return rc;
@@ -1350,6 +1386,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
     const GradLayout GL{w->c_in, w->c1, w->c2, w->c3};
     hipStream_t st = (hipStream_t)stream;
     if (p.cl.B == 0) {
+        if (ln_on) { if (int rc = ln_alone()) return rc; }
         if (phase != 1) PCRL_CHECK_HIP(hipMemsetAsync(grads, 0, sizeof(float) * GL.total(), st));
         return cs_n ? pcrl_colsum_jobs_f32(cs_jobs, cs_n, stream) : PCRL_OK;
     }
@@ -1371,6 +1408,9 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
         // function at the forward's routing, as close to the bf16 function's straight-through gradient as that one's own bf16
         // data-gradient GEMMs were (tests: the same 3e-2 bounds), and 12 % faster at K2's 512 x 1 200 clouds (380 -> 334 us).
         if (p.cl.B <= kMaxTileModeClouds && w->w2 && pooled) {
+            if (ln_on && w->c3 <= 256) { p.ln = ln_job; p.ln_blocks = (ln_job.M + 3) / 4; }
+            else if (ln_on) { if (int rc = ln_alone()) return rc; }
+            ln_on = false;
             p.ops = reinterpret_cast<float*>(base + wg.ops); p.pw = reinterpret_cast<float*>(base + wg.pw);
             p.n_act = reinterpret_cast<int*>(base + wg.nact); p.act = reinterpret_cast<int*>(base + wg.act);
             p.slot = reinterpret_cast<unsigned char*>(base + wg.slot); p.own = reinterpret_cast<unsigned*>(base + wg.own);
@@ -1404,6 +1444,7 @@ static int encoder_bwd_impl(int mode /* 0 fp32, 1 bf16, 2 split */, const pcrl_c
                                     "given, at most %d clouds", w->c1, w->c2, w->c3, kMaxTileModeClouds);
     }
     t_bwd_schedule = 1;
+    if (ln_on) { if (int rc = ln_alone()) return rc; }
     p.ops = reinterpret_cast<float*>(base + ws.ops); p.xs = reinterpret_cast<float*>(base + ws.xs);
     p.pw = reinterpret_cast<float*>(base + ws.pw); p.n_act = reinterpret_cast<int*>(base + ws.nact);
     p.flag = reinterpret_cast<int*>(base + ws.flag); p.act = reinterpret_cast<int*>(base + ws.act);

@@ -565,6 +565,14 @@ def layernorm_rows_bwd_partials(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, ldd
                                                      ctypes.c_size_t(workspace.numel() * workspace.element_size()), _stream()))
 
 
+def encoder_bwd_attach_ln_bwd(dy0, dy1, lddy, xhat, rstd, gamma, M, F, dx, lddx, workspace):
+    """include/pcrl.h: pcrl_encoder_bwd_attach_ln_bwd -- the feature head's LayerNorm backward (arguments as layernorm_rows_bwd_partials) rides
+    on the NEXT encoder-backward prep launch of this thread (hip.encoder_bwd_prepare / encoder_bwd) instead of being a launch of its own."""
+    check(lib().pcrl_encoder_bwd_attach_ln_bwd(ctypes.c_void_p(dy0), ctypes.c_void_p(dy1) if dy1 else None, ctypes.c_int64(lddy), _ptr(xhat), _ptr(rstd),
+                                               _ptr(gamma), M, F, _ptr(dx), ctypes.c_int64(lddx), _ptr(workspace),
+                                               ctypes.c_size_t(workspace.numel() * workspace.element_size())))
+
+
 def colsum_jobs(jobs, attach_to_encoder_bwd=False):
     """jobs: [(part ptr (int), blk_stride, nblk, ncols, out ptr (int), scale, op)] -> out[c] = scale * (sum | max)_b part[b * blk_stride + c].
     attach_to_encoder_bwd: no launch -- the jobs ride on the reduce launch of the next encoder_bwd call (pcrl_encoder_bwd_attach_colsum)."""

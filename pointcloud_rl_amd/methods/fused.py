@@ -218,6 +218,7 @@ class FusedStep:
         self.tail_bwd = True               # pcrl_policy_tail_bwd_f32: four launches of the actor's backward in one
         self.entry_pack = True             # the critic phase's re-pack rides on the replay's sampling launch
         self.publish_first = True          # the metrics leave BEFORE the step's last optimizer pass (the host's turn-around overlaps it)
+        self.ln_rider = True               # the feature LayerNorm's backward rides on the encoder backward's prep launch (one node fewer)
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
@@ -449,8 +450,16 @@ class FusedStep:
                               self.q.Bv(2, tgt, -self.q_base), hs, nlp_n, rewards, dones_u8, repeat, a.log_alpha, a.gamma, reward_scale,
                               a.ignore_dones, group, M, H, q, q_target, dq, dh2, part, stat_part)
             launch_layers(*[bwd_stages[1:]])
-            hip.layernorm_rows_bwd_partials(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd,
-                                            fc.data[off[pre + "1.weight"]:], M, F, dy, F, ws)
+            # The feature LayerNorm's backward (4.9 us of launch for 256 x 50 values) as extra workgroups of the encoder backward's prep
+            # launch, which needs only the forward's outputs and is brought forward to here: prep | LayerNorm -> feature GEMMs -> points ...
+            if self.ln_rider and not prepared and enc.can_prepare(ctx_o):
+                hip.encoder_bwd_attach_ln_bwd(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd,
+                                              fc.data[off[pre + "1.weight"]:], M, F, dy, F, ws)
+                prepared = enc.backward_prepare(ctx_o, argmax_o)
+                assert prepared
+            else:
+                hip.layernorm_rows_bwd_partials(dX0.data_ptr(), dX0.data_ptr() + 4 * M * ceil4(F), ceil4(F), xhat, rstd,
+                                                fc.data[off[pre + "1.weight"]:], M, F, dy, F, ws)
             n_wg, n_ln, Hp = (M + 3) // 4, (M + 3) // 4, H + 4
             g = fc.grad.data_ptr()
             jobs = [(ws.data_ptr(), 2 * F, n_ln, F, g + 4 * off[pre + "1.weight"], 1.0, 0),

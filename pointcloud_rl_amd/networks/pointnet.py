@@ -223,11 +223,16 @@ class PointNet(ExtendedModule):
         ew, packed = self._weights_desc()
         return desc, keep, aug, (hip.make_aug_desc(**aug) if aug else None), ew, packed, pooled
 
+    def can_prepare(self, ctx):
+        """Whether backward_prepare would launch (exact fp32 arithmetic, the forward's pooled values at hand, at most 2 048 clouds)."""
+        desc, keep, aug, aug_desc, ew, packed, pooled = ctx
+        return self.compute_dtype == "f32" and pooled is not None and desc.B <= 2048
+
     def backward_prepare(self, ctx, argmax):
         """The part of backward_raw that needs only the forward's outputs (hip.encoder_bwd_prepare); True when it was launched --
         backward_raw must then be called with prepared=True, behind it.  Exact fp32 arithmetic, Gram form only."""
         desc, keep, aug, aug_desc, ew, packed, pooled = ctx
-        if self.compute_dtype != "f32" or pooled is None or desc.B > 2048:
+        if not self.can_prepare(ctx):
             return False
         hip.encoder_bwd_prepare(desc, ew, packed, argmax, pooled, self._workspace("bwd", desc.B), aug=aug_desc)
         return True

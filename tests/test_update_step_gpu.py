@@ -417,12 +417,15 @@ def test_round4_launch_cuts_equal_the_launches_they_replace(cuda, monkeypatch, k
         assert (err <= 2e-6).float().mean() >= 0.999 and err.max() <= 2.1e-3, (n, float(err.max()))
 
 
+@pytest.mark.parametrize("switch", ["publish_first", "ln_rider"])
 @pytest.mark.parametrize("graphs", [False, True], ids=["eager", "hipgraph"])
-def test_metrics_published_before_the_last_optimizer_pass_change_nothing(cuda, graphs):
-    """Round 6: the step's last optimizer pass runs BEHIND the launch that publishes the metrics (csrc/optim.hip: gradnorm_kernel takes the
-    pass's norm ahead of it, the temperature's pass rides there).  Same partial sums, same reduction tree, same bias corrections: every
-    metric of six updates (critic-only and actor steps alternate) and every parameter, moment and the target network are bit-identical
-    to the order of rounds 1-5, eager and replayed from the step's hipGraph."""
+def test_metrics_published_before_the_last_optimizer_pass_change_nothing(cuda, graphs, switch):
+    """Round 6, two re-orderings of the step's launches that must change NOTHING.  publish_first: the step's last optimizer pass runs BEHIND
+    the launch that publishes the metrics (csrc/optim.hip: gradnorm_kernel takes the pass's norm ahead of it, the temperature's pass rides
+    there) -- same partial sums, same reduction tree, same bias corrections.  ln_rider: the feature LayerNorm's backward runs as extra
+    workgroups of the encoder backward's prep launch, brought forward in front of the feature GEMMs (pcrl_encoder_bwd_attach_ln_bwd) -- the
+    same block function.  Every metric of six updates (critic-only and actor steps alternate) and every parameter, moment and the target
+    network are bit-identical to the order of rounds 1-5, eager and replayed from the step's hipGraph."""
     from pointcloud_rl_amd import configs
     from pointcloud_rl_amd.methods import build_agent
     from pointcloud_rl_amd.synthetic import SyntheticReplay
@@ -436,7 +439,7 @@ def test_metrics_published_before_the_last_optimizer_pass_change_nothing(cuda, g
         torch.manual_seed(0)
         agent = build_agent(cfg).to(cuda)
         agent._prepare()
-        agent._fused.publish_first = first
+        setattr(agent._fused, switch, first)
         if graphs:
             agent.enable_graphs()
         mem = SyntheticReplay(B, N, A, seed=4, device=cuda)
@@ -452,7 +455,7 @@ def test_metrics_published_before_the_last_optimizer_pass_change_nothing(cuda, g
     old, rets_o = run(False)
     torch.manual_seed(11)
     new, rets_n = run(True)
-    assert new._fused.publish_first and not old._fused.publish_first
+    assert getattr(new._fused, switch) and not getattr(old._fused, switch)
     for u, (ro, rn) in enumerate(zip(rets_o, rets_n)):
         assert ro.keys() == rn.keys()
         for k in ro:
