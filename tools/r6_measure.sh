@@ -9,6 +9,10 @@ sha256sum pointcloud_rl_amd/libpcrl_hip.so | tee $OUT/libpcrl_hip.sha256
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 echo "library the suite ran on: $(cat $OUT/libpcrl_hip.sha256)" >> $OUT/pytest.log
 tail -4 $OUT/pytest.log
+# counters first, folded into profiles/ ON THE BOX: the bench lines below then carry the HBM traffic / matrix-busy figures of THIS library
+for wl in k1 k2 k4; do bash tools/pmc_traffic.sh $wl > $OUT/pmc_traffic_$wl.log 2>&1; cp gpurun_out/pmc/traffic_$wl.json profiles/r06_pmc_traffic_$wl.json; done
+bash tools/step_ledger.sh k1 > $OUT/step_ledger_k1.md 2>&1
+cp $OUT/step_ledger_k1.md profiles/r06_step_ledger_k1.md; python tools/gemm_busy_json.py profiles/r06_step_ledger_k1.md profiles/r06_gemm_matrix_busy.json > /dev/null; cp profiles/r06_gemm_matrix_busy.json $OUT/
 for wl in k1 k2 k3 k4; do
   steps=2000; warm=500
   [ "$wl" = "k3" ] && { steps=400; warm=100; }
@@ -22,10 +26,8 @@ done
 python bench.py --steps 20 --warmup 5 > $OUT/bench_k1_driver_style.json 2> /dev/null
 for b in 128 64 32; do python bench.py --batch $b --no-cpu-baseline --no-experimental --no-extra-workloads > $OUT/share_k1_b$b.json 2>/dev/null; done
 python bench.py --workload k3 --batch 128 --steps 1000 --warmup 200 --no-cpu-baseline --no-extra-workloads > $OUT/share_k3_b128.json 2>/dev/null
-for wl in k1 k2 k4; do bash tools/pmc_traffic.sh $wl > $OUT/pmc_traffic_$wl.log 2>&1; done
 bash tools/r3_timeline.sh $OUT/tl_k1 > $OUT/timeline_k1.txt 2>&1
 bash tools/r3_timeline.sh $OUT/tl_b32 --batch 32 > $OUT/timeline_k1_b32.txt 2>&1
 bash tools/r3_timeline.sh $OUT/tl_k3b128 --workload k3 --batch 128 > $OUT/timeline_k3_b128.txt 2>&1
 rm -rf $OUT/tl_*
-bash tools/step_ledger.sh k1 > $OUT/step_ledger_k1.md 2>&1
 ls $OUT
