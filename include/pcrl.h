@@ -298,7 +298,8 @@ int pcrl_adam_step_rider_f32(float* param, const float* grad, float* exp_avg, fl
 /* A step that publishes its metrics BEFORE its last optimizer pass (the host's turn-around to the next step then overlaps that pass):
  *   pcrl_grad_norm_partials_f32  -- the pass's gradient-norm partial sums without the pass: same grid, element order and reduction tree as
  *       pcrl_adam_step_f32, so the norm (module_utils.py:40-45) is bit for bit the one the pass would have reported; `pending` is filled as by
- *       defer_finalize above and goes to pcrl_gather_scalars_f32, which forms the norm and ADVANCES the step count.  An optional rider (the
+ *       defer_finalize above -- except that this launch ADVANCES the pass's step count itself (pending->step_counter comes back NULL) -- and goes to
+ *       pcrl_gather_scalars_f32 / pcrl_adam_step_published_gather_f32, which form the norm.  An optional rider (the
  *       temperature: its whole Adam pass, sac.py:192-195, so that alpha = exp(log_alpha) is final before the metrics are gathered) runs in one
  *       extra workgroup, its own `rider_pending` filled alike.
  *   pcrl_adam_step_published_f32 -- the pass itself, launched AFTER that gather launch: reads *step_counter as already advanced (bias
@@ -310,6 +311,14 @@ int pcrl_grad_norm_partials_f32(const float* grad, size_t n, float grad_scale, i
 int pcrl_adam_step_published_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                                  float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* step_counter,
                                  float* target, size_t target_begin, size_t target_end, float tau, void* stream);
+/* The same pass with pcrl_gather_scalars_host_f32 (declared below; same arguments) done by its FIRST workgroup instead of by a launch of its own in
+ * front of it: the metrics leave when the pass starts.  None of the pending passes may be this pass itself (its step count was advanced by
+ * pcrl_grad_norm_partials_f32: that call's `pending` carries a NULL step counter and only has its norm formed here). */
+int pcrl_adam_step_published_gather_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                        float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* step_counter,
+                                        float* target, size_t target_begin, size_t target_end, float tau,
+                                        const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n_scalars,
+                                        const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream);
 /* target <- (1 - tau) target + tau src  (soft_update / hard_update with tau = 1, ops.py:59-100). */
 int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream);
 

@@ -207,6 +207,91 @@ __host__ __device__ inline float u01_to_range(uint32_t w, float lo, float hi) {
     return lo + (float)(w >> 8) * (1.0f / 16777216.0f) * (hi - lo);
 }
 
+// ---- the scalars a step reports, gathered by ONE workgroup of 256 threads (csrc/tail.hip: gather_scalars_kernel; csrc/optim.hip: the first
+// workgroup of a published optimizer pass, pcrl_adam_step_published_gather_f32): up to four deferred optimizer passes are finished first --
+// gradient norm = sqrt of the fixed-order sum of the pass's per-block partial sums, step count += 1 where the pass has not advanced it itself
+// (step == NULL) -- so a norm can be one of the gathered scalars. ------------------------------------------------------------------------
+constexpr int kMaxScalars = 16;
+constexpr int kMaxFinalize = 4;
+struct ScalarListParams {
+    const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n;
+    const float* partial[kMaxFinalize]; int n_partial[kMaxFinalize]; float* norm[kMaxFinalize]; int* step[kMaxFinalize]; int n_fin;
+    float* host_out;      // optional pinned host mirror of the n values (slots pre-filled with 0xFFFFFFFF by the host)
+};
+// s_part: kMaxFinalize * 4 floats of LDS; tid in [0, 256)
+__device__ __forceinline__ void gather_scalars_block(const ScalarListParams& p, int tid, float* s_part) {
+    // The partials were written by the previous launch on every XCD: each load is a miss.  All of them (every optimizer's, eight per
+    // thread at a time) are requested before the first sum; thread t still adds partial[t], partial[t + 256], ... in that order, then the
+    // fixed-order tree gradnorm_finalize_kernel uses.
+    float s[kMaxFinalize];
+#pragma unroll
+    for (int f = 0; f < kMaxFinalize; ++f) {
+        s[f] = 0.0f;
+        if (f < p.n_fin) {
+            const int n = p.n_partial[f];
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = tid + 256 * k; v[k] = i < n ? p.partial[f][i] : 0.0f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (tid + 256 * k < n) s[f] += v[k];
+            for (int i = tid + 2048; i < n; i += 256) s[f] += p.partial[f][i];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < kMaxFinalize; ++f) {
+        for (int off = 32; off > 0; off >>= 1) s[f] += __shfl_down(s[f], off, 64);
+        if ((tid & 63) == 0) s_part[f * 4 + (tid >> 6)] = s[f];
+    }
+    __syncthreads();
+    if (tid < p.n_fin) {
+        const int f = tid;
+        if (p.norm[f]) p.norm[f][0] = __builtin_sqrtf((s_part[f * 4 + 0] + s_part[f * 4 + 1]) + (s_part[f * 4 + 2] + s_part[f * 4 + 3]));
+        if (p.step[f]) p.step[f][0] += 1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int i = tid;
+    float out = 0.0f;
+    if (i < p.n) {
+        const float v = p.src[i][0];
+        out = ((p.exp_mask >> i) & 1u) ? expf(v) : v;
+        p.dst[i][0] = out;
+    }
+    // Pinned host mirror: every value is ONE 4-byte store, so no ordering between them is needed -- the host pre-fills the
+    // slots with a sentinel bit pattern (0xFFFFFFFF, a NaN no arithmetic here produces) and reads a value as soon as its
+    // slot differs.  (A system-scope fence + flag would first write the whole dirty L2 back; that happens at the end of the
+    // kernel anyway, now under the host's work between two steps.)
+    if (p.host_out && i < p.n) {
+        unsigned bits = __builtin_bit_cast(unsigned, out);
+        if (bits == 0xFFFFFFFFu) bits = 0x7FC00000u;
+        __builtin_nontemporal_store(bits, reinterpret_cast<unsigned*>(p.host_out) + i);
+    }
+}
+
+// host side: the C arguments of pcrl_gather_scalars_*_f32 -> ScalarListParams (validated)
+inline int scalar_list_fill(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
+                            const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, ScalarListParams& p) {
+    if (n < 0 || n > kMaxScalars || (n > 0 && (!src || !dst))) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
+    if (n_pending < 0 || n_pending > kMaxFinalize || (n_pending > 0 && !pending))
+        return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n_pending <= %d", kMaxFinalize);
+    p = ScalarListParams{};
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || !dst[i]) return fail(PCRL_E_ARG, "NULL scalar pointer");
+        p.src[i] = src[i]; p.dst[i] = dst[i];
+        if (take_exp && take_exp[i]) p.exp_mask |= 1u << i;
+    }
+    p.n = n;
+    for (int f = 0; f < n_pending; ++f) {
+        // (step_counter NULL: the pass has advanced its step count itself -- pcrl_grad_norm_partials_f32)
+        if (!pending[f].partial || pending[f].n_partial < 1) return fail(PCRL_E_ARG, "bad pending optimizer pass %d", f);
+        p.partial[f] = pending[f].partial; p.n_partial[f] = pending[f].n_partial;
+        p.norm[f] = pending[f].grad_norm_out; p.step[f] = pending[f].step_counter;
+    }
+    p.n_fin = n_pending;
+    p.host_out = host_out;
+    return PCRL_OK;
+}
+
 // ---- backward of a row-wise LayerNorm over F <= 256 features (PointNet.final_mlp[1]), four rows per 256-thread block: dx and the per-block
 // partial sums of dgamma / dbeta.  One block function, two hosts: layernorm_rows_bwd_kernel (csrc/dense.hip) and -- riding on the encoder
 // backward's prep launch, which needs nothing it writes (pcrl_encoder_bwd_attach_ln_bwd) -- encoder_bwdg_prep_kernel. ------------------------

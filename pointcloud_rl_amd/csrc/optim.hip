@@ -66,15 +66,14 @@ __device__ __forceinline__ void adam_rider_block(const AdamRider& r) {
     if (threadIdx.x == 0) r.partial[0] = (s_rider[0] + s_rider[1]) + (s_rider[2] + s_rider[3]);
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const AdamRider rider) {
-    if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
+__device__ __forceinline__ void adam_main_block(const AdamParams& p, const int block) {
     const float step = (float)(p.step[0] + p.step_add);
     const float bc1 = 1.0f - powf(p.beta1, step);
     const float bc2_sqrt = __builtin_sqrtf(1.0f - powf(p.beta2, step));
     const float step_size = p.lr / bc1;
     float gsq = 0.0f;
     const long long stride = (long long)p.main_blocks * blockDim.x * 4;
-    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < p.n; i += stride) {
+    for (long long i = ((long long)block * blockDim.x + threadIdx.x) * 4; i < p.n; i += stride) {
         if (i + 3 < p.n) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.grad + i);
             f32x4 m4 = *reinterpret_cast<const f32x4*>(p.exp_avg + i);
@@ -115,13 +114,31 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const Ada
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gsq;
     __syncthreads();
-    if (threadIdx.x == 0) p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (threadIdx.x == 0) p.partial[block] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamParams p, const AdamRider rider) {
+    if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
+    adam_main_block(p, (int)blockIdx.x);
+}
+
+// A published pass (its norm and step count went ahead of it) whose FIRST workgroup gathers and publishes the step's metrics
+// (gather_scalars_block, csrc/common.h) instead of a launch of its own in front: the metrics leave when this launch starts.  Nothing that
+// workgroup writes -- norms, the step counts of OTHER (deferred) passes, the gathered scalars, the pinned host mirror -- is read by the
+// pass's own workgroups.
+__global__ __launch_bounds__(256) void adam_gather_kernel(const AdamParams p, const ScalarListParams g) {
+    if (blockIdx.x == 0) {
+        __shared__ float s_fin[kMaxFinalize * 4];
+        gather_scalars_block(g, (int)threadIdx.x, s_fin);
+        return;
+    }
+    adam_main_block(p, (int)blockIdx.x - 1);
 }
 
 // The gradient norm of a pass WITHOUT the pass: the same grid, the same per-thread element order and the same reduction tree as
 // adam_kernel, so the partial sums (and the norm the end-of-step launch forms from them) are bit for bit what the optimizer pass would
 // have produced.  Lets a step publish its metrics BEFORE its last optimizer launch (pcrl_grad_norm_partials_f32): 4 B per parameter read.
-struct GradNormParams { const float* grad; long long n; float grad_scale; float* partial; int main_blocks; };
+struct GradNormParams { const float* grad; long long n; float grad_scale; float* partial; int main_blocks; int* step; };   // step: advanced by ONE thread of this launch (nothing in it reads it)
 __global__ __launch_bounds__(256) void gradnorm_kernel(const GradNormParams p, const AdamRider rider) {
     if ((int)blockIdx.x >= p.main_blocks) { adam_rider_block(rider); return; }
     float gsq = 0.0f;
@@ -139,7 +156,10 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const GradNormParams p, c
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = gsq;
     __syncthreads();
-    if (threadIdx.x == 0) p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (threadIdx.x == 0) {
+        p.partial[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        if (blockIdx.x == 0) p.step[0] += 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void gradnorm_finalize_kernel(const float* partial, int n, float* out, int* step) {
@@ -185,7 +205,8 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
                        int32_t* step_counter, float* grad_norm_out,
                        float* target, size_t target_begin, size_t target_end, float tau,
                        void* workspace, size_t workspace_bytes, pcrl_adam_pending* defer_finalize,
-                       const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream, bool published = false) {
+                       const pcrl_adam_rider* rider, pcrl_adam_pending* rider_defer, void* stream, bool published = false,
+                       const ScalarListParams* gather = nullptr) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !step_counter) return fail(PCRL_E_ARG, "NULL argument");
     if (n == 0) return PCRL_OK;
     if (published) {
@@ -194,6 +215,11 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
         const int grid = adam_grid((long long)n);
         AdamParams p{param, grad, exp_avg, exp_avg_sq, (long long)n, lr, beta1, beta2, eps, grad_scale, step_counter,
                      target, (long long)target_begin, (long long)target_end, tau, nullptr, grid, 0};
+        if (gather) {
+            hipLaunchKernelGGL(adam_gather_kernel, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream, p, *gather);
+            PCRL_CHECK_LAUNCH("adam_gather_kernel");
+            return PCRL_OK;
+        }
         hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, AdamRider{});
         PCRL_CHECK_LAUNCH("adam_kernel");
         return PCRL_OK;
@@ -266,10 +292,11 @@ extern "C" int pcrl_grad_norm_partials_f32(const float* grad, size_t n, float gr
         r = AdamRider{rider->param, rider->grad, rider->exp_avg, rider->exp_avg_sq, (long long)rider->n, rider->lr, rider->beta1, rider->beta2,
                       rider->eps, rider->grad_scale, rider->step_counter, rider->partial};
     }
-    GradNormParams p{grad, (long long)n, grad_scale, static_cast<float*>(workspace), grid};
+    GradNormParams p{grad, (long long)n, grad_scale, static_cast<float*>(workspace), grid, step_counter};
     hipLaunchKernelGGL(gradnorm_kernel, dim3(grid + (rider ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, p, r);
     PCRL_CHECK_LAUNCH("gradnorm_kernel");
-    pending->partial = p.partial; pending->n_partial = grid; pending->grad_norm_out = grad_norm_out; pending->step_counter = step_counter;
+    // (the launch has advanced this pass's step count itself: the gather launch only forms the norm)
+    pending->partial = p.partial; pending->n_partial = grid; pending->grad_norm_out = grad_norm_out; pending->step_counter = nullptr;
     if (rider) {
         rider_pending->partial = rider->partial; rider_pending->n_partial = 1;
         rider_pending->grad_norm_out = rider->grad_norm_out; rider_pending->step_counter = rider->step_counter;
@@ -282,6 +309,20 @@ extern "C" int pcrl_adam_step_published_f32(float* param, const float* grad, flo
                                             float* target, size_t target_begin, size_t target_end, float tau, void* stream) {
     return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_counter), nullptr, target,
                        target_begin, target_end, tau, nullptr, 0, nullptr, nullptr, nullptr, stream, true);
+}
+
+extern "C" int pcrl_adam_step_published_gather_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                                   float lr, float beta1, float beta2, float eps, float grad_scale, const int32_t* step_counter,
+                                                   float* target, size_t target_begin, size_t target_end, float tau,
+                                                   const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n_scalars,
+                                                   const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream) {
+    ScalarListParams g;
+    if (int rc = scalar_list_fill(src, dst, take_exp, n_scalars, pending, n_pending, host_out, g)) return rc;
+    for (int f = 0; f < n_pending; ++f)
+        if (pending[f].step_counter == step_counter) return fail(PCRL_E_ARG, "the published pass's own step count must have been advanced before it (pcrl_grad_norm_partials_f32)");
+    if (n == 0) return fail(PCRL_E_ARG, "empty pass");
+    return adam_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_counter), nullptr, target,
+                       target_begin, target_end, tau, nullptr, 0, nullptr, nullptr, nullptr, stream, true, &g);
 }
 
 extern "C" int pcrl_polyak_f32(float* target, const float* src, size_t n, float tau, void* stream) {

@@ -206,61 +206,9 @@ __global__ __launch_bounds__(1024) void actor_loss_kernel(const ActorLossParams 
 // four deferred optimizer passes (pcrl_adam_step_f32 with defer_finalize): gradient norm = sqrt of the fixed-order
 // sum of the pass's per-block partial sums, step count += 1 -- before the scalars are copied, so a norm can be one
 // of them.
-constexpr int kMaxScalars = 16;
-constexpr int kMaxFinalize = 4;
-struct ScalarListParams {
-    const float* src[kMaxScalars]; float* dst[kMaxScalars]; unsigned exp_mask; int n;
-    const float* partial[kMaxFinalize]; int n_partial[kMaxFinalize]; float* norm[kMaxFinalize]; int* step[kMaxFinalize]; int n_fin;
-    float* host_out;      // optional pinned host mirror of the n values (slots pre-filled with 0xFFFFFFFF by the host)
-};
 __global__ __launch_bounds__(256) void gather_scalars_kernel(const ScalarListParams p) {
-    // The partials were written by the previous launch on every XCD: each load is a miss.  All of them (every optimizer's, eight per
-    // thread at a time) are requested before the first sum; thread t still adds partial[t], partial[t + 256], ... in that order, then the
-    // fixed-order tree gradnorm_finalize_kernel uses.
-    __shared__ float s_part[kMaxFinalize][4];
-    float s[kMaxFinalize];
-#pragma unroll
-    for (int f = 0; f < kMaxFinalize; ++f) {
-        s[f] = 0.0f;
-        if (f < p.n_fin) {
-            const int n = p.n_partial[f];
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int i = threadIdx.x + 256 * k; v[k] = i < n ? p.partial[f][i] : 0.0f; }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if ((int)threadIdx.x + 256 * k < n) s[f] += v[k];
-            for (int i = threadIdx.x + 2048; i < n; i += 256) s[f] += p.partial[f][i];
-        }
-    }
-#pragma unroll
-    for (int f = 0; f < kMaxFinalize; ++f) {
-        for (int off = 32; off > 0; off >>= 1) s[f] += __shfl_down(s[f], off, 64);
-        if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = s[f];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < p.n_fin) {
-        const int f = threadIdx.x;
-        if (p.norm[f]) p.norm[f][0] = __builtin_sqrtf((s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]));
-        p.step[f][0] += 1;
-    }
-    __threadfence_block();
-    __syncthreads();
-    const int i = threadIdx.x;
-    float out = 0.0f;
-    if (i < p.n) {
-        const float v = p.src[i][0];
-        out = ((p.exp_mask >> i) & 1u) ? expf(v) : v;
-        p.dst[i][0] = out;
-    }
-    // Pinned host mirror: every value is ONE 4-byte store, so no ordering between them is needed -- the host pre-fills the
-    // slots with a sentinel bit pattern (0xFFFFFFFF, a NaN no arithmetic here produces) and reads a value as soon as its
-    // slot differs.  (A system-scope fence + flag would first write the whole dirty L2 back; that happens at the end of the
-    // kernel anyway, now under the host's work between two steps.)
-    if (p.host_out && i < p.n) {
-        unsigned bits = __builtin_bit_cast(unsigned, out);
-        if (bits == 0xFFFFFFFFu) bits = 0x7FC00000u;
-        __builtin_nontemporal_store(bits, reinterpret_cast<unsigned*>(p.host_out) + i);
-    }
+    __shared__ float s_part[kMaxFinalize * 4];
+    gather_scalars_block(p, (int)threadIdx.x, s_part);
 }
 
 }  // namespace pcrl
@@ -274,24 +222,9 @@ extern "C" int pcrl_gather_scalars_f32(const float* const* src, float* const* ds
 
 extern "C" int pcrl_gather_scalars_host_f32(const float* const* src, float* const* dst, const int32_t* take_exp, int32_t n,
                                             const pcrl_adam_pending* pending, int32_t n_pending, float* host_out, void* stream) {
-    if (n < 0 || n > kMaxScalars || (n > 0 && (!src || !dst))) return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n <= %d", kMaxScalars);
-    if (n_pending < 0 || n_pending > kMaxFinalize || (n_pending > 0 && !pending))
-        return fail(PCRL_E_ARG, "pcrl_gather_scalars_f32: 0 <= n_pending <= %d", kMaxFinalize);
     if (n == 0 && n_pending == 0) return PCRL_OK;
-    ScalarListParams p{};
-    for (int i = 0; i < n; ++i) {
-        if (!src[i] || !dst[i]) return fail(PCRL_E_ARG, "NULL scalar pointer");
-        p.src[i] = src[i]; p.dst[i] = dst[i];
-        if (take_exp && take_exp[i]) p.exp_mask |= 1u << i;
-    }
-    p.n = n;
-    for (int f = 0; f < n_pending; ++f) {
-        if (!pending[f].partial || !pending[f].step_counter || pending[f].n_partial < 1) return fail(PCRL_E_ARG, "bad pending optimizer pass %d", f);
-        p.partial[f] = pending[f].partial; p.n_partial[f] = pending[f].n_partial;
-        p.norm[f] = pending[f].grad_norm_out; p.step[f] = pending[f].step_counter;
-    }
-    p.n_fin = n_pending;
-    p.host_out = host_out;
+    ScalarListParams p;
+    if (int rc = scalar_list_fill(src, dst, take_exp, n, pending, n_pending, host_out, p)) return rc;
     hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     PCRL_CHECK_LAUNCH("gather_scalars_kernel");
     return PCRL_OK;

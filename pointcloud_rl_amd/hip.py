@@ -374,10 +374,31 @@ def grad_norm_partials(grad, grad_scale, step_counter, grad_norm_out, workspace,
     return (pending, r_pending) if rider is not None else pending
 
 
+def _scalar_list(entries, pending):
+    n = len(entries)
+    pend = (_lib.AdamPending * max(len(pending), 1))(*pending)
+    src = (ctypes.c_void_p * n)(*[e[0].data_ptr() for e in entries])
+    dst = (ctypes.c_void_p * n)(*[e[1].data_ptr() for e in entries])
+    flags = (ctypes.c_int32 * n)(*[int(bool(e[2])) for e in entries])
+    return src, dst, flags, n, pend
+
+
 def adam_step_published(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, grad_scale, step_counter, target=None, target_begin=0,
-                        target_end=0, tau=0.0):
+                        target_end=0, tau=0.0, gather=None):
     """include/pcrl.h: pcrl_adam_step_published_f32 -- the optimizer pass of a step whose norm / step count went ahead of it
-    (grad_norm_partials + gather_scalars): reads the step count as already advanced."""
+    (grad_norm_partials): reads the step count as already advanced.  gather = (entries, pending, host_out) as for gather_scalars: the
+    pass's first workgroup gathers and publishes the step's metrics (pcrl_adam_step_published_gather_f32) instead of a launch in front."""
+    if gather is not None:
+        entries, pending, host_out = gather
+        assert host_out.dtype == torch.float32 and host_out.is_pinned() and host_out.numel() >= len(entries) and host_out.is_contiguous()
+        src, dst, flags, n, pend = _scalar_list(entries, pending)
+        with _span("adam_step"):
+            check(lib().pcrl_adam_step_published_gather_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
+                                                            ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),
+                                                            ctypes.c_float(grad_scale), _ptr(step_counter), _ptr(target), ctypes.c_size_t(target_begin),
+                                                            ctypes.c_size_t(target_end), ctypes.c_float(tau), src, dst, flags, n, pend, len(pending),
+                                                            ctypes.c_void_p(host_out.data_ptr()), _stream()))
+        return
     with _span("adam_step"):
         check(lib().pcrl_adam_step_published_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), ctypes.c_size_t(param.numel()),
                                                  ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps),

@@ -219,6 +219,7 @@ class FusedStep:
         self.entry_pack = True             # the critic phase's re-pack rides on the replay's sampling launch
         self.publish_first = True          # the metrics leave BEFORE the step's last optimizer pass (the host's turn-around overlaps it)
         self.ln_rider = True               # the feature LayerNorm's backward rides on the encoder backward's prep launch (one node fewer)
+        self.gather_rider = True           # the metrics are gathered / published by the first workgroup of the published pass (one node fewer)
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
@@ -503,7 +504,7 @@ class FusedStep:
             split = a._optim_norm_first("critic", scale, pending)
             if split is not None:
                 stats["critic_grad"], finish = split
-                last_pass = lambda: finish(polyak)
+                last_pass = lambda gather=None: finish(polyak, gather)
         if last_pass is None:
             stats["critic_grad"] = a._optim_step("critic", scale, polyak=polyak, pending=pending)   # also invalidates enc's packed image
         stats.update(critic_loss=self.stats_c[0], max_critic_abs_err=self.stats_c[1], q=self.stats_c[2], q_target=self.stats_c[3])
@@ -586,7 +587,7 @@ class FusedStep:
             split = a._optim_norm_first("actor", scale, pending, rider=("alpha", scale if a.sync_alpha else 1.0)) if self.publish_first else None
             if split is not None:
                 stats["actor_grad"], finish_a = split
-                last_pass = lambda: finish_a(False)
+                last_pass = lambda gather=None: finish_a(False, gather)
             else:
                 stats["actor_grad"] = a._optim_step("actor", scale, pending=pending, rider=("alpha", scale if a.sync_alpha else 1.0))
             stats.update(actor_loss=self.stats_a[0], entropy=self.stats_a[1], alpha_loss=self.stats_a[2], new_alpha=None)
@@ -598,9 +599,12 @@ class FusedStep:
             entries.append((a.log_alpha, a._alpha_t, True))
         if self.host_stats is None:
             self.host_stats = torch.zeros(32, dtype=torch.float32).pin_memory()
-        hip.gather_scalars(entries, pending=pending, host_out=self.host_stats)
-        if last_pass is not None:
-            last_pass()
+        if last_pass is not None and self.gather_rider:
+            last_pass((entries, pending, self.host_stats))      # the pass's first workgroup gathers and publishes
+        else:
+            hip.gather_scalars(entries, pending=pending, host_out=self.host_stats)
+            if last_pass is not None:
+                last_pass()
         packed = PackedStats((k, out[i]) for i, k in enumerate(names))
         packed.packed = out[:len(names)]
         packed.host = self.host_stats

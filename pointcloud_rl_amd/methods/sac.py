@@ -164,11 +164,12 @@ class HipAdam(torch.optim.Optimizer):
         self.hyper()
         return hip.grad_norm_partials(self.flat.grad, grad_scale, self.step_counter, self.grad_norm, self.workspace, rider=rider)
 
-    def step_published(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0):
+    def step_published(self, grad_scale=1.0, target=None, target_range=(0, 0), tau=0.0, gather=None):
         g = self.param_groups[0]
         self.hyper()
         hip.adam_step_published(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                                grad_scale, self.step_counter, target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau)
+                                grad_scale, self.step_counter, target=target, target_begin=target_range[0], target_end=target_range[1], tau=tau,
+                                gather=gather)
 
     def _views(self, flat_tensor):
         return self.flat.views(flat_tensor)
@@ -430,11 +431,11 @@ class SAC(BaseAgent):
         pending.append(pend)
         polyak = name == "critic"
 
-        def finish(do_polyak):
+        def finish(do_polyak, gather=None):
             if do_polyak and polyak and self._target_flat is not None:
-                opt.step_published(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau)
+                opt.step_published(scale, target=self._target_flat.data, target_range=self._target_range, tau=self._target_tau, gather=gather)
             else:
-                opt.step_published(scale)
+                opt.step_published(scale, gather=gather)
             for enc in self._packed_owners.get(name, ()):
                 enc.invalidate_packed()
         return opt.grad_norm.reshape(()), finish
