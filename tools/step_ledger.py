@@ -35,7 +35,8 @@ def mean(v):
 mf, dur = counters(sys.argv[1])
 fe, _ = counters(sys.argv[2])
 wr, _ = counters(sys.argv[3])
-steps = len(dur.get("gather_scalars_kernel", [])) or 1
+# one replay gather per update step (the metrics' gather rides the published Adam pass since round 6: adam_gather_kernel)
+steps = len(dur.get("replay_gather_kernel", [])) or len(dur.get("gather_scalars_kernel", [])) or 1
 total = sum(sum(v) for v in dur.values())
 print(f"# Every kernel of the update step against both rooflines\n\n`{sys.argv[4]}` under `rocprofv3 --kernel-trace --pmc <set>`, three passes "
       f"(SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 | FETCH_SIZE | WRITE_SIZE); {steps} eager steps "
