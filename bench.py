@@ -58,6 +58,19 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def library_source_sha():
+    """Hash of everything libpcrl_hip.so is compiled from (csrc/*.hip, csrc/*.h, csrc/Makefile, include/pcrl.h): the identity of the
+    shipped library that survives a rebuild (hipcc's objects are not bit-reproducible).  profiles/*_final_binary.json records it next to the
+    log of the last whole `-m gpu` suite; tests/test_measurement_tools.py holds the tree to it (no kernel change after the last suite)."""
+    import glob
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "pointcloud_rl_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "pcrl.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def gemm_source_sha():
     """Hash of the sources the head GEMM kernels are compiled from; tags profiles/*_gemm_matrix_busy.json."""
     h = hashlib.sha256()

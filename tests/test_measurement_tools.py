@@ -82,3 +82,15 @@ def test_the_committed_matrix_busy_figure_is_per_step_and_of_the_shipped_sources
     assert busy["kernel_source_sha"] == bench.gemm_source_sha()
     assert 50.0 < busy["us_per_step"] < 400.0                                       # nine launches of a K1 step, not a whole trace
     assert all(r["launches_per_step"] <= 4.0 for r in busy["rows"])
+
+
+def test_no_kernel_source_changed_after_the_last_whole_gpu_suite():
+    """The final-binary rule: the library sources in the tree are the ones the last whole `-m gpu` suite ran on.  Whoever
+    changes csrc/ or include/pcrl.h re-runs tools/gpu_round.sh (rebuild, whole suite, sha256) and updates profiles/*_final_binary.json."""
+    import glob
+    import bench
+    rec = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_binary.json")))[-1]))
+    assert rec["library_source_sha256"] == bench.library_source_sha(), \
+        "csrc/ or include/pcrl.h changed after the last whole GPU suite: run tools/gpu_round.sh on an MI355X and record the new identity"
+    assert rec["library_sha256"][:8] in open(os.path.join(ROOT, rec["suite_log"])).read()
+    assert " passed" in rec["suite"] and "failed" not in rec["suite"]

@@ -15,6 +15,7 @@ git -C . rev-parse HEAD 2>/dev/null | tee $OUT/head.txt || true
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -5 $OUT/pytest.log
 echo "library the suite ran on: $(cat $OUT/libpcrl_hip.sha256)" >> $OUT/pytest.log
+python3 tools/final_binary_json.py $OUT/pytest.log profiles/r06_gpu_suite.txt $OUT/final_binary.json || echo "suite not green: no final_binary.json"
 for wl in $WLS; do
   steps=2000; warm=500
   [ "$wl" = "k3" ] && { steps=400; warm=100; }

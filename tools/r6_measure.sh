@@ -8,6 +8,7 @@ make -C pointcloud_rl_amd/csrc > $OUT/make.log 2>&1; echo "make rc=$? ($(grep -c
 sha256sum pointcloud_rl_amd/libpcrl_hip.so | tee $OUT/libpcrl_hip.sha256
 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 echo "library the suite ran on: $(cat $OUT/libpcrl_hip.sha256)" >> $OUT/pytest.log
+python3 tools/final_binary_json.py $OUT/pytest.log profiles/r06_gpu_suite.txt $OUT/final_binary.json || echo "suite not green: no final_binary.json"
 tail -4 $OUT/pytest.log
 # counters first, folded into profiles/ ON THE BOX: the bench lines below then carry the HBM traffic / matrix-busy figures of THIS library
 for wl in k1 k2 k4; do bash tools/pmc_traffic.sh $wl > $OUT/pmc_traffic_$wl.log 2>&1; cp gpurun_out/pmc/traffic_$wl.json profiles/r06_pmc_traffic_$wl.json; done
