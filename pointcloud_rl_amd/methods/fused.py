@@ -220,11 +220,6 @@ class FusedStep:
         self.publish_first = True          # the metrics leave BEFORE the step's last optimizer pass (the host's turn-around overlaps it)
         self.ln_rider = True               # the feature LayerNorm's backward rides on the encoder backward's prep launch (one node fewer)
         self.gather_rider = True           # the metrics are gathered / published by the first workgroup of the published pass (one node fewer)
-        # A captured step is TWO graphs: [sampling launch + first encoder pass] and [the rest].  hipGraphLaunch costs the host ~7 us + ~0.4 us a
-        # node and the device starts when it returns (tools/probes/graph_launch_cost.py): the short head starts the device ~10 us earlier and
-        # the launch of the rest hides under the encoder pass.  `steps` yields ("split", []) at the cut; only a capture acts on it (`on_split`).
-        self.head_split = False
-        self.on_split = None
         self._entry_cols = None            # (M, group) of a column-gather job attach_entry() has already attached for the next critic phase
 
     def _policy_tail_fits(self, M, bwd=False):
@@ -358,8 +353,6 @@ class FusedStep:
         try:
             kind, pieces = next(gen)
             while True:
-                if kind == "split" and self.on_split is not None:
-                    self.on_split()
                 for t in pieces:
                     ex.start(t)
                 kind, pieces = gen.send(ex.finish() if kind == "finish" else None)
@@ -415,8 +408,6 @@ class FusedStep:
         self.last_pooled = pooled_o          # (with it: which channels are live -- bench.py counts the backward's active points and tiles)
         if fold_c:
             hip.pack_flush_cols()            # (a phase whose weights needed no re-pack: the gather as a launch of its own)
-        if self.head_split:
-            yield ("split", [])              # no branch of the step is open here: a capture may end one graph and begin the next
         prepared = self._fork_prepare(enc, ctx_o, argmax_o)
         qn_h1, qn_h2 = self._buf("qn_h1", 2, M, H), self._buf("qn_h2", 2, M, H)
         q_next = self._buf("q_next", M, 2)

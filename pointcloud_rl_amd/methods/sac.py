@@ -808,8 +808,6 @@ class SAC(BaseAgent):
         pinned = torch.empty(16, dtype=torch.float32, pin_memory=True)     # allocated outside the capture
         key = (do_actor, polyak, exchanging)
         self._graph_flag.pop(key, None)
-        if self._fused is not None and self._fused.head_split:
-            return self._capture_head_and_rest(batch, do_actor, polyak, pre, exchanging, pinned, key)
         # thread_local: the process group's watchdog thread may touch the HIP runtime while this thread captures
         with _no_gc(), torch.cuda.graph(graph, **(dict(capture_error_mode="thread_local") if exchanging else {})):
             if pre is not None:
@@ -825,55 +823,6 @@ class SAC(BaseAgent):
                 host = pinned[:len(names)]
                 host.copy_(out, non_blocking=True)
         return [(graph, ("finish", []))], names, (host if host is not None else out)
-
-    def _capture_head_and_rest(self, batch, do_actor, polyak, pre, exchanging, pinned, key):
-        """`_capture_whole` as TWO graphs of one memory pool, cut where FusedStep.steps says ("split"): the sampling launch and the first
-        encoder pass, then everything else (the collectives of a data-parallel step with it).  Same launches in the same order; the host
-        launches the second graph while the device runs the first."""
-        pool = torch.cuda.graph_pool_handle()
-        opts = dict(capture_error_mode="thread_local") if exchanging else {}
-        graphs, open_ctx = [torch.cuda.CUDAGraph()], []
-
-        def begin():
-            ctx = torch.cuda.graph(graphs[-1], pool=pool, **opts)
-            ctx.__enter__()
-            open_ctx.append(ctx)
-
-        def cut():
-            open_ctx.pop().__exit__(None, None, None)
-            graphs.append(torch.cuda.CUDAGraph())
-            begin()
-
-        host = None
-        fused = self._fused
-        with _no_gc():
-            begin()
-            fused.on_split = cut
-            try:
-                if pre is not None:
-                    pre()
-                stats = self._step_body(batch, do_actor, polyak)
-                names = list(stats.keys())
-                packed = getattr(stats, "packed", None)
-                mirror = getattr(stats, "host", None)
-                out = packed if packed is not None else torch.stack([stats[k].reshape(()).float() for k in names])
-                if mirror is not None:
-                    self._graph_flag[key] = (mirror.numpy().view(np.uint32), len(names))
-                elif packed is not None:
-                    host = pinned[:len(names)]
-                    host.copy_(out, non_blocking=True)
-            except BaseException as err:
-                fused.on_split = None
-                while open_ctx:
-                    try:
-                        open_ctx.pop().__exit__(type(err), err, err.__traceback__)
-                    except Exception:
-                        pass
-                raise
-            fused.on_split = None
-            open_ctx.pop().__exit__(None, None, None)
-        segments = [(g, ("start", [])) for g in graphs[:-1]] + [(graphs[-1], ("finish", []))]
-        return segments, names, (host if host is not None else out)
 
     def _capture_segments(self, batch, do_actor, polyak, pre=None):
         """Data-parallel: one hipGraph per stretch between gradient exchanges; the RCCL all-reduces stay
