@@ -13,8 +13,8 @@ tail -1 $OUT/timeline_k1.txt $OUT/timeline_k1_b32.txt $OUT/timeline_k3_b128.txt
 grep -h "replay_gather" $OUT/timeline_k1_b32.txt
 DRY="--steps 20 --warmup 5 --no-extra-workloads --no-cpu-baseline --replay-capacity 512"
 fails=0; t0=$(date +%s)
-for i in $(seq 1 10); do
+for i in $(seq 1 ${LAUNCHES:-10}); do
   timeout 300 python bench.py --dry-run-ranks 8 $DRY > $OUT/F_$i.out 2> $OUT/F_$i.err; rc=$?
   if [ $rc -ne 0 ]; then fails=$((fails+1)); echo "rehearsal $i rc=$rc $(grep -m1 -o 'HSA_STATUS[A-Z_]*' $OUT/F_$i.err)"; else rm -f $OUT/F_$i.err $OUT/F_$i.out; fi
 done
-echo "== bench --dry-run-ranks 8 on $(cut -c1-8 $OUT/libpcrl_hip.sha256): $fails failed of 10 in $(( $(date +%s) - t0 )) s ==" | tee $OUT/final_loops.txt
+echo "== bench --dry-run-ranks 8 on $(cut -c1-8 $OUT/libpcrl_hip.sha256): $fails failed of ${LAUNCHES:-10} in $(( $(date +%s) - t0 )) s ==" | tee $OUT/final_loops.txt
